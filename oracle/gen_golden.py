@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference code (CPU) and stores inputs + outputs.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container (where /root/reference exists);
+never on the GPU box, never from the product path.  Only data (inputs / expected
+outputs) is written, as small .npz files under tests/golden/.  No reference source text
+is copied: the reference modules are imported from where they lie, with the import
+recipe of SURVEY.md section 8c (namespace packages so that the two __init__.py files are
+skipped, an empty `cv2` module, a stub for the Q-Former resampler that no longer imports
+on the installed transformers).
+
+Usage:  python oracle/gen_golden.py [--only NAME ...]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("V3D_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _import_reference():
+    def ns(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+        return m
+
+    ns("llava", REF + "/llava")
+    ns("llava.model", REF + "/llava/model")
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    q = types.ModuleType("llava.model.multimodal_resampler.qformer")
+
+    class Qformer:  # never instantiated on this path
+        pass
+
+    q.Qformer = Qformer
+    sys.modules["llava.model.multimodal_resampler.qformer"] = q
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def t2n(t):
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.int16).numpy().view(np.uint16)  # raw bits
+    return t.numpy()
+
+
+class _Tower:
+    num_patches_per_side = 27
+
+
+def make_arch(cfg_kw):
+    """A minimal concrete LlavaMetaForCausalLM so its mixin methods can be called."""
+    import llava.model.llava_arch as arch
+
+    class M(arch.LlavaMetaForCausalLM):
+        def __init__(self):
+            self.config = types.SimpleNamespace(**cfg_kw)
+            self.model = types.SimpleNamespace()
+
+        def get_model(self):
+            return self.model
+
+        def get_vision_tower(self):
+            return _Tower()
+
+    return M()
+
+
+DEFAULT_CFG = dict(mm_spatial_pool_mode="bilinear", mm_spatial_pool_stride=2, voxel_size=0.1,
+                   min_xyz_range=[-15, -15, -5], max_xyz_range=[15, 15, 5],
+                   world_position_embedding_type="avg-discrete-sin3d")
+
+
+# --------------------------------------------------------------------------------------
+def g_unproject():
+    from llava.video_utils import unproject
+    g = torch.Generator().manual_seed(1)
+    V, H, W = 3, 48, 64
+    depth = torch.randint(0, 6000, (V, H, W), generator=g, dtype=torch.int32)
+    depth[0, :4, :4] = 0  # invalid-depth pixels
+    K = torch.zeros(V, 4, 4)
+    for v in range(V):
+        K[v] = torch.tensor([[577.870605 + v, 0, 31.5 + 0.25 * v, 0], [0, 577.870605 - v, 23.5, 0],
+                             [0, 0, 1, 0], [0, 0, 0, 1]])
+    P = torch.zeros(V, 4, 4, dtype=torch.float64)
+    for v in range(V):
+        a, b = 0.3 + v, -0.2 * v
+        Rz = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        Rx = torch.tensor([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        P[v, :3, :3] = Rz @ Rx
+        P[v, :3, 3] = torch.tensor([1.5 * v - 1, 0.7, 1.2 + 0.1 * v])
+        P[v, 3, 3] = 1
+    P = P.float()
+    out = unproject(K, P, depth.float())
+    save("unproject", depth=depth.numpy().astype(np.uint16), intrinsics=K.numpy(), poses=P.numpy(),
+         world=out.numpy())
+
+
+def _coords_frame(seed, V=1):
+    """Plausible world coords whose values are all fp16-representable (so one file serves both dtypes)."""
+    g = torch.Generator().manual_seed(seed)
+    base = (torch.rand(V, 384, 384, 3, generator=g) - 0.5) * torch.tensor([12.0, 12.0, 4.0])
+    base[:, :27, :27] = 20.0 + base[:, :27, :27]      # first patch beyond the +15 clamp
+    base[:, 27:54, :27] = -20.0 + base[:, 27:54, :27]  # below the -15 clamp
+    return base.half()
+
+
+def g_coord_pool():
+    m = make_arch(DEFAULT_CFG)
+    x16 = _coords_frame(2)
+    x32 = x16.float() * np.float32(1.001) + np.float32(0.0003)  # full-mantissa f32 variant (IEEE-deterministic)
+    o32 = m.average_coordinate_in_patch(x32)
+    o16 = m.average_coordinate_in_patch(x16)
+    d32 = m.discrete_coords(o32, None)
+    d16 = m.discrete_coords(o16, None)
+    save("coord_pool", coords_f16=x16.numpy(), avg_f32=o32.numpy(), avg_f16=o16.numpy(),
+         vox_f32=d32.numpy(), vox_f16=d16.numpy())
+
+
+def g_discrete():
+    m = make_arch(DEFAULT_CFG)
+    # exhaustive fp16: every finite bit pattern, used as x, y and z
+    bits = np.arange(65536, dtype=np.uint16)
+    h = torch.from_numpy(bits.view(np.float16).copy())
+    finite = torch.isfinite(h)
+    hx = h[finite]
+    xyz16 = torch.stack([hx, hx, hx], -1)
+    out16 = m.discrete_coords(xyz16, None)
+    # f32: exact ties, near ties, out of range, random
+    g = torch.Generator().manual_seed(3)
+    ks = torch.arange(0, 301, dtype=torch.float32)
+    ties = (ks + 0.5) * 0.1 - 15.0
+    f = torch.cat([ties, torch.nextafter(ties, torch.tensor(100.0)), torch.nextafter(ties, torch.tensor(-100.0)),
+                   torch.tensor([-1e9, -15.0, -15.00001, 15.0, 15.00001, 1e9, 0.0, -0.0, 0.05, 0.15, 0.25]),
+                   (torch.rand(20000, generator=g) - 0.5) * 40])
+    xyz32 = torch.stack([f, f.flip(0), f * (1.0 / 3.0)], -1)
+    out32 = m.discrete_coords(xyz32, None)
+    save("discrete_coords", finite_mask=finite.numpy(), vox_f16=out16.numpy(), xyz_f32=xyz32.numpy(),
+         vox_f32=out32.numpy())
+    # VideoProcessor.discrete_point (host, int output)
+    from llava.video_utils import VideoProcessor
+    vp = object.__new__(VideoProcessor)
+    vp.voxel_size = 0.1
+    vp.min_xyz_range = None
+    vp.max_xyz_range = None
+    pts = ((torch.rand(500, 3, generator=g) - 0.5) * 20).tolist() + [[0, 0, 0], [0.05, 0.15, 0.25], [-0.05, -0.15, -0.25]]
+    a = vp.discrete_point(pts)
+    vp.min_xyz_range = torch.tensor([-15, -15, -5])
+    vp.max_xyz_range = torch.tensor([15, 15, 5])
+    b = vp.discrete_point(pts)
+    save("discrete_point", pts=np.array(pts, dtype=np.float64), ids_norange=np.array(a, dtype=np.int32),
+         ids_range=np.array(b, dtype=np.int32))
+
+
+def g_sin3d():
+    from llava.model.position_encoding import PositionEmbeddingSine3D
+    pe = PositionEmbeddingSine3D(3584)
+    ids = torch.arange(301, dtype=torch.float32)
+    x = torch.stack([ids, ids.flip(0), ids.clamp(max=100)], -1)[None]     # [1,301,3]
+    out = pe(x)[0]                                                          # [301,3584] f32
+    nf = 3584 // 3
+    d = torch.arange(nf, dtype=torch.float32)
+    dim_t = 10000 ** (2 * (d // 2) / nf)   # same expression, same CPU pow as the module evaluates
+    tab = out[:, :nf]
+    assert torch.equal(out[:, nf:2 * nf], tab.flip(0))
+    assert torch.equal(out[:101, 2 * nf:3 * nf], tab[:101])
+    assert torch.equal(out[:, 3 * nf:], torch.zeros(301, 2))
+    save("sin3d_table_3584", dim_t=dim_t.numpy(), table=tab.numpy())
+    # fp16 / bf16 inputs -> output is cast to the input dtype
+    g = torch.Generator().manual_seed(4)
+    xi = torch.stack([torch.randint(0, 301, (64,), generator=g), torch.randint(0, 301, (64,), generator=g),
+                      torch.randint(0, 101, (64,), generator=g)], -1)[None].float()
+    o16 = pe(xi.half())
+    ob16 = pe(xi.bfloat16())
+    save("sin3d_tokens_3584", ids=xi.numpy().astype(np.int32), pe_f16=o16.numpy(), pe_bf16_bits=t2n(ob16))
+    # odd num_feats branch (embedding 16 -> num_feats 5) and continuous (non-integer) coords, small width
+    pe16 = PositionEmbeddingSine3D(16)
+    xc = (torch.rand(1, 50, 3, generator=g) - 0.5) * 30
+    o = pe16(xc)
+    pe96 = PositionEmbeddingSine3D(96)
+    o96 = pe96(xc)
+    d5 = torch.arange(5, dtype=torch.float32)
+    d32 = torch.arange(32, dtype=torch.float32)
+    save("sin3d_small", xyz=xc.numpy(), pe16=o.numpy(), pe96=o96.numpy(),
+         dim_t5=(10000 ** (2 * (d5 // 2) / 5)).numpy(), dim_t32=(10000 ** (2 * (d32 // 2) / 32)).numpy())
+
+
+def g_pool2d():
+    m = make_arch(DEFAULT_CFG)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 729, 64, generator=g)
+    o32 = m.get_2dPool(x)
+    o16 = m.get_2dPool(x.half())
+    ob = m.get_2dPool(x.bfloat16())
+    save("pool2d_bilinear", feat=x.numpy(), out_f32=o32.numpy(), out_f16=o16.numpy(), out_bf16_bits=t2n(ob))
+
+
+def g_newline():
+    m = make_arch(DEFAULT_CFG)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 196, 8, generator=g)
+    m.model.image_newline = torch.randn(8, generator=g)
+    o = m.add_token_per_grid(x)
+    save("add_token_per_grid", feat=x.numpy(), newline=m.model.image_newline.numpy(), out=o.contiguous().numpy())
+
+
+def g_fused():
+    """pool -> voxel PE -> add -> newline, composed exactly as prepare_inputs_labels_for_multimodal does
+    (llava_arch.py:395-420, 469, 506-517, 536) but at a small channel width (C=96)."""
+    from llava.model.position_encoding import PositionEmbeddingSine3D
+    C = 96
+    m = make_arch(DEFAULT_CFG)
+    pe = PositionEmbeddingSine3D(C)
+    g = torch.Generator().manual_seed(7)
+    coords = _coords_frame(8, V=2)
+    feats = torch.randn(2, 729, C, generator=g)
+    m.model.image_newline = torch.randn(C, generator=g)
+    out = {}
+    for name, dt in (("f16", torch.float16), ("bf16", torch.bfloat16), ("f32", torch.float32)):
+        wc = coords.to(dt)
+        f = feats.to(dt)
+        avg = m.average_coordinate_in_patch(wc)
+        vox = m.discrete_coords(avg, None)
+        pooled = m.get_2dPool(f)
+        fused = pooled + pe(vox.flatten(1, 2).detach())
+        old = m.model.image_newline
+        m.model.image_newline = old.to(dt)
+        seq = m.add_token_per_grid(fused).contiguous()
+        m.model.image_newline = old
+        out["vox_" + name] = vox.float().numpy()
+        out["seq_" + name] = t2n(seq) if dt == torch.bfloat16 else seq.numpy()
+    d = torch.arange(C // 3, dtype=torch.float32)
+    save("fused_small", coords_f16=coords.numpy(), feat=feats.numpy(), newline=m.model.image_newline.numpy(),
+         dim_t=(10000 ** (2 * (d // 2) / (C // 3))).numpy(), **out)
+
+
+def g_frames():
+    from llava.video_utils import VideoProcessor
+    vp = object.__new__(VideoProcessor)
+    vp.video_folder = "data"
+    res = {}
+    for n in (8, 31, 32, 33, 100, 517, 1):
+        vp.scene = {"s": {"images": [{"img_path": f"posed_images/s/{i * 10:05d}.jpg"} for i in range(n)]}}
+        for F in (8, 32):
+            files = vp.sample_frame_files("s", force_sample=True, frames_upbound=F)
+            res[f"n{n}_F{F}"] = [int(os.path.basename(f).split(".")[0]) // 10 for f in files]
+        files = vp.sample_frame_files("s", force_sample=False, frames_upbound=F)
+        res[f"n{n}_default"] = [int(os.path.basename(f).split(".")[0]) // 10 for f in files]
+    # max-coverage prefix / ratio cuts
+    rnd = random.Random(9)
+    order = list(range(60))
+    rnd.shuffle(order)
+    voxel_nums = sorted([rnd.randint(1, 900) for _ in range(40)], reverse=True)
+    entry = {"video_id": "s", "frame_files": [f"data/posed_images/s/{i * 20:05d}.jpg" for i in order[:40]],
+             "voxel_nums": voxel_nums, "num_all_voxels": int(sum(voxel_nums) * 1.04)}
+    mc = {}
+    for strat in ("mc", "mc-ratio90", "mc-ratio95"):
+        for F in (8, 16, 32):
+            vp.frame_sampling_strategy = strat
+            vp.mc_sampling_files = {"s": json.loads(json.dumps(entry))}
+            mc[f"{strat}_F{F}"] = vp.sample_frame_files_mc("s", frames_upbound=F)
+    with open(os.path.join(OUT, "frame_sampling.json"), "w") as f:
+        json.dump({"uniform": res, "mc_entry": entry, "mc": mc}, f)
+    print("  wrote frame_sampling.json")
+
+
+def g_greedy():
+    """Greedy max-coverage selection: executes the reference's own loop
+    (scripts/3d/preprocessing/max_coverage_sampling.py:44-94) on synthetic voxel sets, with the
+    unseeded random.choice tie-break replaced by "first candidate" (= lowest position in frame order)."""
+    path = REF + "/scripts/3d/preprocessing/max_coverage_sampling.py"
+    with open(path) as f:
+        lines = f.read().split("\n")
+    # lines 43..94 (1-based) of main(): from `world_coords = world_coords / voxel_size` to the break
+    start = next(i for i, l in enumerate(lines) if "world_coords = world_coords / video_processor.voxel_size" in l)
+    end = next(i for i, l in enumerate(lines) if "if len(select_frame_files) >= 32:" in l) + 2
+    body = "\n".join(l[8:] if l.startswith("        ") else l for l in lines[start:end])
+    body = body.replace("world_coords.to('cuda')", "world_coords")
+    from llava.video_utils import VideoProcessor
+    cases = {}
+    for case, (n_frames, seed) in {"a": (40, 11), "b": (12, 12), "c": (70, 13)}.items():
+        g = torch.Generator().manual_seed(seed)
+        H, W = 24, 32
+        centers = (torch.rand(n_frames, 1, 1, 3, generator=g) - 0.5) * torch.tensor([6.0, 6.0, 1.0])
+        wc = centers + (torch.rand(n_frames, H, W, 3, generator=g) - 0.5) * torch.tensor([2.5, 2.5, 1.5])
+        if case == "b":
+            wc[5] = wc[2]  # exact duplicate frames -> forced ties
+            wc[7] = wc[2]
+        frame_files = [f"f{i:03d}.jpg" for i in range(n_frames)]
+        vp = object.__new__(VideoProcessor)
+        vp.voxel_size = 0.1
+        vp.min_xyz_range = None
+        vp.max_xyz_range = None
+        scene_pts = (wc.reshape(-1, 3)[torch.randperm(wc.numel() // 3, generator=g)[: wc.numel() // 4]]).tolist()
+        pc = list(set(tuple(x) for x in vp.discrete_point(scene_pts)))
+
+        class FirstChoice:
+            @staticmethod
+            def choice(seq):
+                return seq[0]
+
+        ns = dict(world_coords=wc.clone(), video_processor=vp, frame_files=frame_files, torch=torch, np=np,
+                  random=FirstChoice, pc_data={"s": pc}, scene_id="s", world_coords_discrete={})
+        exec(compile(body, "<reference greedy loop>", "exec"), ns)
+        cases[case] = dict(
+            world=wc.numpy(), pc=np.array(pc, dtype=np.int32),
+            select=np.array([frame_files.index(f) for f in ns["select_frame_files"]], dtype=np.int32),
+            voxel_nums=np.array(ns["voxel_nums"], dtype=np.int64),
+            num_all=np.int64(len(ns["all_voxel"] & ns["pc_voxel"])),
+            num_sel=np.int64(len(ns["used_voxel"] & ns["pc_voxel"])))
+    flat = {f"{c}_{k}": v for c, d in cases.items() for k, v in d.items()}
+    save("greedy_cover", **flat)
+
+
+def g_box():
+    from llava.utils_3d import convert_pc_to_box
+    g = np.random.default_rng(14)
+    pc = g.normal(size=(200, 6)).astype(np.float32)
+    c, s = convert_pc_to_box(pc)
+    save("convert_pc_to_box", pc=pc, center=np.array(c), size=np.array(s))
+
+
+GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    _import_reference()
+    torch.set_num_threads(4)
+    for name, fn in GENS.items():
+        if a.only and name not in a.only:
+            continue
+        print(f"[{name}]")
+        with torch.no_grad():
+            fn()
+
+
+if __name__ == "__main__":
+    main()
