@@ -1,0 +1,137 @@
+/*
+ * v3d.h - C ABI of libv3d_hip.so: the MI355X (gfx950) hot path of Video-3D-LLM's
+ * position-aware video -> LLM forward path.
+ *
+ * The reference (zd11024/Video-3D-LLM) is pure Python: it has no FFI for this path.  The
+ * boundary is therefore the set of PyTorch calls its hot path makes; each entry point below
+ * names the reference site (file:line under the reference checkout) whose arithmetic it
+ * replaces.  The host-side mirror (video-3d-llm_amd/llava/...) binds these with ctypes; see
+ * INTEGRATION.md for the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all entry points are
+ *     asynchronous with respect to the host, allocate nothing, keep no pointer after return
+ *     and are re-entrant;
+ *   - return value: 0 = ok, negative = error (V3D_E_*); the message for the calling thread is
+ *     returned by v3d_last_error();
+ *   - dtype codes: V3D_F32 / V3D_F16 / V3D_BF16.  16-bit tensors are raw IEEE half / bfloat16.
+ *   - tensors are dense row-major unless a row stride (in elements) is passed explicitly.
+ */
+#ifndef V3D_H_
+#define V3D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V3D_ABI_VERSION 1
+
+enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
+
+enum {
+  V3D_OK = 0,
+  V3D_E_INVALID = -1,   /* bad argument (null pointer, shape or alignment the kernel cannot take) */
+  V3D_E_LAUNCH = -2,    /* HIP reported a launch/runtime error */
+  V3D_E_UNSUPPORTED = -3
+};
+
+int v3d_abi_version(void);
+const char* v3d_last_error(void);
+
+/* ------------------------------------------------------------------ geometry (K1-K4) ---- */
+
+/* K1  llava/video_utils.py:38-68 `unproject`.
+ * depth_mm [V,H,W] f32 millimetres, intrinsics/poses [V,4,4] f32 -> world [V,H,W,3] f32. */
+int v3d_unproject_f32(const float* depth_mm, const float* intrinsics, const float* poses,
+                      float* world, int V, int H, int W, void* stream);
+
+/* K1+K2  `unproject` evaluated only at the pixels that survive the nearest-neighbour resize
+ * (cv2.resize INTER_NEAREST to (int(W*crop/H), crop)) and centre crop of
+ * llava/video_utils.py:296-308.  depth [V,H,W] uint16 PNG values (the reference converts
+ * u16 -> int32 -> f32, video_utils.py:217,230).  out [V,crop,crop,3] in out_dtype
+ * (f32 = the tensor VideoProcessor returns; f16/bf16 = after the eval driver's
+ * `.half()` / model-dtype cast, llava/eval/model_scanqa.py:163-165). */
+int v3d_unproject_sampled_u16(const uint16_t* depth, const float* intrinsics, const float* poses,
+                              void* out, int out_dtype, int V, int H, int W, int crop, void* stream);
+
+/* K3+K4  llava/model/llava_arch.py:213-223 `average_coordinate_in_patch` and :259-272
+ * `discrete_coords`.  coords [V,S,S,3] (dtype), the last S - n*patch rows/cols are dropped
+ * (n = (S-6)/patch when S==384, patch==27 -> n = 14).  The 27x27 mean is accumulated in f32
+ * in the reference's own (row, column) order so that voxel ids are bit-exact.
+ * Outputs (any may be NULL): avg [V,n,n,3] dtype; vox [V,n,n,3] dtype (integer-valued floats,
+ * what the reference returns); ids [V,n,n,3] int32.
+ * min_xyz_host/max_xyz_host: 3 floats each on the HOST (config.min_xyz_range / max_xyz_range). */
+int v3d_coord_pool_voxel(const void* coords, int dtype, int V, int S, int patch,
+                         const float* min_xyz_host, const float* max_xyz_host, float voxel_size,
+                         void* avg, void* vox, int32_t* ids, void* stream);
+
+/* K4 alone on arbitrary points: xyz [N,3] dtype -> vox [N,3] dtype and/or ids [N,3] int32
+ * (box centres / box_input path, llava_arch.py:416-420). */
+int v3d_discrete_coords(const void* xyz, int dtype, int64_t N, const float* min_xyz_host,
+                        const float* max_xyz_host, float voxel_size, void* vox, int32_t* ids,
+                        void* stream);
+
+/* ------------------------------------------------------------------ 3-D sinusoid (K5) --- */
+
+/* Number of elements of one row of the shifted 16-byte-aligned PE table for `embedding_size`
+ * channels of `dtype` (see v3d_sin3d_table_build). */
+int64_t v3d_sin3d_table_row_elems(int embedding_size, int dtype);
+
+/* llava/model/position_encoding.py:17-49 evaluated for every integer coordinate 0..n_ids-1.
+ * dim_t [num_feats = embedding_size/3] f32 is supplied by the caller (the reference computes
+ * `temperature ** (2*(i//2)/num_feats)` with torch's pow, :24-25; pow is not bit-reproducible
+ * across libraries so it stays on the caller's side of the boundary).
+ * table [3][n_ids][row_elems] dtype: axis a's copy is shifted by (a*num_feats) % (16/sizeof)
+ * elements so that the fused kernel reads whole 16-byte vectors; padding is zero.
+ * table_f32 (nullable) [n_ids][num_feats] f32: the unshifted f32 values. */
+int v3d_sin3d_table_build(const float* dim_t, int embedding_size, int n_ids, int dtype,
+                          void* table, float* table_f32, void* stream);
+
+/* PositionEmbeddingSine3D.forward for arbitrary (also non-integer) coordinates:
+ * xyz [N,3] dtype -> out [N,embedding_size] dtype; f32 math, output cast to dtype (:46-47). */
+int v3d_sin3d_pe(const void* xyz, int dtype, int64_t N, const float* dim_t, int embedding_size,
+                 void* out, void* stream);
+
+/* ------------------------------------------------------------------ fusion (K5-K8) ------ */
+
+/* The north-star kernel.  One pass over the projector output:
+ *   K7  get_2dPool bilinear side x side -> n x n            llava_arch.py:191-210   (flag POOL)
+ *   K5+K6  + PE(voxel ids) from the table                    llava_arch.py:506-517   (flag PE)
+ *   K8  add_token_per_grid: `newline` after each row of n    llava_arch.py:307-328   (flag NEWLINE)
+ * feat  [V, side*side, C] if POOL else [V, n*n, C]           (dtype)
+ * ids   [V, n*n, 3] int32 voxel ids (PE only)
+ * table from v3d_sin3d_table_build for (C, dtype), n_ids rows per axis (PE only)
+ * newline [C] dtype (NEWLINE only)
+ * out   rows of C elements, row stride out_stride elements: V*n*(n+1) rows if NEWLINE else V*n*n.
+ * Rounding follows the reference: pooled value rounded to dtype, then the add rounded to dtype. */
+enum { V3D_VT_POOL = 1, V3D_VT_PE = 2, V3D_VT_NEWLINE = 4 };
+int v3d_visual_tokens(const void* feat, const int32_t* ids, const void* table, int n_ids,
+                      const void* newline, void* out, int64_t out_stride, int dtype, int V, int side,
+                      int n, int C, int flags, void* stream);
+
+/* K9  embed_tokens gather for the text segments (llava_arch.py:693): out[i,:] = table[ids[i],:]. */
+int v3d_embed_gather(const void* table, int64_t vocab, int C, const int64_t* ids, int64_t n,
+                     void* out, int64_t out_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ host helpers -------- */
+
+/* a1  llava/video_utils.py:187  np.linspace(0, total-1, n, dtype=int).  out_host[n]. */
+int v3d_uniform_frame_indices_host(int total_frames, int n, int32_t* out_host);
+
+/* a3  scripts/3d/preprocessing/max_coverage_sampling.py:44-94 greedy max-coverage with the tie
+ * rule "lowest frame position" (the reference draws random.choice, unseeded, :84).
+ * keys_host [n_frames, pts_per_frame, 3] int32 voxel keys (round(xyz/voxel)), scene_host [m,3]
+ * int32 scene voxel set.  Writes up to max_frames picks: sel_host (frame positions), gain_host
+ * (voxel_nums), and the two totals.  Returns the number of picks or a negative error. */
+int v3d_greedy_cover_host(const int32_t* keys_host, int n_frames, int64_t pts_per_frame,
+                          const int32_t* scene_host, int64_t m, int max_frames, int32_t* sel_host,
+                          int64_t* gain_host, int64_t* num_all_host, int64_t* num_sel_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V3D_H_ */

@@ -1,0 +1,78 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/v3d.h declares,
+rejects bad arguments with a message, and its host-only helpers match the reference goldens."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from v3d import _native, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "v3d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(v3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.lib()
+    names = declared_symbols()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/v3d.h but not exported"
+        assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
+    assert lib.v3d_abi_version() == 1
+
+
+def test_invalid_arguments_report_an_error():
+    lib = _native.lib()
+    rc = lib.v3d_unproject_f32(None, None, None, None, 1, 1, 1, None)
+    assert rc == -1
+    assert b"null pointer" in lib.v3d_last_error()
+    with pytest.raises(_native.V3DError):
+        ops.uniform_frame_indices(0, 4)
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    with pytest.raises(_native.V3DError, match="no CPU path"):
+        ops.unproject(torch.eye(4)[None], torch.eye(4)[None], torch.zeros(1, 4, 4))
+
+
+def test_uniform_frame_indices_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "frame_sampling.json")) as f:
+        g = json.load(f)["uniform"]
+    for key, want in g.items():
+        n = int(key.split("_")[0][1:])
+        F = 10 if key.endswith("default") else int(key.split("_F")[1])
+        assert ops.uniform_frame_indices(n, F) == want, key
+    # against numpy for a sweep
+    for n in range(1, 700, 7):
+        for F in (1, 2, 8, 10, 32):
+            assert ops.uniform_frame_indices(n, F) == np.linspace(0, n - 1, F, dtype=int).tolist()
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_greedy_cover_golden(golden, case):
+    g = golden("greedy_cover")
+    keys = np.rint(g[case + "_world"].astype(np.float32) / np.float32(0.1)).astype(np.int32)
+    sel, gains, n_all, n_sel = ops.greedy_cover(keys, g[case + "_pc"])
+    assert sel.tolist() == g[case + "_select"].tolist()
+    assert gains.tolist() == g[case + "_voxel_nums"].tolist()
+    assert n_all == int(g[case + "_num_all"]) and n_sel == int(g[case + "_num_sel"])
+
+
+def test_greedy_cover_edge_cases():
+    # one frame, empty scene set, duplicate frames (ties -> lowest position)
+    keys = np.zeros((3, 4, 3), np.int32)
+    keys[1] = 5
+    sel, gains, n_all, n_sel = ops.greedy_cover(keys, np.zeros((0, 3), np.int32))
+    assert sel.tolist() == [0, 1, 2] and gains.tolist() == [0, 0, 0] and n_all == 0 and n_sel == 0
+    sel, gains, n_all, n_sel = ops.greedy_cover(keys, np.array([[0, 0, 0], [5, 5, 5]], np.int32))
+    assert sel.tolist() == [0, 1, 2] and gains.tolist() == [1, 1, 0] and n_all == 2 and n_sel == 2
+    with pytest.raises(_native.V3DError):
+        ops.greedy_cover(np.full((1, 1, 3), 1 << 22, np.int32), np.zeros((1, 3), np.int32))

@@ -1,0 +1,315 @@
+// Geometry kernels: depth back-projection (K1, K1+K2), per-patch coordinate mean and
+// voxelisation (K3+K4).  All HBM-bound byte/float streaming; no MFMA.
+//
+// Compiled with -ffp-contract=off: every f32 operation below is a single IEEE operation in the
+// order written, so results are reproducible against the CPU oracle.
+#include "v3d_common.h"
+
+namespace v3d {
+
+// ----------------------------------------------------------------------------------------
+// K1  unproject  (llava/video_utils.py:38-68)
+//   z = d/1000; x = (u-cx)*z/fx; y = (v-cy)*z/fy; w = P @ [x,y,z,1]; out = w[:3]/w[3]
+// One thread = 4 consecutive pixels of a row: one 16-B depth load, three 16-B stores.
+// ----------------------------------------------------------------------------------------
+struct Cam {
+  float fx, fy, cx, cy;
+  float p[16];
+};
+
+__device__ __forceinline__ Cam load_cam(const float* K, const float* P, int v) {
+  Cam c;
+  const float* k = K + (size_t)v * 16;
+  c.fx = k[0]; c.fy = k[5]; c.cx = k[2]; c.cy = k[6];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.p[i] = P[(size_t)v * 16 + i];
+  return c;
+}
+
+__device__ __forceinline__ void backproject(const Cam& c, float u, float v, float d, float* o) {
+  const float z = __fdiv_rn(d, 1000.0f);
+  const float x = __fdiv_rn(__fmul_rn(__fsub_rn(u, c.cx), z), c.fx);
+  const float y = __fdiv_rn(__fmul_rn(__fsub_rn(v, c.cy), z), c.fy);
+  float w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // sequential 4-term dot, one rounding per operation
+    float s = __fmul_rn(c.p[i * 4 + 0], x);
+    s = __fadd_rn(s, __fmul_rn(c.p[i * 4 + 1], y));
+    s = __fadd_rn(s, __fmul_rn(c.p[i * 4 + 2], z));
+    s = __fadd_rn(s, c.p[i * 4 + 3]);
+    w[i] = s;
+  }
+  o[0] = __fdiv_rn(w[0], w[3]);
+  o[1] = __fdiv_rn(w[1], w[3]);
+  o[2] = __fdiv_rn(w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void unproject_f32_kernel(const float* __restrict__ depth,
+                                                            const float* __restrict__ K,
+                                                            const float* __restrict__ P,
+                                                            float* __restrict__ world, int H, int W,
+                                                            int quads_per_frame) {
+  const int v = blockIdx.y;
+  const Cam c = load_cam(K, P, v);
+  const size_t frame = (size_t)v * H * W;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < quads_per_frame; q += gridDim.x * blockDim.x) {
+    const int pix = q * 4;
+    const int row = pix / W, col = pix - row * W;
+    const float4 d = *reinterpret_cast<const float4*>(depth + frame + pix);
+    float o[12];
+    backproject(c, (float)(col + 0), (float)row, d.x, o + 0);
+    backproject(c, (float)(col + 1), (float)row, d.y, o + 3);
+    backproject(c, (float)(col + 2), (float)row, d.z, o + 6);
+    backproject(c, (float)(col + 3), (float)row, d.w, o + 9);
+    float4* dst = reinterpret_cast<float4*>(world + (frame + pix) * 3);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+  }
+}
+
+__global__ __launch_bounds__(256) void unproject_f32_scalar_kernel(const float* __restrict__ depth,
+                                                                   const float* __restrict__ K,
+                                                                   const float* __restrict__ P,
+                                                                   float* __restrict__ world, int H, int W) {
+  const int v = blockIdx.y;
+  const Cam c = load_cam(K, P, v);
+  const size_t frame = (size_t)v * H * W;
+  const int n = H * W;
+  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += gridDim.x * blockDim.x) {
+    const int row = pix / W, col = pix - row * W;
+    float o[3];
+    backproject(c, (float)col, (float)row, depth[frame + pix], o);
+    float* dst = world + (frame + pix) * 3;
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// K1+K2  back-projection at the pixels kept by resize(INTER_NEAREST)+centre-crop
+// (llava/video_utils.py:296-308).  OpenCV rule: src = min(floor(dst * src/dst_size), src-1),
+// computed in double like cv::resize does.  One thread = one output pixel (3 values).
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void unproject_sampled_kernel(const uint16_t* __restrict__ depth,
+                                                                const float* __restrict__ K,
+                                                                const float* __restrict__ P,
+                                                                T* __restrict__ out, int H, int W, int crop,
+                                                                int new_w, int left, double inv_fx, double inv_fy) {
+  const int v = blockIdx.y;
+  const Cam c = load_cam(K, P, v);
+  const int n = crop * crop;
+  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += gridDim.x * blockDim.x) {
+    const int r = pix / crop, col = pix - r * crop;
+    int sr = (int)floor((double)r * inv_fy);
+    int sc = (int)floor((double)(col + left) * inv_fx);
+    sr = sr < H - 1 ? sr : H - 1;
+    sc = sc < W - 1 ? sc : W - 1;
+    const float d = (float)(int)depth[((size_t)v * H + sr) * W + sc];
+    float o[3];
+    backproject(c, (float)sc, (float)sr, d, o);
+    T* dst = out + ((size_t)v * n + pix) * 3;
+    dst[0] = from_f32<T>(o[0]); dst[1] = from_f32<T>(o[1]); dst[2] = from_f32<T>(o[2]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// K4  discrete_coords (llava/model/llava_arch.py:259-272), torch-on-CPU dtype rules
+// (pinned exhaustively for fp16 by tests/golden/discrete_coords.npz):
+//   clamp; t = T(x - lo); q = T(float(t) / float(voxel)); r = rint(q)
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float voxelise(float x, float lo, float hi, float voxel) {
+  // torch.maximum / minimum propagate NaN
+  if (x == x) {
+    x = x < lo ? lo : x;
+    x = x > hi ? hi : x;
+  }
+  const float t = round_to<T>(__fsub_rn(x, lo));
+  const float q = round_to<T>(__fdiv_rn(t, voxel));
+  return rintf(q);
+}
+
+struct Range { float lo[3], hi[3], voxel; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void discrete_coords_kernel(const T* __restrict__ xyz, int64_t n3, Range rg,
+                                                              T* __restrict__ vox, int32_t* __restrict__ ids) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(i % 3);
+    const float r = voxelise<T>(to_f32(xyz[i]), round_to<T>(rg.lo[a]), round_to<T>(rg.hi[a]), rg.voxel);
+    if (vox) vox[i] = from_f32<T>(r);
+    if (ids) ids[i] = (int32_t)r;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// K3+K4  average_coordinate_in_patch + discrete_coords (llava_arch.py:213-223, 259-272)
+//
+// One workgroup = one (frame, patch-row): n patches x 3 channels = 3n running sums.  The
+// reference (ATen avg_pool2d, CPU and CUDA alike) adds the patch*patch values of a window one
+// by one in (row, column) order in f32; voxel ids are only bit-exact if we add in the same
+// order, so the sum itself is a 729-long dependent chain per output.  To keep HBM busy anyway
+// the whole workgroup streams rows of the strip into LDS with 16-byte loads (coalesced, full
+// 128-B lines) a chunk of rows at a time, and lanes 0..3n-1 walk the chunk out of LDS.
+// ----------------------------------------------------------------------------------------
+constexpr int kPoolChunkRows = 9;
+
+template <typename T, int PATCH>
+__global__ __launch_bounds__(256) void coord_pool_voxel_kernel(const T* __restrict__ coords, int S, int patch_rt,
+                                                               int n, Range rg, T* __restrict__ avg,
+                                                               T* __restrict__ vox, int32_t* __restrict__ ids,
+                                                               int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* buf = reinterpret_cast<float*>(smem_raw);
+  const int patch = PATCH > 0 ? PATCH : patch_rt;
+  const int v = blockIdx.y, py = blockIdx.x;
+  const int row_elems = S * 3;              // full image row, the unused tail rides along
+  const int tid = threadIdx.x;
+  constexpr int VEC = 16 / sizeof(T);
+  const T* strip = coords + ((size_t)v * S + (size_t)py * patch) * row_elems;
+
+  const int lanes = n * 3;
+  const int px = tid / 3, ch = tid - px * 3;
+  float s = 0.0f;
+
+  for (int r0 = 0; r0 < patch; r0 += kPoolChunkRows) {
+    const int rows = (patch - r0) < kPoolChunkRows ? (patch - r0) : kPoolChunkRows;
+    const T* src = strip + (size_t)r0 * row_elems;
+    const int total = rows * row_elems;
+    if (vec_ok) {
+      const uint4* src4 = reinterpret_cast<const uint4*>(src);
+      for (int i = tid; i < total / VEC; i += blockDim.x) {
+        const uint4 raw = src4[i];
+        float f[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = vec_get<T>(raw, j);
+        float4* d4 = reinterpret_cast<float4*>(buf + (size_t)i * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC / 4; ++j) d4[j] = make_float4(f[4 * j], f[4 * j + 1], f[4 * j + 2], f[4 * j + 3]);
+      }
+    } else {
+      for (int i = tid; i < total; i += blockDim.x) buf[i] = to_f32(src[i]);
+    }
+    __syncthreads();
+    if (tid < lanes) {
+      const float* p = buf + (px * patch) * 3 + ch;
+      for (int r = 0; r < rows; ++r) {
+        if (PATCH > 0) {
+#pragma unroll
+          for (int iw = 0; iw < (PATCH > 0 ? PATCH : 1); ++iw) s = __fadd_rn(s, p[iw * 3]);
+        } else {
+          for (int iw = 0; iw < patch; ++iw) s = __fadd_rn(s, p[iw * 3]);
+        }
+        p += row_elems;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < lanes) {
+    const float mean = round_to<T>(__fdiv_rn(s, (float)(patch * patch)));
+    const size_t o = (((size_t)v * n + py) * n + px) * 3 + ch;
+    if (avg) avg[o] = from_f32<T>(mean);
+    if (vox || ids) {
+      const float r = voxelise<T>(mean, round_to<T>(rg.lo[ch]), round_to<T>(rg.hi[ch]), rg.voxel);
+      if (vox) vox[o] = from_f32<T>(r);
+      if (ids) ids[o] = (int32_t)r;
+    }
+  }
+}
+
+}  // namespace v3d
+
+using namespace v3d;
+
+extern "C" int v3d_unproject_f32(const float* depth_mm, const float* intrinsics, const float* poses, float* world,
+                                 int V, int H, int W, void* stream) {
+  V3D_REQUIRE(depth_mm && intrinsics && poses && world, "v3d_unproject_f32: null pointer");
+  V3D_REQUIRE(V > 0 && H > 0 && W > 0, "v3d_unproject_f32: bad shape V=%d H=%d W=%d", V, H, W);
+  V3D_REQUIRE((int64_t)H * W < (1ll << 30), "v3d_unproject_f32: frame too large");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (W % 4 == 0) && aligned16(depth_mm) && aligned16(world);
+  if (vec) {
+    const int quads = H * W / 4;
+    int bx = (quads + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(unproject_f32_kernel, dim3(bx, V), dim3(256), 0, st, depth_mm, intrinsics, poses, world, H, W, quads);
+  } else {
+    int bx = (H * W + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(unproject_f32_scalar_kernel, dim3(bx, V), dim3(256), 0, st, depth_mm, intrinsics, poses, world, H, W);
+  }
+  return check_launch("v3d_unproject_f32");
+}
+
+extern "C" int v3d_unproject_sampled_u16(const uint16_t* depth, const float* intrinsics, const float* poses,
+                                         void* out, int out_dtype, int V, int H, int W, int crop, void* stream) {
+  V3D_REQUIRE(depth && intrinsics && poses && out, "v3d_unproject_sampled_u16: null pointer");
+  V3D_REQUIRE(V > 0 && H > 0 && W > 0 && crop > 0, "v3d_unproject_sampled_u16: bad shape");
+  // llava/video_utils.py:297-304: new_height = crop; new_width = int(W * (crop / H)); centre crop
+  const int new_h = crop;
+  const int new_w = (int)((double)W * ((double)crop / (double)H));
+  V3D_REQUIRE(new_w >= crop, "v3d_unproject_sampled_u16: resized width %d < crop %d", new_w, crop);
+  const int left = (new_w - crop) / 2;
+  const double inv_fx = (double)W / (double)new_w;   // cv::resize: scale_x = src.cols / dst.cols
+  const double inv_fy = (double)H / (double)new_h;
+  hipStream_t st = (hipStream_t)stream;
+  int bx = (crop * crop + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  V3D_DISPATCH_DTYPE(out_dtype,
+                     hipLaunchKernelGGL(unproject_sampled_kernel<T>, dim3(bx, V), dim3(256), 0, st, depth, intrinsics,
+                                        poses, (T*)out, H, W, crop, new_w, left, inv_fx, inv_fy));
+  return check_launch("v3d_unproject_sampled_u16");
+}
+
+static int fill_range(Range& rg, const float* lo, const float* hi, float voxel, const char* who) {
+  V3D_REQUIRE(lo && hi, "%s: min/max range pointers are null", who);
+  V3D_REQUIRE(voxel > 0.0f, "%s: voxel_size must be > 0", who);
+  for (int i = 0; i < 3; ++i) { rg.lo[i] = lo[i]; rg.hi[i] = hi[i]; }
+  rg.voxel = voxel;
+  return V3D_OK;
+}
+
+extern "C" int v3d_discrete_coords(const void* xyz, int dtype, int64_t N, const float* min_xyz_host,
+                                   const float* max_xyz_host, float voxel_size, void* vox, int32_t* ids,
+                                   void* stream) {
+  V3D_REQUIRE(xyz && (vox || ids), "v3d_discrete_coords: null pointer");
+  V3D_REQUIRE(N >= 0, "v3d_discrete_coords: negative N");
+  if (N == 0) return V3D_OK;
+  Range rg;
+  if (int e = fill_range(rg, min_xyz_host, max_xyz_host, voxel_size, "v3d_discrete_coords")) return e;
+  int64_t blocks = (N * 3 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(discrete_coords_kernel<T>, dim3((int)blocks), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)xyz, N * 3, rg, (T*)vox, ids));
+  return check_launch("v3d_discrete_coords");
+}
+
+extern "C" int v3d_coord_pool_voxel(const void* coords, int dtype, int V, int S, int patch,
+                                    const float* min_xyz_host, const float* max_xyz_host, float voxel_size,
+                                    void* avg, void* vox, int32_t* ids, void* stream) {
+  V3D_REQUIRE(coords && (avg || vox || ids), "v3d_coord_pool_voxel: null pointer");
+  V3D_REQUIRE(V > 0 && S > 0 && patch > 0 && patch <= S, "v3d_coord_pool_voxel: bad shape V=%d S=%d patch=%d", V, S, patch);
+  // llava_arch.py:217: [:, :-6, :-6, :] then kernel=stride=patch -> n = floor((S-6)/patch)
+  const int n = (S - 6) / patch;
+  V3D_REQUIRE(n > 0 && n * 3 <= 256, "v3d_coord_pool_voxel: n=%d patches per row unsupported", n);
+  Range rg;
+  if (int e = fill_range(rg, min_xyz_host, max_xyz_host, voxel_size, "v3d_coord_pool_voxel")) return e;
+  const size_t lds = (size_t)kPoolChunkRows * S * 3 * sizeof(float);
+  V3D_REQUIRE(lds <= 160 * 1024, "v3d_coord_pool_voxel: S=%d needs %zu B of LDS", S, lds);
+  const size_t esz = dtype == V3D_F32 ? 4 : 2;
+  const int vec_ok = aligned16(coords) && ((size_t)S * 3 * esz) % 16 == 0;
+  hipStream_t st = (hipStream_t)stream;
+  V3D_DISPATCH_DTYPE(dtype, {
+    auto k27 = coord_pool_voxel_kernel<T, 27>;
+    auto kg = coord_pool_voxel_kernel<T, 0>;
+    auto k = patch == 27 ? k27 : kg;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { set_error("v3d_coord_pool_voxel: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; }
+    }
+    hipLaunchKernelGGL(k, dim3(n, V), dim3(256), lds, st, (const T*)coords, S, patch, n, rg, (T*)avg, (T*)vox, ids, vec_ok);
+  });
+  return check_launch("v3d_coord_pool_voxel");
+}

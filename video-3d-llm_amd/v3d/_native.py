@@ -1,0 +1,64 @@
+"""ctypes binding of libv3d_hip.so (include/v3d.h).  No fallback: if the library is missing the
+import of any op fails loudly - the product path never computes on the CPU."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libv3d_hip.so")
+
+_lib = None
+
+
+class V3DError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise V3DError(
+                f"{LIB_PATH} not found: build it with `make -C video-3d-llm_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for this path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+        if _lib.v3d_abi_version() != 1:
+            raise V3DError("libv3d_hip.so ABI version mismatch")
+    return _lib
+
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/v3d.h one to one
+SIGNATURES = {
+    "v3d_abi_version": (c_i, []),
+    "v3d_last_error": (ctypes.c_char_p, []),
+    "v3d_unproject_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "v3d_unproject_sampled_u16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_coord_pool_voxel": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
+    "v3d_discrete_coords": (c_i, [c_p, c_i, c_l, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "v3d_sin3d_table_row_elems": (c_l, [c_i, c_i]),
+    "v3d_sin3d_table_build": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "v3d_sin3d_pe": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p, c_p]),
+    "v3d_visual_tokens": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_embed_gather": (c_i, [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_i, c_p]),
+    "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),
+    "v3d_greedy_cover_host": (c_i, [c_p, c_i, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_p]),
+}
+
+
+def _declare(l):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def check(rc, what):
+    if rc < 0:
+        msg = lib().v3d_last_error().decode("utf-8", "replace")
+        raise V3DError(f"{what} failed ({rc}): {msg}")
+    return rc

@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI.  Every op takes CUDA(=HIP) tensors, launches on torch's
+current stream and returns CUDA tensors.  PyTorch only provides the memory and the stream."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from ._native import V3DError, check, lib
+
+F32, F16, BF16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+VT_POOL, VT_PE, VT_NEWLINE = 1, 2, 4
+
+
+def _code(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise V3DError(f"unsupported dtype {t.dtype}") from None
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise V3DError(f"{name} must be a CUDA/HIP tensor resident in HBM (got {type(t).__name__}"
+                       f"{'' if not isinstance(t, torch.Tensor) else ' on ' + str(t.device)}); there is no CPU path")
+    return t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f3(v):
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+# ------------------------------------------------------------------------------ geometry
+
+
+def unproject(intrinsics, poses, depths):
+    """K1.  intrinsics, poses [V,4,4]; depths [V,H,W] (millimetres) -> [V,H,W,3] f32."""
+    K = _dev(intrinsics, "intrinsics").float()
+    P = _dev(poses, "poses").float()
+    d = _dev(depths, "depths").float()
+    V, H, W = d.shape
+    out = torch.empty((V, H, W, 3), dtype=torch.float32, device=d.device)
+    check(lib().v3d_unproject_f32(_p(d), _p(K), _p(P), _p(out), V, H, W, _stream()), "v3d_unproject_f32")
+    return out
+
+
+def unproject_sampled(depth_u16, intrinsics, poses, crop=384, dtype=torch.float32):
+    """K1+K2.  depth [V,H,W] uint16/int16 raw PNG values -> [V,crop,crop,3] in `dtype`."""
+    d = _dev(depth_u16, "depth")
+    if d.dtype not in (torch.uint16, torch.int16):
+        raise V3DError("depth must be a 16-bit integer tensor (raw PNG millimetres)")
+    K = _dev(intrinsics, "intrinsics").float()
+    P = _dev(poses, "poses").float()
+    V, H, W = d.shape
+    out = torch.empty((V, crop, crop, 3), dtype=dtype, device=d.device)
+    check(lib().v3d_unproject_sampled_u16(_p(d), _p(K), _p(P), _p(out), _DT[dtype], V, H, W, crop, _stream()),
+          "v3d_unproject_sampled_u16")
+    return out
+
+
+def coord_pool_voxel(coords, patch=27, min_xyz=(-15, -15, -5), max_xyz=(15, 15, 5), voxel_size=0.1,
+                     want_avg=True, want_vox=True, want_ids=True):
+    """K3+K4.  coords [V,S,S,3] -> (avg [V,n,n,3], vox [V,n,n,3] same dtype, ids int32)."""
+    x = _dev(coords, "coords")
+    V, S, S2, D = x.shape
+    if S != S2 or D != 3:
+        raise V3DError(f"coords must be [V,S,S,3], got {tuple(x.shape)}")
+    n = (S - 6) // patch
+    avg = torch.empty((V, n, n, 3), dtype=x.dtype, device=x.device) if want_avg else None
+    vox = torch.empty((V, n, n, 3), dtype=x.dtype, device=x.device) if want_vox else None
+    ids = torch.empty((V, n, n, 3), dtype=torch.int32, device=x.device) if want_ids else None
+    check(lib().v3d_coord_pool_voxel(_p(x), _code(x), V, S, patch, _f3(min_xyz), _f3(max_xyz), float(np.float32(voxel_size)),
+                                     _p(avg), _p(vox), _p(ids), _stream()), "v3d_coord_pool_voxel")
+    return avg, vox, ids
+
+
+def discrete_coords(xyz, min_xyz=(-15, -15, -5), max_xyz=(15, 15, 5), voxel_size=0.1, want_ids=False):
+    """K4 on arbitrary [...,3] points."""
+    x = _dev(xyz, "xyz")
+    if x.shape[-1] != 3:
+        raise V3DError("xyz must end in a dimension of 3")
+    N = x.numel() // 3
+    vox = torch.empty_like(x)
+    ids = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_ids else None
+    check(lib().v3d_discrete_coords(_p(x), _code(x), N, _f3(min_xyz), _f3(max_xyz), float(np.float32(voxel_size)),
+                                    _p(vox), _p(ids), _stream()), "v3d_discrete_coords")
+    return (vox, ids) if want_ids else vox
+
+
+# ------------------------------------------------------------------------------ 3-D sinusoid
+
+
+def reference_dim_t(num_feats, temperature=10000):
+    """position_encoding.py:24-25 evaluated exactly as the reference's CPU path does (torch pow)."""
+    d = torch.arange(num_feats, dtype=torch.float32)
+    return temperature ** (2 * (d // 2) / num_feats)
+
+
+class Sin3DTable:
+    """PE values for every integer voxel id, in the shifted layout v3d_visual_tokens reads."""
+
+    def __init__(self, embedding_size, n_ids, dtype, device, dim_t=None, temperature=10000, keep_f32=False):
+        self.embedding_size = embedding_size
+        self.n_ids = n_ids
+        self.dtype = dtype
+        nf = embedding_size // 3
+        if dim_t is None:
+            dim_t = reference_dim_t(nf, temperature)
+        self.dim_t = dim_t.to(device=device, dtype=torch.float32).contiguous()
+        row = lib().v3d_sin3d_table_row_elems(embedding_size, _DT[dtype])
+        self.row_elems = row
+        self.table = torch.empty((3, n_ids, row), dtype=dtype, device=device)
+        self.table_f32 = torch.empty((n_ids, nf), dtype=torch.float32, device=device) if keep_f32 else None
+        check(lib().v3d_sin3d_table_build(_p(self.dim_t), embedding_size, n_ids, _DT[dtype], _p(self.table),
+                                          _p(self.table_f32), _stream()), "v3d_sin3d_table_build")
+
+
+def sin3d_pe(xyz, embedding_size, dim_t=None, temperature=10000):
+    """PositionEmbeddingSine3D.forward (n_points=1): xyz [B,N,3] -> [B,N,E] in xyz.dtype."""
+    x = _dev(xyz, "xyz")
+    if dim_t is None:
+        dim_t = reference_dim_t(embedding_size // 3, temperature)
+    dim_t = dim_t.to(device=x.device, dtype=torch.float32).contiguous()
+    N = x.numel() // 3
+    out = torch.empty(x.shape[:-1] + (embedding_size,), dtype=x.dtype, device=x.device)
+    check(lib().v3d_sin3d_pe(_p(x), _code(x), N, _p(dim_t), embedding_size, _p(out), _stream()), "v3d_sin3d_pe")
+    return out
+
+
+# ------------------------------------------------------------------------------ fusion
+
+
+def visual_tokens(feat, ids=None, table=None, newline=None, side=27, n=14, pool=True, out=None):
+    """K7 (+K5+K6) (+K8).  feat [V, side*side | n*n, C]; ids [V,n,n,3] int32; table Sin3DTable;
+    newline [C].  Returns / fills `out` [rows, C] (rows = V*n*(n+1) with newline else V*n*n);
+    `out` may be a row-slice view of a larger [S, C] buffer (the LLM's inputs_embeds)."""
+    f = _dev(feat, "feat")
+    V, T, C = f.shape
+    flags = (VT_POOL if pool else 0) | (VT_PE if table is not None else 0) | (VT_NEWLINE if newline is not None else 0)
+    expect = side * side if pool else n * n
+    if T != expect:
+        raise V3DError(f"feat has {T} tokens per frame, expected {expect}")
+    rows = V * n * ((n + 1) if newline is not None else n)
+    if out is None:
+        out = torch.empty((rows, C), dtype=f.dtype, device=f.device)
+    if out.dtype != f.dtype or out.shape[0] != rows or out.shape[1] != C or out.stride(1) != 1:
+        raise V3DError(f"out must be [{rows},{C}] {f.dtype} with unit column stride")
+    idt = tbl = nl = None
+    n_ids = 0
+    if table is not None:
+        if ids is None:
+            raise V3DError("PE requested without voxel ids")
+        idt = _dev(ids, "ids")
+        if idt.dtype != torch.int32 or idt.numel() != V * n * n * 3:
+            raise V3DError("ids must be int32 [V,n,n,3]")
+        if table.dtype != f.dtype or table.embedding_size != C:
+            raise V3DError("PE table was built for another dtype / width")
+        tbl, n_ids = table.table, table.n_ids
+    if newline is not None:
+        nl = _dev(newline, "newline").to(f.dtype)
+    check(lib().v3d_visual_tokens(_p(f), _p(idt), _p(tbl), n_ids, _p(nl), _p(out), out.stride(0), _code(f), V, side, n, C,
+                                  flags, _stream()), "v3d_visual_tokens")
+    return out
+
+
+def embed_gather(weight, ids, out=None):
+    w = _dev(weight, "weight")
+    i = _dev(ids, "ids").to(torch.int64).reshape(-1)
+    vocab, C = w.shape
+    if out is None:
+        out = torch.empty((i.numel(), C), dtype=w.dtype, device=w.device)
+    check(lib().v3d_embed_gather(_p(w), vocab, C, _p(i), i.numel(), _p(out), out.stride(0), _code(w), _stream()),
+          "v3d_embed_gather")
+    return out
+
+
+# ------------------------------------------------------------------------------ host helpers
+
+
+def uniform_frame_indices(total_frames, n):
+    out = (ctypes.c_int32 * n)()
+    check(lib().v3d_uniform_frame_indices_host(total_frames, n, out), "v3d_uniform_frame_indices_host")
+    return list(out)
+
+
+def greedy_cover(keys, scene_voxels, max_frames=32):
+    """a3.  keys [n_frames, pts, 3] int32 (numpy), scene_voxels [m,3] int32 ->
+    (sel, gains, num_all_voxels, num_select_voxels)."""
+    k = np.ascontiguousarray(keys, dtype=np.int32)
+    s = np.ascontiguousarray(scene_voxels, dtype=np.int32).reshape(-1, 3)
+    n_frames = k.shape[0]
+    pts = int(np.prod(k.shape[1:-1]))
+    sel = np.zeros(max_frames, np.int32)
+    gain = np.zeros(max_frames, np.int64)
+    na = ctypes.c_int64()
+    nsel = ctypes.c_int64()
+    picks = check(lib().v3d_greedy_cover_host(k.ctypes.data_as(ctypes.c_void_p), n_frames, pts,
+                                              s.ctypes.data_as(ctypes.c_void_p), s.shape[0], max_frames,
+                                              sel.ctypes.data_as(ctypes.c_void_p), gain.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.byref(na), ctypes.byref(nsel)), "v3d_greedy_cover_host")
+    return sel[:picks], gain[:picks], na.value, nsel.value
