@@ -117,6 +117,31 @@ int v3d_visual_tokens(const void* feat, const int32_t* ids, const void* table, i
 int v3d_embed_gather(const void* table, int64_t vocab, int C, const int64_t* ids, int64_t n,
                      void* out, int64_t out_stride, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ dense linears ------- */
+
+/* K10-K12, K15, K17  every nn.Linear on the path (SigLIP q/k/v/out/fc1/fc2 and patch embedding,
+ * siglip_encoder.py:156-174,197-265; mlp2x_gelu projector, multimodal_projector/builder.py:41-48;
+ * Qwen2 q/k/v/o and gate/up/down, modeling_qwen2.py:177-189,237-240,322):
+ *     out[M, N'] = epilogue( A[M,K] . W[N,K]^T ),   16-bit operands, f32 MFMA accumulation.
+ * A row stride lda, W row stride ldw (elements).  N % 128 == 0 and K % 64 == 0 (pad weights with
+ * zero rows / columns once at load); M is arbitrary (M <= 8 takes a weight-streaming path for decode).
+ * Epilogues (rounding points as torch: linear output rounded to dtype, then each further op):
+ *   NONE            out = acc
+ *   BIAS            out = acc + bias[n]
+ *   BIAS_GELU_ERF   out = gelu(acc + bias)            nn.GELU()            (projector)
+ *   BIAS_GELU_TANH  out = gelu_tanh(acc + bias)       gelu_pytorch_tanh    (SigLIP fc1)
+ *   BIAS_RES        out = res[m or m % res_mod, n] + (acc + bias)          (SigLIP out_proj/fc2, patch-embed + pos-emb)
+ *   RES             out = res[m, n] + acc                                  (Qwen2 o_proj / down_proj)
+ *   SWIGLU          out[m, j] = silu(gate_j) * up_j, N' = N/2; W rows are tile-interleaved: rows
+ *                   [128t, 128t+64) = gate rows [64t, 64t+64), rows [128t+64, 128t+128) = the up rows. */
+enum {
+  V3D_EPI_NONE = 0, V3D_EPI_BIAS = 1, V3D_EPI_BIAS_GELU_ERF = 2, V3D_EPI_BIAS_GELU_TANH = 3,
+  V3D_EPI_BIAS_RES = 4, V3D_EPI_RES = 5, V3D_EPI_SWIGLU = 6
+};
+int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* res,
+             int64_t ldr, int res_mod, void* out, int64_t ldo, int M, int N, int K, int dtype, int epilogue,
+             void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* a1  llava/video_utils.py:187  np.linspace(0, total-1, n, dtype=int).  out_host[n]. */

@@ -1,0 +1,110 @@
+"""GPU parity tests for v3d_gemm (every nn.Linear on the path) against a plain fp32 torch
+reference on the CPU with the reference's rounding points (the oracle for a floating-point kernel)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+# tolerance: K-long f32 accumulation in a different order + one 16-bit rounding per stage
+RTOL = {"bf16": 1.6e-2, "f16": 2e-3}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from v3d import ops as _ops
+    return _ops
+
+
+def ref_linear(a, w, bias, dt):
+    y = a.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    return y.to(dt)
+
+
+def close(got, want, kind, scale=None):
+    got, want = got.float().cpu(), want.float()
+    tol = RTOL[kind]
+    s = want.abs().mean().item() if scale is None else scale
+    err = (got - want).abs()
+    assert torch.all(err <= tol * want.abs() + tol * s), f"max err {err.max().item()} (scale {s})"
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (1, 128, 64), (7, 384, 1152), (729, 1152, 640), (1000, 3584, 1152)])
+def test_gemm_plain_and_bias(ops, kind, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    dt = DT[kind]
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    b = torch.randn(N, generator=g).to(dt)
+    close(ops.gemm(a.cuda(), w.cuda()), ref_linear(a, w, None, dt), kind)
+    close(ops.gemm(a.cuda(), w.cuda(), bias=b.cuda(), epilogue=ops.EPI_BIAS), ref_linear(a, w, b, dt), kind)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("M", [5, 333])
+def test_gemm_epilogues(ops, kind, M):
+    g = torch.Generator().manual_seed(M)
+    dt = DT[kind]
+    N, K = 256, 320
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.08).to(dt)
+    b = torch.randn(N, generator=g).to(dt)
+    r = torch.randn(M, N, generator=g).to(dt)
+    lin = ref_linear(a, w, b, dt)
+    ac, wc, bc, rc = a.cuda(), w.cuda(), b.cuda(), r.cuda()
+    close(ops.gemm(ac, wc, bias=bc, epilogue=ops.EPI_BIAS_GELU_ERF), torch.nn.functional.gelu(lin.float()).to(dt), kind, scale=1.0)
+    close(ops.gemm(ac, wc, bias=bc, epilogue=ops.EPI_BIAS_GELU_TANH),
+          torch.nn.functional.gelu(lin.float(), approximate="tanh").to(dt), kind, scale=1.0)
+    close(ops.gemm(ac, wc, bias=bc, res=rc, epilogue=ops.EPI_BIAS_RES), (r.float() + lin.float()).to(dt), kind, scale=1.0)
+    close(ops.gemm(ac, wc, res=rc, epilogue=ops.EPI_RES), (r.float() + ref_linear(a, w, None, dt).float()).to(dt), kind, scale=1.0)
+    # residual broadcast by row modulo (ViT position embedding): res has 3 rows
+    r3 = torch.randn(3, N, generator=g).to(dt)
+    want = (r3.float()[torch.arange(M) % 3] + lin.float()).to(dt)
+    close(ops.gemm(ac, wc, bias=bc, res=r3.cuda(), epilogue=ops.EPI_BIAS_RES, res_mod=3), want, kind, scale=1.0)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("M", [3, 200])
+def test_gemm_swiglu(ops, kind, M):
+    """Qwen2MLP gate/up (modeling_qwen2.py:188-189): act(gate(x)) * up(x), each stage rounded to dtype."""
+    g = torch.Generator().manual_seed(M + 1)
+    dt = DT[kind]
+    I, K = 192, 256
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    wg = (torch.randn(I, K, generator=g) * 0.1).to(dt)
+    wu = (torch.randn(I, K, generator=g) * 0.1).to(dt)
+    gate = ref_linear(a, wg, None, dt)
+    up = ref_linear(a, wu, None, dt)
+    want = (torch.nn.functional.silu(gate.float()).to(dt).float() * up.float()).to(dt)
+    wgu = ops.interleave_gate_up(wg, wu)
+    # N must be a multiple of 128: 2*192 = 384 ok
+    got = ops.gemm(a.cuda(), wgu.cuda(), epilogue=ops.EPI_SWIGLU)
+    assert got.shape == (M, I)
+    close(got, want, kind, scale=0.5)
+
+
+def test_gemm_strided_operands_and_out(ops):
+    """A with a padded row stride (K-padding of SigLIP's 4304-wide MLP) and out into a wider buffer."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 150, 128, 128
+    abuf = torch.zeros(M, K + 64, dtype=dt)
+    abuf[:, :K] = (torch.randn(M, K, generator=g) * 0.5).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dt)
+    ac = abuf.cuda()
+    obuf = torch.full((M, N + 128), 7.0, dtype=dt, device="cuda")
+    ops.gemm(ac[:, :K], w.cuda(), out=obuf[:, :N])
+    close(obuf[:, :N], ref_linear(abuf[:, :K], w, None, dt), "bf16")
+    assert torch.all(obuf[:, N:] == 7.0)
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from v3d import V3DError
+    a = torch.zeros(4, 100, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(128, 100, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(V3DError, match="multiple"):
+        ops.gemm(a, w)

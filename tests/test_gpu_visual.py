@@ -133,7 +133,7 @@ def test_coord_pool_voxel_full_size_bitexact(ops, kind):
     assert np.array_equal(host32(avg), want_avg)
     assert np.array_equal(host32(vox), want_vox)
     assert np.array_equal(ids.cpu().numpy(), want_vox.astype(np.int32))
-    assert ids.min().item() == 0 and ids.max().item() <= 300
+    assert ids.min().item() >= 0 and ids.max().item() <= 300
 
 
 def test_discrete_coords_exhaustive_f16(ops, golden):

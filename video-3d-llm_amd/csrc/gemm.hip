@@ -1,0 +1,375 @@
+// Dense 16-bit GEMM on MFMA for the ViT / projector / LLM linears (K10-K12, K15, K17):
+//     out[M, N'] = epilogue( A[M,K] . W[N,K]^T )        A, W: K-contiguous (nn.Linear layout)
+//
+// Tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 sub-tile as 4 x 4
+// v_mfma_f32_16x16x32 accumulators.  Both operand tiles are staged HBM -> LDS with
+// global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 2-deep ring; the LDS image is
+// XOR-swizzled through the per-lane SOURCE address (the DMA's destination is lane-linear) so that
+// the ds_read_b128 fragment reads are bank-conflict free.  The accumulators are produced
+// TRANSPOSED (mfma(W-frag, A-frag)): a lane then owns 4 consecutive output columns of one row,
+// i.e. one 8-byte LDS write, and the tile leaves through LDS as whole 256-byte row segments.
+//
+// Rounding points follow the reference (torch): the linear output (acc + bias, f32) is rounded to
+// the 16-bit dtype once; activation / gate product / residual add each take 16-bit inputs,
+// compute in f32 and round again.
+#include "v3d_common.h"
+
+namespace v3d {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_A_BYTES = BM * BK * 2;            // 16 KiB
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;      // 32 KiB
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;      // 64 KiB -> 2 workgroups per CU
+constexpr int C_ROW_BYTES = BN * 2 + 16;             // padded C-tile row in LDS
+
+struct GemmArgs {
+  const void* A; const void* W; const void* bias; const void* res; void* out;
+  int M, N, K;
+  int64_t lda, ldw, ldr, ldo;
+  int res_mod;        // >0: residual row = m % res_mod (ViT position embedding)
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float u = 0.79788456080286535588f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware logical block id (blocks b and b+8 share an XCD's L2), then grouped row-major tiles:
+// the ~64 workgroups resident on one XCD cover an 8 x 8 patch of tiles and share operand panels.
+__device__ __forceinline__ void tile_of_block(int bid, int nblocks, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+  const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int g = L / per_group, in_g = L - g * per_group;
+  const int first_m = g * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU_ERF = 2, EPI_BIAS_GELU_TANH = 3, EPI_BIAS_RES = 4, EPI_RES = 5, EPI_SWIGLU = 6 };
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using M16 = Mfma16<T>;
+  using frag = typename M16::frag;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows (1 KiB) per DMA ----
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);          // logical 16-B chunk that lands in slot lane&7
+    int gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;                             // M tail: re-read the last row, never stored
+    a_src[i] = (const uint16_t*)p.A + (int64_t)gm * p.lda + chunk * 8;
+    w_src[i] = (const uint16_t*)p.W + (int64_t)(n0 + row) * p.ldw + chunk * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE_BYTES + (wave * 32) * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i] + kt * BK, base + i * 8 * (BK * 2));
+      glds16(w_src[i] + kt * BK, base + TILE_A_BYTES + i * 8 * (BK * 2));
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside one operand tile) ----
+  // lane reads row (16*t + lane&15), logical chunk 4*ks + lane>>4; ((row>>1)&7) == ((lane>>1)&7)
+  const int sw = (lane >> 1) & 7;
+  const int frow = (lane & 15) * (BK * 2);
+  const int fo0 = frow + (((0 + (lane >> 4)) ^ sw) << 4);
+  const int fo1 = frow + (((4 + (lane >> 4)) ^ sw) << 4);
+
+  f32x4 acc[4][4];   // [ni][mi], transposed product: D[row = n][col = m]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  __syncthreads();   // hipcc drains vmcnt before the barrier: tile 0 has landed
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(cur ^ 1, t + 1);
+    const char* sA = smem + cur * STAGE_BYTES + (wm * 64) * (BK * 2);
+    const char* sW = smem + cur * STAGE_BYTES + TILE_A_BYTES + (wn * 64) * (BK * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = ks ? fo1 : fo0;
+      frag a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = *reinterpret_cast<const frag*>(sA + i * 16 * (BK * 2) + fo);
+        b[i] = *reinterpret_cast<const frag*>(sW + i * 16 * (BK * 2) + fo);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = M16::run(b[ni], a[mi], acc[ni][mi]);
+    }
+    __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+  }
+
+  // ---- epilogue: accumulators -> LDS C tile (16-bit, bias added in f32 first) -> coalesced rows ----
+  const T* bias = (const T*)p.bias;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI >= EPI_BIAS && EPI <= EPI_BIAS_RES) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int ml = wm * 64 + mi * 16 + (lane & 15);
+      uint2 pk;
+      pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
+      pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
+      *reinterpret_cast<uint2*>(smem + ml * C_ROW_BYTES + nl * 2) = pk;
+    }
+  }
+  __syncthreads();
+
+  T* out = (T*)p.out;
+  if (EPI == EPI_SWIGLU) {
+    // tile columns [0,64) = gate_j, [64,128) = up_j of the same 64 j's; output width N/2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+      const int gm = m0 + row;
+      const uint4 g = *reinterpret_cast<const uint4*>(smem + row * C_ROW_BYTES + ch * 16);
+      const uint4 u = *reinterpret_cast<const uint4*>(smem + row * C_ROW_BYTES + 128 + ch * 16);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu(vec_get<T>(g, j))) * vec_get<T>(u, j);
+      if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + tn * 64 + ch * 8) = vec_pack<T>(v);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (tid >> 4) + 16 * i, ch = tid & 15;
+    const int gm = m0 + row;
+    if (gm >= p.M) continue;
+    uint4 c = *reinterpret_cast<const uint4*>(smem + row * C_ROW_BYTES + ch * 16);
+    if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+      float v[8];
+      uint4 rr = make_uint4(0, 0, 0, 0);
+      if (EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+        const int64_t rm = p.res_mod > 0 ? (gm % p.res_mod) : gm;
+        rr = *reinterpret_cast<const uint4*>((const T*)p.res + rm * p.ldr + n0 + ch * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = vec_get<T>(c, j);
+        v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : x + vec_get<T>(rr, j);
+      }
+      c = vec_pack<T>(v);
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + n0 + ch * 8) = c;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Skinny GEMM for decode (M <= 8): out[m, n] = A[m,:] . W[n,:] (+bias)(+res).  Pure weight
+// streaming: one wave per output column group, 16-byte loads, f32 accumulate, shuffle reduce.
+// ------------------------------------------------------------------------------------------
+template <typename T, int MAXM>
+__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                   const T* __restrict__ bias, const T* __restrict__ res,
+                                                   T* __restrict__ out, int M, int N, int K, int64_t lda, int64_t ldw,
+                                                   int64_t ldr, int64_t ldo, int epi, int res_mod) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int kv = K / 8;
+  for (int n = wave_global; n < N; n += n_waves) {
+    float s[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) s[m] = 0.f;
+    const uint4* wrow = reinterpret_cast<const uint4*>(W + (int64_t)n * ldw);
+    for (int k = lane; k < kv; k += 64) {
+      const uint4 w = wrow[k];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+          const uint4 a = reinterpret_cast<const uint4*>(A + (int64_t)m * lda)[k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[m] = fmaf(vec_get<T>(w, j), vec_get<T>(a, j), s[m]);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[m] += __shfl_xor(s[m], off);
+    }
+    if (lane == 0) {
+      for (int m = 0; m < M; ++m) {
+        float x = s[m];
+        if (bias) x += to_f32(bias[n]);
+        x = round_to<T>(x);
+        if (epi == EPI_BIAS_GELU_ERF) x = gelu_erf(x);
+        if (epi == EPI_BIAS_GELU_TANH) x = gelu_tanh(x);
+        if (epi == EPI_BIAS_GELU_ERF || epi == EPI_BIAS_GELU_TANH) x = round_to<T>(x);
+        if (res) x = x + to_f32(res[(int64_t)(res_mod > 0 ? m % res_mod : m) * ldr + n]);
+        out[(int64_t)m * ldo + n] = from_f32<T>(x);
+      }
+    }
+  }
+}
+
+// decode SwiGLU: out[m, j] = silu(A.Wg_j) * (A.Wu_j) with the tile-interleaved [gate64 | up64] row order
+template <typename T, int MAXM>
+__global__ __launch_bounds__(256) void gemv_swiglu_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                          T* __restrict__ out, int M, int N, int K, int64_t lda,
+                                                          int64_t ldw, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int kv = K / 8;
+  const int half = N / 2;
+  for (int j = wave_global; j < half; j += n_waves) {
+    const int ng = (j >> 6) * 128 + (j & 63), nu = ng + 64;
+    float sg[MAXM], su[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) sg[m] = su[m] = 0.f;
+    const uint4* wg = reinterpret_cast<const uint4*>(W + (int64_t)ng * ldw);
+    const uint4* wu = reinterpret_cast<const uint4*>(W + (int64_t)nu * ldw);
+    for (int k = lane; k < kv; k += 64) {
+      const uint4 g = wg[k], u = wu[k];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+          const uint4 a = reinterpret_cast<const uint4*>(A + (int64_t)m * lda)[k];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float av = vec_get<T>(a, e);
+            sg[m] = fmaf(vec_get<T>(g, e), av, sg[m]);
+            su[m] = fmaf(vec_get<T>(u, e), av, su[m]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { sg[m] += __shfl_xor(sg[m], off); su[m] += __shfl_xor(su[m], off); }
+    }
+    if (lane == 0)
+      for (int m = 0; m < M; ++m)
+        out[(int64_t)m * ldo + j] = from_f32<T>(round_to<T>(silu(round_to<T>(sg[m]))) * round_to<T>(su[m]));
+  }
+}
+
+template <typename T>
+static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
+#define V3D_GEMM_CASE(E)                                                                                  \
+  case E: {                                                                                               \
+    auto k = gemm_kernel<T, E>;                                                                           \
+    static bool attr_done = false;                                                                        \
+    if (!attr_done) {                                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
+      if (e != hipSuccess) { set_error("v3d_gemm: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
+      attr_done = true;                                                                                   \
+    }                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(256), GEMM_LDS_BYTES, st, p);                 \
+  } break;
+  switch (epi) {
+    V3D_GEMM_CASE(EPI_NONE)
+    V3D_GEMM_CASE(EPI_BIAS)
+    V3D_GEMM_CASE(EPI_BIAS_GELU_ERF)
+    V3D_GEMM_CASE(EPI_BIAS_GELU_TANH)
+    V3D_GEMM_CASE(EPI_BIAS_RES)
+    V3D_GEMM_CASE(EPI_RES)
+    V3D_GEMM_CASE(EPI_SWIGLU)
+    default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
+  }
+#undef V3D_GEMM_CASE
+  return check_launch("v3d_gemm");
+}
+
+template <typename T>
+static int launch_gemv(const GemmArgs& p, int epi, hipStream_t st) {
+  const int waves_needed = epi == EPI_SWIGLU ? p.N / 2 : p.N;
+  int blocks = (waves_needed + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (epi == EPI_SWIGLU) {
+    hipLaunchKernelGGL((gemv_swiglu_kernel<T, 8>), dim3(blocks), dim3(256), 0, st, (const T*)p.A, (const T*)p.W,
+                       (T*)p.out, p.M, p.N, p.K, p.lda, p.ldw, p.ldo);
+  } else {
+    const bool has_bias = epi >= EPI_BIAS && epi <= EPI_BIAS_RES;
+    const bool has_res = epi == EPI_BIAS_RES || epi == EPI_RES;
+    hipLaunchKernelGGL((gemv_kernel<T, 8>), dim3(blocks), dim3(256), 0, st, (const T*)p.A, (const T*)p.W,
+                       has_bias ? (const T*)p.bias : nullptr, has_res ? (const T*)p.res : nullptr, (T*)p.out, p.M, p.N,
+                       p.K, p.lda, p.ldw, p.ldr, p.ldo, epi, p.res_mod);
+  }
+  return check_launch("v3d_gemm (skinny)");
+}
+
+}  // namespace v3d
+
+using namespace v3d;
+
+extern "C" int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* res,
+                        int64_t ldr, int res_mod, void* out, int64_t ldo, int M, int N, int K, int dtype, int epilogue,
+                        void* stream) {
+  V3D_REQUIRE(A && W && out, "v3d_gemm: null pointer");
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_gemm: dtype must be f16 or bf16");
+  V3D_REQUIRE(M > 0 && N > 0 && K > 0, "v3d_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+  V3D_REQUIRE(N % BN == 0 && K % BK == 0, "v3d_gemm: N=%d must be a multiple of %d and K=%d of %d (pad the weights)", N, BN, K, BK);
+  V3D_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "v3d_gemm: leading dimensions must be >= K and multiples of 8");
+  V3D_REQUIRE(aligned16(A) && aligned16(W) && aligned16(out), "v3d_gemm: pointers must be 16-byte aligned");
+  const bool need_bias = epilogue >= EPI_BIAS && epilogue <= EPI_BIAS_RES;
+  const bool need_res = epilogue == EPI_BIAS_RES || epilogue == EPI_RES;
+  V3D_REQUIRE(!need_bias || bias, "v3d_gemm: epilogue %d needs a bias", epilogue);
+  V3D_REQUIRE(!need_res || (res && aligned16(res) && ldr % 8 == 0), "v3d_gemm: epilogue %d needs an aligned residual", epilogue);
+  V3D_REQUIRE(ldo >= (epilogue == EPI_SWIGLU ? N / 2 : N), "v3d_gemm: ldo too small");
+  GemmArgs p;
+  p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldo = ldo; p.res_mod = res_mod;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = N / BN;
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 8) return dtype == V3D_BF16 ? launch_gemv<bf16_t>(p, epilogue, st) : launch_gemv<f16_t>(p, epilogue, st);
+  return dtype == V3D_BF16 ? launch_gemm<bf16_t>(p, epilogue, st) : launch_gemm<f16_t>(p, epilogue, st);
+}

@@ -45,6 +45,7 @@ SIGNATURES = {
     "v3d_sin3d_pe": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p, c_p]),
     "v3d_visual_tokens": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "v3d_embed_gather": (c_i, [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_i, c_p]),
+    "v3d_gemm": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),
     "v3d_greedy_cover_host": (c_i, [c_p, c_i, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_p]),
 }

@@ -209,3 +209,34 @@ def greedy_cover(keys, scene_voxels, max_frames=32):
                                               sel.ctypes.data_as(ctypes.c_void_p), gain.ctypes.data_as(ctypes.c_void_p),
                                               ctypes.byref(na), ctypes.byref(nsel)), "v3d_greedy_cover_host")
     return sel[:picks], gain[:picks], na.value, nsel.value
+
+
+# ------------------------------------------------------------------------------ dense linears
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_ERF, EPI_BIAS_GELU_TANH, EPI_BIAS_RES, EPI_RES, EPI_SWIGLU = range(7)
+
+
+def gemm(a, w, bias=None, res=None, epilogue=EPI_NONE, out=None, res_mod=0):
+    """out = epilogue(a @ w.T).  a [M,K] (row stride may exceed K), w [N,K]; N%128==0, K%64==0."""
+    if not a.is_cuda or not w.is_cuda:
+        raise V3DError("gemm operands must live in HBM")
+    if a.stride(-1) != 1 or w.stride(-1) != 1:
+        raise V3DError("gemm operands must be K-contiguous")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise V3DError(f"gemm: a is [*,{K}] but w is {tuple(w.shape)}")
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=a.dtype, device=a.device)
+    check(lib().v3d_gemm(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res),
+                         res.stride(0) if res is not None else 0, res_mod, _p(out), out.stride(0), M, N, K, _code(a),
+                         epilogue, _stream()), "v3d_gemm")
+    return out
+
+
+def interleave_gate_up(wg, wu):
+    """Row order v3d_gemm's SWIGLU epilogue expects: per 128-row tile, 64 gate rows then the 64 up rows."""
+    I, K = wg.shape
+    assert I % 64 == 0
+    return torch.stack([wg.view(I // 64, 64, K), wu.view(I // 64, 64, K)], 1).reshape(2 * I, K).contiguous()
