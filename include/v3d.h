@@ -142,6 +142,54 @@ int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void*
              int64_t ldr, int res_mod, void* out, int64_t ldo, int M, int N, int K, int dtype, int epilogue,
              void* stream);
 
+/* ------------------------------------------------------------------ norms / rotary ------ */
+
+/* K13  Qwen2RMSNorm, modeling_qwen2.py:85-90: out = weight * T(x * rsqrt(mean(x^2) + eps)), f32 inside. */
+int v3d_rmsnorm(const void* x, int64_t ldx, const void* weight, void* out, int64_t ldo, int64_t rows,
+                int cols, float eps, int dtype, void* stream);
+
+/* nn.LayerNorm of the SigLIP encoder layers, siglip_encoder.py:272-274,292,300 (f32 statistics). */
+int v3d_layernorm(const void* x, int64_t ldx, const void* weight, const void* bias, void* out,
+                  int64_t ldo, int64_t rows, int cols, float eps, int dtype, void* stream);
+
+/* K14  Qwen2RotaryEmbedding.forward, modeling_qwen2.py:106-129, for positions 0..n_pos-1:
+ * cos/sin tables [n_pos, head_dim/2] in dtype.  inv_freq [head_dim/2] f32 comes from the caller
+ * (the reference evaluates 1/(base**(arange/dim)) with torch on the host, :100). */
+int v3d_rope_table_build(const float* inv_freq, int head_dim, int n_pos, int dtype, void* cos_table,
+                         void* sin_table, void* stream);
+
+/* apply_rotary_pos_emb, modeling_qwen2.py:141-173, in place on n_heads heads of head_dim laid out
+ * contiguously from x in every token row (row stride ldx).  Token t uses positions[t] if positions
+ * is non-NULL, else pos0 + t.  (The three M-RoPE position rows are identical on this path, :1003.) */
+int v3d_rope_apply(void* x, int64_t ldx, int64_t tokens, int n_heads, int head_dim,
+                   const void* cos_table, const void* sin_table, int n_pos, const int32_t* positions,
+                   int pos0, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ attention ----------- */
+
+/* K16 / K11  softmax(Q K^T * scale [+ causal mask]) V without materialising the scores.
+ * Prefill: Qwen2 causal GQA (spec: eager Qwen2Attention, modeling_qwen2.py:289-311; runtime:
+ * flash-attn-2 :567-574) with D = 128; SigLIP attention (siglip_encoder.py:213-239) non-causal with
+ * D = 96 (head dim 72 zero-padded by the QKV weight layout; d_out = 72 columns are written).
+ * Element (b, token s, head h, dim d) of q is at q + b*bsq + s*ldq + h*hsq + d (likewise k, v with
+ * bsk/ldk|ldv/hsk and o with bso/ldo/hso); kv head = h / (Hq/Hkv).  With causal != 0 query i sits at
+ * key position q_pos0 + i (q_pos0 = number of cached tokens).  Sq <= 8 with B == 1 takes the
+ * cache-streaming decode path. */
+int v3d_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int Sq, int Sk,
+                  int Hq, int Hkv, int D, int d_out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                  int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0,
+                  float scale, void* stream);
+
+/* ------------------------------------------------------------------ data movement ------- */
+
+/* out[r, 0:cols] = in[r, 0:cols] for strided rows (KV-cache append). */
+int v3d_copy_rows(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int dtype,
+                  void* stream);
+
+/* K10 input: SigLipVisionEmbeddings' Conv2d(kernel = stride = patch), siglip_encoder.py:156-172, as a
+ * GEMM: gathers images [B,3,S,S] into rows [B*(S/patch)^2, kpad], columns (c, ky, kx) zero padded. */
+int v3d_patchify(const void* images, void* out, int B, int S, int patch, int kpad, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* a1  llava/video_utils.py:187  np.linspace(0, total-1, n, dtype=int).  out_host[n]. */

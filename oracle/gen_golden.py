@@ -11,6 +11,8 @@ on the installed transformers).
 
 Usage:  python oracle/gen_golden.py [--only NAME ...]
 """
+import sys
+sys.dont_write_bytecode = True  # never write into the reference tree
 import argparse
 import json
 import os
@@ -330,6 +332,85 @@ def g_box():
     pc = g.normal(size=(200, 6)).astype(np.float32)
     c, s = convert_pc_to_box(pc)
     save("convert_pc_to_box", pc=pc, center=np.array(c), size=np.array(s))
+
+
+def g_llm():
+    """Qwen2 building blocks run through the reference's vendored modeling_qwen2 (eager attention spec)."""
+    from llava.model.language_model.qwen2 import modeling_qwen2 as mq
+    from transformers.models.qwen2.configuration_qwen2 import Qwen2Config
+    cfg = Qwen2Config(vocab_size=320, hidden_size=256, intermediate_size=384, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=4096, rms_norm_eps=1e-6,
+                      rope_theta=1000000.0, use_sliding_window=False, attention_dropout=0.0)
+    cfg.rope_theta = 1000000.0
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(31)
+    layer = mq.Qwen2DecoderLayer(cfg, 0).eval()
+    for n, p_ in layer.named_parameters():
+        with torch.no_grad():
+            if "norm" in n:
+                p_.copy_(1.0 + 0.1 * torch.randn_like(p_))
+            elif "bias" in n:
+                p_.copy_(0.1 * torch.randn_like(p_))
+            else:
+                p_.copy_(0.05 * torch.randn_like(p_))
+    S = 150
+    x = torch.randn(1, S, 256) * 0.7
+    pos = torch.arange(S)[None, :, None].repeat(1, 1, 3)
+    from transformers.modeling_attn_mask_utils import _prepare_4d_causal_attention_mask
+    out = {}
+    weights = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        l2 = mq.Qwen2DecoderLayer(cfg, 0).eval().to(dt)
+        l2.load_state_dict({k: v.to(dt) for k, v in weights.items()})
+        # from_pretrained(torch_dtype=...) (llava/model/builder.py:35-38, 206-228) leaves the explicitly-f32
+        # rotary inv_freq buffer in f32; a bare module.to(dt) would round it - keep the eval-path behaviour.
+        l2.self_attn.rotary_emb.inv_freq = layer.self_attn.rotary_emb.inv_freq.float().clone()
+        xd = x.to(dt)
+        mask = _prepare_4d_causal_attention_mask(None, (1, S), xd, 0)
+        y = l2(xd, attention_mask=mask, position_ids=pos)[0]
+        h = l2.input_layernorm(xd)
+        cos, sin = l2.self_attn.rotary_emb(xd, pos)
+        out["y_" + name] = t2n(y) if dt == torch.bfloat16 else y.numpy()
+        out["norm_" + name] = t2n(h) if dt == torch.bfloat16 else h.numpy()
+        out["cos_" + name] = t2n(cos[0, 0]) if dt == torch.bfloat16 else cos[0, 0].numpy()
+        out["sin_" + name] = t2n(sin[0, 0]) if dt == torch.bfloat16 else sin[0, 0].numpy()
+        m = l2.mlp(h)
+        out["mlp_" + name] = t2n(m) if dt == torch.bfloat16 else m.numpy()
+    save("qwen2_layer", x=x.numpy(), **{"w." + k: v.numpy() for k, v in weights.items()}, **out)
+
+
+def g_vit():
+    """One SigLIP encoder layer + embeddings + the mlp2x_gelu projector, through the reference modules."""
+    from llava.model.multimodal_encoder import siglip_encoder as se
+    from llava.model.multimodal_projector.builder import build_vision_projector
+    cfg = se.SigLipVisionConfig(hidden_size=144, intermediate_size=272, num_hidden_layers=1, num_attention_heads=2,
+                                image_size=56, patch_size=14)
+    torch.manual_seed(41)
+    layer = se.SigLipEncoderLayer(cfg).eval()
+    emb = se.SigLipVisionEmbeddings(cfg).eval()
+    proj = build_vision_projector(types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=144, hidden_size=256)).eval()
+    with torch.no_grad():
+        for mod in (layer, emb, proj):
+            for n, p_ in mod.named_parameters():
+                if "layer_norm" in n and "weight" in n:
+                    p_.copy_(1.0 + 0.1 * torch.randn_like(p_))
+                elif "bias" in n:
+                    p_.copy_(0.1 * torch.randn_like(p_))
+                else:
+                    p_.copy_(0.06 * torch.randn_like(p_))
+    pix = torch.randn(3, 3, 56, 56)
+    out = {}
+    wl = {"layer." + k: v.detach().clone() for k, v in layer.state_dict().items()}
+    we = {"emb." + k: v.detach().clone() for k, v in emb.state_dict().items() if "position_ids" not in k}
+    wp = {"proj." + k: v.detach().clone() for k, v in proj.state_dict().items()}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        e = emb.to(dt)(pix.to(dt))
+        y = layer.to(dt)(e, None)[0]
+        z = proj.to(dt)(y)
+        for k, v in (("emb_", e), ("y_", y), ("proj_", z)):
+            out[k + name] = t2n(v) if dt == torch.bfloat16 else v.numpy()
+        emb.float(); layer.float(); proj.float()
+    save("siglip_layer", pixels=pix.numpy(), **{k: v.numpy() for k, v in {**wl, **we, **wp}.items()}, **out)
 
 
 GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}

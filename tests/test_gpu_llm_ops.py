@@ -1,0 +1,187 @@
+"""GPU parity tests for RMSNorm / LayerNorm / rotary / attention kernels (C ABI) against the torch
+oracle (oracle/llm_oracle.py, itself pinned to the reference modules) run on the CPU in the same
+dtype, so both sides share the reference's rounding points."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import llm_oracle as L
+
+pytestmark = pytest.mark.gpu
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+EPS = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from v3d import ops as _ops
+    return _ops
+
+
+def close(got, want, kind, ulps=2.0, floor=None):
+    got, want = got.float().cpu(), want.float()
+    f = want.abs().mean().item() if floor is None else floor
+    err = (got - want).abs()
+    bound = ulps * EPS[kind] * (want.abs() + f)
+    assert torch.all(err <= bound), f"max err {err.max().item():.4g}, worst ratio {(err / bound).max().item():.3g}"
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("cols", [256, 3584, 1152])
+def test_rmsnorm(ops, kind, cols):
+    g = torch.Generator().manual_seed(cols)
+    x = (torch.randn(301, cols, generator=g) * 2).to(DT[kind])
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(DT[kind])
+    got = ops.rmsnorm(x.cuda(), w.cuda(), 1e-6)
+    want = L.rmsnorm(x, w, 1e-6)
+    close(got, want, kind, ulps=1.01)
+    assert (got.float().cpu() != want.float()).float().mean() < 5e-3   # almost everywhere bit-equal
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_layernorm(ops, kind):
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(733, 1152, generator=g) * 3 + 0.5).to(DT[kind])
+    w = (1 + 0.1 * torch.randn(1152, generator=g)).to(DT[kind])
+    b = (0.1 * torch.randn(1152, generator=g)).to(DT[kind])
+    got = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6)
+    want = F.layer_norm(x.float(), (1152,), w.float(), b.float(), 1e-6).to(DT[kind])
+    close(got, want, kind, ulps=1.01)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_rope_table_and_apply(ops, kind):
+    dt = DT[kind]
+    S, H, KV, D = 700, 4, 2, 128
+    table = ops.RopeTable(D, 8192, 1000000.0, dt, "cuda")
+    pos = torch.arange(S)
+    cos, sin = L.rotary_cos_sin(pos, D, 1000000.0, dt)
+    assert (table.cos[:S].cpu().float() != cos[:, :64].float()).float().mean() < 2e-3
+    close(table.cos[:S], cos[:, :64], kind, ulps=1.01, floor=0.0)
+    close(table.sin[:S], sin[:, :64], kind, ulps=1.01, floor=1e-3)
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(S, (H + 2 * KV) * D, generator=g).to(dt)
+    q = qkv[:, :H * D].view(1, S, H, D).transpose(1, 2)
+    k = qkv[:, H * D:(H + KV) * D].view(1, S, KV, D).transpose(1, 2)
+    qe, ke = L.apply_rope(q, k, cos, sin)
+    dev = qkv.cuda()
+    ops.rope_apply(dev, H + KV, D, table, pos0=0)
+    got_q = dev[:, :H * D].view(S, H, D)
+    got_k = dev[:, H * D:(H + KV) * D].view(S, KV, D)
+    # two rounded products are summed: the bound is in ulps of the operands (|x| up to ~4), not of the sum
+    close(got_q, qe[0].transpose(0, 1), kind, ulps=2.0, floor=2.0)
+    close(got_k, ke[0].transpose(0, 1), kind, ulps=2.0, floor=2.0)
+    assert torch.equal(dev[:, (H + KV) * D:].cpu(), qkv[:, (H + KV) * D:])          # v untouched
+    # decode position offset
+    one = qkv[5:6].clone().cuda()
+    ops.rope_apply(one, H + KV, D, table, pos0=5)
+    assert torch.equal(one, dev[5:6])
+
+
+def ref_attention(q, k, v, causal, scale, q_pos0=0):
+    """f32 reference: q [B,Sq,H,D], k/v [B,Sk,Hkv,D]."""
+    B, Sq, H, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    qf, kf, vf = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    kf = L.repeat_kv(kf, H // Hkv)
+    vf = L.repeat_kv(vf, H // Hkv)
+    s = qf @ kf.transpose(2, 3) * scale
+    if causal:
+        i = torch.arange(Sq)[:, None] + q_pos0
+        j = torch.arange(Sk)[None, :]
+        s = s.masked_fill(j > i, float("-inf"))
+    return (torch.softmax(s, -1) @ vf).transpose(1, 2)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("S", [1, 77, 128, 300, 1000])
+def test_attention_prefill_causal_gqa(ops, kind, S):
+    dt = DT[kind]
+    H, KV, D = 28, 4, 128
+    g = torch.Generator().manual_seed(S)
+    q = torch.randn(1, S, H, D, generator=g).to(dt)
+    k = torch.randn(1, S, KV, D, generator=g).to(dt)
+    v = torch.randn(1, S, KV, D, generator=g).to(dt)
+    got = ops.attention_bshd(q.cuda(), k.cuda(), v.cuda(), causal=True)
+    want = ref_attention(q, k, v, True, 1 / math.sqrt(D))
+    # P is rounded to 16 bit before P.V (as the reference's eager path does); error relative to |v|~1
+    close(got, want, kind, ulps=3.0, floor=0.3)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_attention_matches_reference_eager_rounding(ops, kind):
+    """Against the oracle's eager attention run in the model dtype (the reference's spec, :289-311)."""
+    dt = DT[kind]
+    S, H, KV, D = 300, 28, 4, 128
+    g = torch.Generator().manual_seed(8)
+    q = (torch.randn(1, H, S, D, generator=g) * 0.7).to(dt)
+    k = (torch.randn(1, KV, S, D, generator=g) * 0.7).to(dt)
+    v = torch.randn(1, KV, S, D, generator=g).to(dt)
+    want = L.eager_attention(q, k, v, H // KV, L.causal_mask(S, S, dt)).transpose(1, 2)
+    got = ops.attention_bshd(q.transpose(1, 2).contiguous().cuda(), k.transpose(1, 2).contiguous().cuda(),
+                             v.transpose(1, 2).contiguous().cuda(), causal=True)
+    close(got, want, kind, ulps=4.0, floor=0.3)
+
+
+def test_attention_online_softmax_rescale_branch(ops):
+    """Force the running max to jump at a late KV tile (rule: rare branches need their own test)."""
+    dt = torch.bfloat16
+    S, H, D = 256, 1, 128
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(1, S, H, D, generator=g) * 0.3
+    k = torch.randn(1, S, H, D, generator=g) * 0.3
+    v = torch.randn(1, S, H, D, generator=g)
+    k[0, 200, 0] = q[0, 230, 0] * 40          # one key spikes against one query, in the 4th tile
+    q, k, v = q.to(dt), k.to(dt), v.to(dt)
+    got = ops.attention_bshd(q.cuda(), k.cuda(), v.cuda(), causal=True)
+    want = ref_attention(q, k, v, True, 1 / math.sqrt(D))
+    close(got, want, "bf16", ulps=3.0, floor=0.3)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_attention_vit_noncausal_padded_heads(ops, kind):
+    """SigLIP: 16 heads of 72, stored zero-padded to 96 (QKV weight layout), batch of frames, 729 keys."""
+    dt = DT[kind]
+    B, S, H, D, DP = 3, 729, 16, 72, 96
+    g = torch.Generator().manual_seed(6)
+    qkv = torch.zeros(B, S, 3, H, DP)
+    qkv[..., :D] = torch.randn(B, S, 3, H, D, generator=g)
+    qkv = qkv.to(dt)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    dev = qkv.cuda()
+    got = ops.attention_bshd(dev[:, :, 0], dev[:, :, 1], dev[:, :, 2], causal=False, scale=D ** -0.5, d_out=D)
+    want = ref_attention(q[..., :D], k[..., :D], v[..., :D], False, D ** -0.5)
+    assert got.shape == (B, S, H, D)
+    close(got, want, kind, ulps=3.0, floor=0.1)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("past", [0, 5, 700])
+def test_attention_decode(ops, kind, past):
+    dt = DT[kind]
+    H, KV, D = 28, 4, 128
+    Sk = past + 1
+    g = torch.Generator().manual_seed(past)
+    q = torch.randn(1, 1, H, D, generator=g).to(dt)
+    kc = torch.randn(1, Sk + 9, KV, D, generator=g).to(dt)   # cache longer than the valid prefix
+    vc = torch.randn(1, Sk + 9, KV, D, generator=g).to(dt)
+    out = torch.empty(1, 1, H, D, dtype=dt, device="cuda")
+    kd, vd = kc.cuda(), vc.cuda()
+    ops.attention(q.cuda(), kd, vd, out, 1, 1, Sk, H, KV, D, D, q.stride(1), kd.stride(1), vd.stride(1), out.stride(1),
+                  0, 0, 0, D, D, D, True, past, 1 / math.sqrt(D))
+    want = ref_attention(q, kc[:, :Sk], vc[:, :Sk], True, 1 / math.sqrt(D), q_pos0=past)
+    close(out, want, kind, ulps=2.0, floor=0.3)
+
+
+def test_patchify_and_copy_rows(ops):
+    img = torch.randn(2, 3, 56, 56).to(torch.bfloat16)
+    got = ops.patchify(img.cuda(), 14, 640).cpu()
+    want = F.unfold(img.float(), 14, stride=14).transpose(1, 2).reshape(2 * 16, 588).to(torch.bfloat16)
+    assert torch.equal(got[:, :588], want) and torch.all(got[:, 588:] == 0)
+    src = torch.randn(10, 64).to(torch.bfloat16).cuda()
+    dst = torch.zeros(20, 128, dtype=torch.bfloat16, device="cuda")
+    ops.copy_rows(src, dst[5:15, 32:96])
+    assert torch.equal(dst[5:15, 32:96], src) and dst.float().abs().sum() == src.float().abs().sum()

@@ -1,0 +1,63 @@
+"""Pins oracle/llm_oracle.py (torch restatement of the Qwen2 / SigLIP / projector modules) against
+golden outputs of the reference's own modules (oracle/gen_golden.py g_llm, g_vit).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import llm_oracle as L
+from oracle import v3d_oracle as O
+
+
+def load_w(g, prefix, dt):
+    return {k[len(prefix):]: torch.from_numpy(g[k]).to(dt) for k in g.files if k.startswith(prefix)}
+
+
+def as_t(arr, name):
+    if name == "bf16":
+        return torch.from_numpy(O.bf16_bits_to_f32(arr))
+    return torch.from_numpy(arr)
+
+
+@pytest.mark.parametrize("name,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_qwen2_layer(golden, name, dt):
+    g = golden("qwen2_layer")
+    w = load_w(g, "w.", dt)
+    x = torch.from_numpy(g["x"]).to(dt)
+    S = x.shape[1]
+    pos = torch.arange(S)
+    # the same torch ops in the same order: bit-exact on the same machine
+    assert torch.equal(L.rmsnorm(x, w["input_layernorm.weight"]).float(), as_t(g["norm_" + name], name))
+    cos, sin = L.rotary_cos_sin(pos, 128, 1000000.0, dt)
+    assert torch.equal(cos.float(), as_t(g["cos_" + name], name))
+    assert torch.equal(sin.float(), as_t(g["sin_" + name], name))
+    h = L.rmsnorm(x, w["input_layernorm.weight"])
+    assert torch.equal(L.qwen2_mlp(h, w, "mlp.").float(), as_t(g["mlp_" + name], name))
+    y, _ = L.qwen2_layer(x, w, "", 2, 1, pos, 1000000.0, 1e-6)
+    assert torch.equal(y.float(), as_t(g["y_" + name], name))
+
+
+@pytest.mark.parametrize("name,dt", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_siglip_layer_and_projector(golden, name, dt):
+    g = golden("siglip_layer")
+    w = {}
+    w.update({"L." + k: v for k, v in load_w(g, "layer.", dt).items()})
+    w.update({"E." + k: v for k, v in load_w(g, "emb.", dt).items()})
+    w.update({"P." + k: v for k, v in load_w(g, "proj.", dt).items()})
+    pix = torch.from_numpy(g["pixels"]).to(dt)
+    e = L.siglip_embeddings(pix, w, "E.")
+    assert torch.equal(e.float(), as_t(g["emb_" + name], name))
+    y = L.siglip_layer(e, w, "L.", 2)
+    assert torch.equal(y.float(), as_t(g["y_" + name], name))
+    z = L.projector(y, w, "P.")
+    assert torch.equal(z.float(), as_t(g["proj_" + name], name))
+
+
+def test_kv_cache_decode_matches_full_prefill(golden):
+    """The oracle's incremental path (past_kv) equals recomputing the whole prefix (f32)."""
+    g = golden("qwen2_layer")
+    w = load_w(g, "w.", torch.float32)
+    x = torch.from_numpy(g["x"])[:, :40]
+    full, _ = L.qwen2_layer(x, w, "", 2, 1, torch.arange(40), 1e6, 1e-6)
+    pre, kv = L.qwen2_layer(x[:, :39], w, "", 2, 1, torch.arange(39), 1e6, 1e-6)
+    last, _ = L.qwen2_layer(x[:, 39:], w, "", 2, 1, torch.arange(39, 40), 1e6, 1e-6, past_kv=kv)
+    torch.testing.assert_close(last, full[:, 39:], rtol=1e-5, atol=1e-5)

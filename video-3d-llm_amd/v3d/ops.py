@@ -240,3 +240,91 @@ def interleave_gate_up(wg, wu):
     I, K = wg.shape
     assert I % 64 == 0
     return torch.stack([wg.view(I // 64, 64, K), wu.view(I // 64, 64, K)], 1).reshape(2 * I, K).contiguous()
+
+
+# ------------------------------------------------------------------------------ norms / rotary
+
+
+def rmsnorm(x, weight, eps=1e-6, out=None):
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    check(lib().v3d_rmsnorm(_p(x), x.stride(0), _p(weight), _p(out), out.stride(0), rows, cols, eps, _code(x), _stream()),
+          "v3d_rmsnorm")
+    return out
+
+
+def layernorm(x, weight, bias, eps=1e-6, out=None):
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    check(lib().v3d_layernorm(_p(x), x.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), rows, cols, eps, _code(x),
+                              _stream()), "v3d_layernorm")
+    return out
+
+
+def reference_inv_freq(head_dim, base):
+    """modeling_qwen2.py:100 evaluated as the reference does (torch on the host)."""
+    return 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+
+
+class RopeTable:
+    def __init__(self, head_dim, n_pos, base, dtype, device, inv_freq=None):
+        self.head_dim, self.n_pos, self.dtype = head_dim, n_pos, dtype
+        if inv_freq is None:
+            inv_freq = reference_inv_freq(head_dim, base)
+        self.inv_freq = inv_freq.to(device=device, dtype=torch.float32).contiguous()
+        self.cos = torch.empty((n_pos, head_dim // 2), dtype=dtype, device=device)
+        self.sin = torch.empty((n_pos, head_dim // 2), dtype=dtype, device=device)
+        check(lib().v3d_rope_table_build(_p(self.inv_freq), head_dim, n_pos, _DT[dtype], _p(self.cos), _p(self.sin),
+                                         _stream()), "v3d_rope_table_build")
+
+
+def rope_apply(x, n_heads, head_dim, table, pos0=0, positions=None):
+    """In place on the first n_heads*head_dim columns of x [tokens, ld]."""
+    tokens = x.shape[0]
+    check(lib().v3d_rope_apply(_p(x), x.stride(0), tokens, n_heads, head_dim, _p(table.cos), _p(table.sin), table.n_pos,
+                               _p(positions), pos0, _code(x), _stream()), "v3d_rope_apply")
+    return x
+
+
+# ------------------------------------------------------------------------------ attention
+
+
+def attention(q, k, v, out, B, Sq, Sk, Hq, Hkv, D, d_out, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, causal,
+              q_pos0, scale):
+    """Raw strided form (see include/v3d.h); q/k/v/out are tensors whose data_ptr is element (0,0,0,0)."""
+    check(lib().v3d_attention(_p(q), _p(k), _p(v), _p(out), _code(q), B, Sq, Sk, Hq, Hkv, D, d_out, ldq, ldk, ldv, ldo,
+                              bsq, bsk, bso, hsq, hsk, hso, 1 if causal else 0, q_pos0, scale, _stream()), "v3d_attention")
+    return out
+
+
+def attention_bshd(q, k, v, causal, scale=None, q_pos0=0, d_out=None):
+    """Convenience: q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (last dim contiguous) -> [B,Sq,Hq,d_out]."""
+    B, Sq, Hq, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    d_out = d_out or D
+    scale = scale if scale is not None else 1.0 / math.sqrt(d_out)
+    out = torch.empty((B, Sq, Hq, d_out), dtype=q.dtype, device=q.device)
+    return attention(q, k, v, out, B, Sq, Sk, Hq, Hkv, D, d_out, q.stride(1), k.stride(1), v.stride(1), out.stride(1),
+                     q.stride(0), k.stride(0), out.stride(0), q.stride(2), k.stride(2), out.stride(2), causal, q_pos0, scale)
+
+
+# ------------------------------------------------------------------------------ data movement
+
+
+def copy_rows(src, dst, cols=None):
+    rows = src.shape[0]
+    cols = cols or src.shape[1]
+    check(lib().v3d_copy_rows(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _code(src), _stream()),
+          "v3d_copy_rows")
+    return dst
+
+
+def patchify(images, patch=14, kpad=640):
+    B, C, S, _ = images.shape
+    g = S // patch
+    im = _dev(images, "images")
+    out = torch.empty((B * g * g, kpad), dtype=im.dtype, device=im.device)
+    check(lib().v3d_patchify(_p(im), _p(out), B, S, patch, kpad, _code(im), _stream()), "v3d_patchify")
+    return out
