@@ -1,0 +1,66 @@
+"""CPU oracle for one whole (scene, question) pass: SigLIP tower -> projector -> coordinate pool /
+voxelise -> bilinear pool + 3-D PE + newline -> splice into text embeddings -> Qwen2 prefill -> greedy
+decode.  Composition of oracle/llm_oracle.py (torch) and oracle/v3d_oracle.py (numpy) in the order
+LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal (llava/model/llava_arch.py:336-836, eval
+branch) and LlavaQwenForCausalLM.generate (llava/model/language_model/llava_qwen.py:208-236) use.
+
+TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline)."""
+import numpy as np
+import torch
+
+from . import llm_oracle as L
+from . import v3d_oracle as O
+
+KIND = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}
+IMAGE_TOKEN_INDEX = -200   # llava/constants.py
+
+
+def _np(t):
+    return t.float().numpy()
+
+
+def visual_sequence(sd, world_coords, feats, dtype):
+    """feats [F,729,C] (dtype) + coords [F,384,384,3] (dtype) -> (ids int32 [F,14,14,3], tokens [F*210, C])."""
+    kind = KIND[dtype]
+    C = feats.shape[-1]
+    d = torch.arange(C // 3, dtype=torch.float32)
+    dim_t = (10000 ** (2 * (d // 2) / (C // 3))).numpy()      # position_encoding.py:24-25, torch pow on the host
+    ids, seq = O.fused_visual_tokens(_np(world_coords), _np(feats), _np(sd["model.image_newline"].to(dtype)), kind, dim_t=dim_t)
+    return ids, torch.from_numpy(seq).to(dtype)
+
+
+def inputs_embeds(sd, input_ids, vis, dtype):
+    """llava_arch.py:684-745 for one sample with one <image> token."""
+    ids = input_ids.tolist()
+    at = ids.index(IMAGE_TOKEN_INDEX)
+    emb = sd["model.embed_tokens.weight"].to(dtype)
+    pre = emb[input_ids[:at]]
+    post = emb[input_ids[at + 1:]]
+    return torch.cat([pre, vis, post], 0)
+
+
+def scene_forward(sd, cfg, input_ids, images, world_coords, dtype, max_new_tokens=4):
+    """Returns a dict of the intermediates the GPU tests compare against."""
+    w = {k: v.to(dtype) for k, v in sd.items()}
+    tower = L.siglip_tower(images.to(dtype), w, cfg["vit_layers"], cfg["vit_heads"])
+    feats = L.projector(tower, w)
+    ids, vis = visual_sequence(w, world_coords.to(dtype), feats, dtype)
+    x = inputs_embeds(w, input_ids, vis, dtype)[None]
+    logits, hidden, kv = L.qwen2_model(x, w, cfg)
+    out = dict(tower=tower, feats=feats, ids=ids, vis=vis, embeds=x[0], logits_last=logits[0, -1], hidden_last=hidden[0, -1])
+    toks = []
+    tok = int(torch.argmax(logits[0, -1]))
+    pos = x.shape[1]
+    step_logits = []
+    for _ in range(max_new_tokens):
+        toks.append(tok)
+        if len(toks) == max_new_tokens:
+            break
+        xe = w["model.embed_tokens.weight"][tok][None, None]
+        lg, _, kv = L.qwen2_model(xe, w, cfg, past=kv, pos0=pos)
+        step_logits.append(lg[0, -1])
+        pos += 1
+        tok = int(torch.argmax(lg[0, -1]))
+    out["tokens"] = toks
+    out["step_logits"] = step_logits
+    return out

@@ -248,7 +248,7 @@ extern "C" int v3d_copy_rows(const void* in, int64_t ldi, void* out, int64_t ldo
 }
 
 extern "C" int v3d_patchify(const void* images, void* out, int B, int S, int patch, int kpad, int dtype, void* stream) {
-  V3D_REQUIRE(images && out && B > 0 && S > 0 && patch > 0 && S % patch == 0 && kpad >= 3 * patch * patch, "v3d_patchify: bad arguments");
+  V3D_REQUIRE(images && out && B > 0 && S >= patch && patch > 0 && kpad >= 3 * patch * patch, "v3d_patchify: bad arguments");  // padding="valid": trailing S % patch pixels are unused
   const int g = S / patch;
   int64_t blocks = ((int64_t)B * g * g * kpad + 255) / 256;
   if (blocks > 16384) blocks = 16384;

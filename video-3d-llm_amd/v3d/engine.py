@@ -1,0 +1,343 @@
+"""Device-resident engine for the position-aware video -> LLM forward path.
+
+Holds the SigLIP tower, the mlp2x_gelu projector and the Qwen2 decoder as HIP-ready weight
+layouts in HBM (fused QKV, tile-interleaved gate/up, zero-padded SigLIP heads and MLP width) plus
+pre-allocated workspaces, and runs the forward by launching kernels through the C ABI.
+PyTorch supplies memory and the stream only; there is no torch compute on the path.
+
+State-dict keys are the reference's (llava_qwen.py / siglip_encoder.py / builder.py):
+  model.vision_tower.vision_tower.vision_model.{embeddings,encoder.layers.N}.*
+  model.mm_projector.{0,2}.{weight,bias}, model.image_newline, model.embed_tokens.weight,
+  model.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj,input_layernorm,post_attention_layernorm}.*
+  model.norm.weight, lm_head.weight
+"""
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+from ._native import V3DError
+
+
+def _up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class VitConfig:
+    hidden: int = 1152
+    inter: int = 4304
+    layers: int = 26          # 27 in the checkpoint, last one deleted (siglip_encoder.py:570)
+    heads: int = 16
+    image: int = 384
+    patch: int = 14
+    eps: float = 1e-6
+
+
+@dataclass
+class LlmConfig:
+    hidden: int = 3584
+    inter: int = 18944
+    layers: int = 28
+    heads: int = 28
+    kv_heads: int = 4
+    vocab: int = 152064
+    eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    max_pos: int = 8192       # rotary table / KV-cache capacity
+
+
+@dataclass
+class EngineConfig:
+    vit: VitConfig = field(default_factory=VitConfig)
+    llm: LlmConfig = field(default_factory=LlmConfig)
+    pool_out: int = 14                     # 27 -> 14 bilinear pool (mm_spatial_pool_stride 2)
+    min_xyz: tuple = (-15, -15, -5)
+    max_xyz: tuple = (15, 15, 5)
+    voxel_size: float = 0.1
+
+
+def random_state_dict(cfg: EngineConfig, dtype, device, seed=0, std=0.02):
+    """Random-init weights at the configured widths under the reference's state-dict keys."""
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def rn(*shape, s=std):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * s).to(dtype)
+
+    sd = {}
+    v, l = cfg.vit, cfg.llm
+    vp = "model.vision_tower.vision_tower.vision_model."
+    n_patches = (v.image // v.patch) ** 2
+    sd[vp + "embeddings.patch_embedding.weight"] = rn(v.hidden, 3, v.patch, v.patch)
+    sd[vp + "embeddings.patch_embedding.bias"] = rn(v.hidden)
+    sd[vp + "embeddings.position_embedding.weight"] = rn(n_patches, v.hidden)
+    for i in range(v.layers):
+        p = vp + f"encoder.layers.{i}."
+        for nme in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{nme}.weight"] = rn(v.hidden, v.hidden)
+            sd[p + f"self_attn.{nme}.bias"] = rn(v.hidden)
+        sd[p + "layer_norm1.weight"] = 1 + rn(v.hidden)
+        sd[p + "layer_norm1.bias"] = rn(v.hidden)
+        sd[p + "layer_norm2.weight"] = 1 + rn(v.hidden)
+        sd[p + "layer_norm2.bias"] = rn(v.hidden)
+        sd[p + "mlp.fc1.weight"] = rn(v.inter, v.hidden)
+        sd[p + "mlp.fc1.bias"] = rn(v.inter)
+        sd[p + "mlp.fc2.weight"] = rn(v.hidden, v.inter)
+        sd[p + "mlp.fc2.bias"] = rn(v.hidden)
+    sd["model.mm_projector.0.weight"] = rn(l.hidden, v.hidden)
+    sd["model.mm_projector.0.bias"] = rn(l.hidden)
+    sd["model.mm_projector.2.weight"] = rn(l.hidden, l.hidden)
+    sd["model.mm_projector.2.bias"] = rn(l.hidden)
+    sd["model.image_newline"] = rn(l.hidden)
+    sd["model.embed_tokens.weight"] = rn(l.vocab, l.hidden)
+    hd = l.hidden // l.heads
+    for i in range(l.layers):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = rn(l.hidden, l.hidden)
+        sd[p + "self_attn.q_proj.bias"] = rn(l.hidden)
+        sd[p + "self_attn.k_proj.weight"] = rn(l.kv_heads * hd, l.hidden)
+        sd[p + "self_attn.k_proj.bias"] = rn(l.kv_heads * hd)
+        sd[p + "self_attn.v_proj.weight"] = rn(l.kv_heads * hd, l.hidden)
+        sd[p + "self_attn.v_proj.bias"] = rn(l.kv_heads * hd)
+        sd[p + "self_attn.o_proj.weight"] = rn(l.hidden, l.hidden)
+        sd[p + "mlp.gate_proj.weight"] = rn(l.inter, l.hidden)
+        sd[p + "mlp.up_proj.weight"] = rn(l.inter, l.hidden)
+        sd[p + "mlp.down_proj.weight"] = rn(l.hidden, l.inter)
+        sd[p + "input_layernorm.weight"] = 1 + rn(l.hidden)
+        sd[p + "post_attention_layernorm.weight"] = 1 + rn(l.hidden)
+    sd["model.norm.weight"] = 1 + rn(l.hidden)
+    sd["lm_head.weight"] = rn(l.vocab, l.hidden)
+    return sd
+
+
+def _pad2(w, rows, cols):
+    out = torch.zeros((rows, cols), dtype=w.dtype, device=w.device)
+    out[: w.shape[0], : w.shape[1]] = w
+    return out
+
+
+def _pad1(b, n):
+    out = torch.zeros(n, dtype=b.dtype, device=b.device)
+    out[: b.shape[0]] = b
+    return out
+
+
+class Engine:
+    VIT_DP = 96      # SigLIP head dim 72, zero padded to the attention kernel's 96
+
+    def __init__(self, cfg: EngineConfig, state_dict, dtype=torch.bfloat16, device="cuda", max_frames=32):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        v, l = cfg.vit, cfg.llm
+        self.hd = l.hidden // l.heads
+        if self.hd != 128:
+            raise V3DError("the Qwen2 path needs head_dim 128 (mrope_section [32,16,16]*2, modeling_qwen2.py:162)")
+        self.vhd = v.hidden // v.heads
+        if self.vhd not in (72,):
+            raise V3DError("the SigLIP path needs head_dim 72")
+        if l.hidden % 128 or l.inter % 64:
+            raise V3DError("LLM hidden must be a multiple of 128 and intermediate of 64")
+        sd = {k: t.to(device=device, dtype=dtype) for k, t in state_dict.items()}
+        self._prep_vit(sd)
+        self._prep_llm(sd)
+        self.newline = sd["model.image_newline"].contiguous()
+        self.embed = sd["model.embed_tokens.weight"].contiguous()
+        n_ids = int(round((max(cfg.max_xyz[0] - cfg.min_xyz[0], cfg.max_xyz[1] - cfg.min_xyz[1],
+                               cfg.max_xyz[2] - cfg.min_xyz[2])) / cfg.voxel_size)) + 1
+        self.pe_table = ops.Sin3DTable(l.hidden, n_ids, dtype, device)
+        self.rope = ops.RopeTable(self.hd, l.max_pos, l.rope_theta, dtype, device)
+        self._alloc(max_frames)
+
+    # ------------------------------------------------------------------ weight layouts
+    def _prep_vit(self, sd):
+        v = self.cfg.vit
+        H, Hp, Hk = v.hidden, _up(v.hidden, 128), _up(v.hidden, 64)
+        I, Ip = v.inter, _up(v.inter, 128)
+        DP, nh, hd = self.VIT_DP, v.heads, self.vhd
+        self.v_Hp, self.v_Hk, self.v_Ip = Hp, Hk, Ip
+        self.v_nqkv = _up(3 * nh * DP, 128)
+        self.v_kpatch = _up(3 * v.patch * v.patch, 64)
+        vp = "model.vision_tower.vision_tower.vision_model."
+        self.v_pe_w = _pad2(sd[vp + "embeddings.patch_embedding.weight"].reshape(H, -1), Hp, self.v_kpatch)
+        self.v_pe_b = _pad1(sd[vp + "embeddings.patch_embedding.bias"], Hp)
+        self.v_pos = _pad2(sd[vp + "embeddings.position_embedding.weight"], (v.image // v.patch) ** 2, Hp)
+        self.v_layers = []
+        for i in range(v.layers):
+            p = vp + f"encoder.layers.{i}."
+            wqkv = torch.zeros((self.v_nqkv, Hk), dtype=self.dtype, device=self.device)
+            bqkv = torch.zeros(self.v_nqkv, dtype=self.dtype, device=self.device)
+            for part, nme in enumerate(("q_proj", "k_proj", "v_proj")):
+                w = sd[p + f"self_attn.{nme}.weight"].view(nh, hd, H)
+                b = sd[p + f"self_attn.{nme}.bias"].view(nh, hd)
+                dst = wqkv[part * nh * DP:(part + 1) * nh * DP].view(nh, DP, Hk)
+                dst[:, :hd, :H] = w
+                bqkv[part * nh * DP:(part + 1) * nh * DP].view(nh, DP)[:, :hd] = b
+            self.v_layers.append(dict(
+                ln1_w=sd[p + "layer_norm1.weight"].contiguous(), ln1_b=sd[p + "layer_norm1.bias"].contiguous(),
+                ln2_w=sd[p + "layer_norm2.weight"].contiguous(), ln2_b=sd[p + "layer_norm2.bias"].contiguous(),
+                wqkv=wqkv, bqkv=bqkv,
+                wo=_pad2(sd[p + "self_attn.out_proj.weight"], Hp, Hk), bo=_pad1(sd[p + "self_attn.out_proj.bias"], Hp),
+                w1=_pad2(sd[p + "mlp.fc1.weight"], Ip, Hk), b1=_pad1(sd[p + "mlp.fc1.bias"], Ip),
+                w2=_pad2(sd[p + "mlp.fc2.weight"], Hp, Ip), b2=_pad1(sd[p + "mlp.fc2.bias"], Hp)))
+        self.p_w0 = _pad2(sd["model.mm_projector.0.weight"], self.cfg.llm.hidden, Hk)
+        self.p_b0 = sd["model.mm_projector.0.bias"].contiguous()
+        self.p_w2 = sd["model.mm_projector.2.weight"].contiguous()
+        self.p_b2 = sd["model.mm_projector.2.bias"].contiguous()
+
+    def _prep_llm(self, sd):
+        l = self.cfg.llm
+        self.l_layers = []
+        for i in range(l.layers):
+            p = f"model.layers.{i}."
+            wqkv = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"],
+                              sd[p + "self_attn.v_proj.weight"]], 0)
+            bqkv = torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"],
+                              sd[p + "self_attn.v_proj.bias"]], 0)
+            nq = _up(wqkv.shape[0], 128)
+            self.l_layers.append(dict(
+                ln1=sd[p + "input_layernorm.weight"].contiguous(), ln2=sd[p + "post_attention_layernorm.weight"].contiguous(),
+                wqkv=_pad2(wqkv, nq, l.hidden), bqkv=_pad1(bqkv, nq),
+                wo=sd[p + "self_attn.o_proj.weight"].contiguous(),
+                wgu=ops.interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]),
+                wd=sd[p + "mlp.down_proj.weight"].contiguous()))
+        self.l_nqkv = self.l_layers[0]["wqkv"].shape[0] if self.l_layers else 0
+        self.l_norm = sd["model.norm.weight"].contiguous()
+        self.l_head = _pad2(sd["lm_head.weight"], _up(l.vocab, 128), l.hidden)
+
+    # ------------------------------------------------------------------ workspaces
+    def _alloc(self, max_frames):
+        v, l = self.cfg.vit, self.cfg.llm
+        dt, dev = self.dtype, self.device
+        T = max_frames * (v.image // v.patch) ** 2
+        z = lambda *s: torch.zeros(s, dtype=dt, device=dev)
+        self.max_frames = max_frames
+        self.v_x, self.v_h = z(T, self.v_Hp), z(T, self.v_Hp)
+        self.v_qkv, self.v_att, self.v_mlp = z(T, self.v_nqkv), z(T, self.v_Hp), z(T, self.v_Ip)
+        self.p_h, self.feat = z(T, l.hidden), z(T, l.hidden)
+        S = l.max_pos
+        self.l_x, self.l_h = z(S, l.hidden), z(S, l.hidden)
+        self.l_qkv, self.l_att, self.l_act = z(S, self.l_nqkv), z(S, l.hidden), z(S, l.inter)
+        kvw = 2 * l.kv_heads * self.hd
+        self.kv = [z(S, kvw) for _ in range(l.layers)]
+        self.l_last = z(8, l.hidden)
+        self.logits = z(8, self.l_head.shape[0])
+        self.kv_len = 0
+
+    # ------------------------------------------------------------------ ViT + projector (a9, a10)
+    def encode_images(self, images):
+        """[F,3,S,S] -> [F, (S/patch)^2, llm.hidden]   (encode_images, llava_arch.py:275-280)."""
+        v = self.cfg.vit
+        F_ = images.shape[0]
+        if F_ > self.max_frames:
+            raise V3DError(f"{F_} frames > engine capacity {self.max_frames}")
+        n = (v.image // v.patch) ** 2
+        T = F_ * n
+        H, Hk, DP, nh = v.hidden, self.v_Hk, self.VIT_DP, v.heads
+        x, h, qkv, att, mlp = self.v_x[:T], self.v_h[:T], self.v_qkv[:T], self.v_att[:T], self.v_mlp[:T]
+        patches = ops.patchify(images.to(self.dtype), v.patch, self.v_kpatch)
+        ops.gemm(patches, self.v_pe_w, bias=self.v_pe_b, res=self.v_pos, res_mod=n, epilogue=ops.EPI_BIAS_RES, out=x)
+        scale = self.vhd ** -0.5
+        for L in self.v_layers:
+            ops.layernorm(x[:, :H], L["ln1_w"], L["ln1_b"], v.eps, out=h[:, :H])
+            ops.gemm(h[:, :Hk], L["wqkv"], bias=L["bqkv"], epilogue=ops.EPI_BIAS, out=qkv)
+            ld = qkv.stride(0)
+            ops.attention(qkv, qkv[:, nh * DP:], qkv[:, 2 * nh * DP:], att, F_, n, n, nh, nh, DP, self.vhd,
+                          ld, ld, ld, att.stride(0), n * ld, n * ld, n * att.stride(0), DP, DP, self.vhd, False, 0, scale)
+            ops.gemm(att[:, :Hk], L["wo"], bias=L["bo"], res=x, epilogue=ops.EPI_BIAS_RES, out=x)
+            ops.layernorm(x[:, :H], L["ln2_w"], L["ln2_b"], v.eps, out=h[:, :H])
+            ops.gemm(h[:, :Hk], L["w1"], bias=L["b1"], epilogue=ops.EPI_BIAS_GELU_TANH, out=mlp)
+            ops.gemm(mlp, L["w2"], bias=L["b2"], res=x, epilogue=ops.EPI_BIAS_RES, out=x)
+        ph, feat = self.p_h[:T], self.feat[:T]
+        ops.gemm(x[:, :Hk], self.p_w0, bias=self.p_b0, epilogue=ops.EPI_BIAS_GELU_ERF, out=ph)
+        ops.gemm(ph, self.p_w2, bias=self.p_b2, epilogue=ops.EPI_BIAS, out=feat)
+        return feat.view(F_, n, self.cfg.llm.hidden)
+
+    def vit_hidden(self, n_frames):
+        """SigLipVisionTower output of the last encode_images call (hidden_states[-1]), [F, n, hidden]."""
+        n = (self.cfg.vit.image // self.cfg.vit.patch) ** 2
+        return self.v_x[: n_frames * n, : self.cfg.vit.hidden].reshape(n_frames, n, -1)
+
+    # ------------------------------------------------------------------ fusion (a11-a17)
+    def voxel_ids(self, world_coords):
+        """[F,384,384,3] (model dtype) -> int32 [F,14,14,3]   (llava_arch.py:403, 416)."""
+        c = self.cfg
+        _, _, ids = ops.coord_pool_voxel(world_coords, 27, c.min_xyz, c.max_xyz, c.voxel_size, want_avg=False, want_vox=False)
+        return ids
+
+    def build_inputs_embeds(self, input_ids, feats, ids, image_token=-200):
+        """prepare_inputs_labels_for_multimodal for one video sample (llava_arch.py:336-836, eval branch):
+        text embeddings around the <image> slot, visual tokens written in place.  Returns [S, hidden] view."""
+        F_ = feats.shape[0]
+        n = self.cfg.pool_out
+        side = int(math.isqrt(feats.shape[1]))
+        n_vis = F_ * n * (n + 1)
+        ids_list = input_ids.tolist()
+        if ids_list.count(image_token) != 1:
+            raise V3DError("exactly one <image> token per prompt (model_scanqa.py:61)")
+        at = ids_list.index(image_token)
+        pre = input_ids[:at]
+        post = input_ids[at + 1:]
+        S = len(pre) + n_vis + len(post)
+        if S > self.cfg.llm.max_pos:
+            raise V3DError(f"sequence {S} exceeds engine capacity {self.cfg.llm.max_pos}")
+        x = self.l_x[:S]
+        if len(pre):
+            ops.embed_gather(self.embed, pre.to(self.device), out=x[: len(pre)])
+        ops.visual_tokens(feats, ids, self.pe_table, self.newline, side=side, n=n, pool=True, out=x[len(pre): len(pre) + n_vis])
+        if len(post):
+            ops.embed_gather(self.embed, post.to(self.device), out=x[len(pre) + n_vis:])
+        return x
+
+    # ------------------------------------------------------------------ Qwen2 decoder (a18-a22)
+    def llm_forward(self, x, pos0):
+        """Runs the decoder over rows x [S, hidden] (in place) at positions pos0.., appends K/V to the
+        cache and returns the f32 logits of the LAST row only ([vocab]); the reference materialises all
+        S rows of logits (modeling_qwen2.py:1190-1192) but generation reads only the last."""
+        l = self.cfg.llm
+        S = x.shape[0]
+        hd, nh, nkv = self.hd, l.heads, l.kv_heads
+        h, qkv, att, act = self.l_h[:S], self.l_qkv[:S], self.l_att[:S], self.l_act[:S]
+        kvw = nkv * hd
+        scale = 1.0 / math.sqrt(hd)
+        for i, L in enumerate(self.l_layers):
+            ops.rmsnorm(x, L["ln1"], l.eps, out=h)
+            ops.gemm(h, L["wqkv"], bias=L["bqkv"], epilogue=ops.EPI_BIAS, out=qkv)
+            ops.rope_apply(qkv, nh + nkv, hd, self.rope, pos0=pos0)
+            cache = self.kv[i]
+            ops.copy_rows(qkv[:, nh * hd:], cache[pos0: pos0 + S], cols=2 * kvw)
+            ops.attention(qkv, cache, cache[:, kvw:], att, 1, S, pos0 + S, nh, nkv, hd, hd, qkv.stride(0), cache.stride(0),
+                          cache.stride(0), att.stride(0), 0, 0, 0, hd, hd, hd, True, pos0, scale)
+            ops.gemm(att, L["wo"], res=x, epilogue=ops.EPI_RES, out=x)
+            ops.rmsnorm(x, L["ln2"], l.eps, out=h)
+            ops.gemm(h, L["wgu"], epilogue=ops.EPI_SWIGLU, out=act)
+            ops.gemm(act, L["wd"], res=x, epilogue=ops.EPI_RES, out=x)
+        self.kv_len = pos0 + S
+        ops.rmsnorm(x[S - 1:], self.l_norm, l.eps, out=self.l_last[:1])
+        ops.gemm(self.l_last[:1], self.l_head, out=self.logits[:1])
+        return self.logits[0, : l.vocab]
+
+    def last_hidden(self):
+        return self.l_last[0]
+
+    # ------------------------------------------------------------------ generate (a23)
+    @torch.no_grad()
+    def generate(self, input_ids, images, world_coords, max_new_tokens=16, eos_token_id=None):
+        """Greedy decoding of one (scene, question): LlavaQwenForCausalLM.generate (llava_qwen.py:208-236)
+        with do_sample=False, num_beams=1 as model_scanqa.py:173-185 calls it."""
+        feats = self.encode_images(images)
+        ids = self.voxel_ids(world_coords.to(self.dtype))
+        x = self.build_inputs_embeds(input_ids, feats, ids)
+        S = x.shape[0]
+        logits = self.llm_forward(x, 0)
+        out = []
+        tok = torch.argmax(logits).view(1)
+        for step in range(max_new_tokens):
+            out.append(tok)
+            if eos_token_id is not None and int(tok) == eos_token_id:
+                break
+            if step + 1 == max_new_tokens:
+                break
+            xe = ops.embed_gather(self.embed, tok, out=self.l_x[S + step: S + step + 1])
+            logits = self.llm_forward(xe, S + step)
+            tok = torch.argmax(logits).view(1)
+        return torch.cat(out)
