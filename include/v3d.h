@@ -180,6 +180,15 @@ int v3d_attention(const void* q, const void* k, const void* v, void* o, int dtyp
                   int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0,
                   float scale, void* stream);
 
+/* Decode step of K16 (one new query row against the K/V cache, modeling_qwen2.py:282-311 with a
+ * DynamicCache): split-KV so the cache is streamed once by the whole chip.  q [Hq*128] (head stride hsq),
+ * caches [Sk, ...] with row strides ldk/ldv and kv-head stride hsk, o [Hq*128] (head stride hso).
+ * workspace: device scratch of at least v3d_attention_decode_workspace_bytes(Hq, 1024/Hkv) bytes. */
+int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits);
+int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int Sk,
+                         int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ data movement ------- */
 
 /* out[r, 0:cols] = in[r, 0:cols] for strided rows (KV-cache append). */

@@ -336,6 +336,112 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Split-KV decode attention (one query row, long cache): workgroup = (kv head, key split); the K/V
+// rows of the split are streamed ONCE for all `group` query heads that share the kv head
+// (16 lanes x 16 B per 256-byte row, 16 key slots per workgroup pass), f32 online softmax per
+// (slot, head), slots merged through LDS, one partial (m, l, o[128]) per (split, head) written to
+// the workspace; a second tiny kernel merges the splits.  HBM-bound: cache bytes read once.
+// ------------------------------------------------------------------------------------------
+constexpr int DEC_MAXG = 8;
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, int n_split, float* __restrict__ ws) {
+  constexpr int D = 128;
+  __shared__ float sm_m[16][G], sm_l[16][G];
+  __shared__ float sm_o[16][G][D + 4];
+  const int tid = threadIdx.x;
+  const int slot = tid >> 4, cl = tid & 15;       // 16 key slots, 16 lanes per key row
+  const int hk = blockIdx.x, split = blockIdx.y;
+  const int n_keys = p.q_pos0 + 1 < p.Sk ? p.q_pos0 + 1 : p.Sk;
+  const int per = (n_keys + n_split - 1) / n_split;
+  const int k_begin = split * per;
+  int k_end = k_begin + per;
+  k_end = k_end < n_keys ? k_end : n_keys;
+  const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * p.hsk;
+  const uint16_t* V = (const uint16_t*)p.v + (int64_t)hk * p.hsk;
+  float qv[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const uint4 q4 = *reinterpret_cast<const uint4*>((const uint16_t*)p.q + (int64_t)(hk * G + g) * p.hsq + cl * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[g][j] = vec_get<T>(q4, j) * p.scale_log2;
+  }
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+  }
+  for (int key = k_begin + slot; key < k_end; key += 16) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(K + (int64_t)key * p.ldk + cl * 8);
+    const uint4 v4 = *reinterpret_cast<const uint4*>(V + (int64_t)key * p.ldv + cl * 8);
+    float kf[8], vf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kf[j] = vec_get<T>(k4, j); vf[j] = vec_get<T>(v4, j); }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf(qv[g][j], kf[j], s);
+      s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+      const float m_new = fmaxf(m[g], s);
+      const float alpha = exp2f(m[g] - m_new);
+      const float e = exp2f(s - m_new);
+      l[g] = l[g] * alpha + e;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[g][j] = fmaf(e, vf[j], acc[g][j] * alpha);
+      m[g] = m_new;
+    }
+  }
+  // merge the 16 key slots
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (cl == 0) { sm_m[slot][g] = m[g]; sm_l[slot][g] = l[g]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm_o[slot][g][cl * 8 + j] = acc[g][j];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, d = idx - g * D;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) mm = fmaxf(mm, sm_m[s_][g]);
+    const float mu = mm == -INFINITY ? 0.f : mm;
+    float lt = 0.f, ot = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const float f = exp2f(sm_m[s_][g] - mu);     // -inf slots contribute 0
+      lt += sm_l[s_][g] * f;
+      ot += sm_o[s_][g][d] * f;
+    }
+    const int head = hk * G + g;
+    float* w = ws + ((size_t)split * p.Hq + head) * (D + 2);
+    w[d] = ot;
+    if (d == 0) { w[D] = mm; w[D + 1] = lt; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, int n_split, const float* __restrict__ ws) {
+  constexpr int D = 128;
+  const int head = blockIdx.x, d = threadIdx.x;
+  float mm = -INFINITY;
+  for (int s = 0; s < n_split; ++s) mm = fmaxf(mm, ws[((size_t)s * p.Hq + head) * (D + 2) + D]);
+  const float mu = mm == -INFINITY ? 0.f : mm;
+  float lt = 0.f, ot = 0.f;
+  for (int s = 0; s < n_split; ++s) {
+    const float* w = ws + ((size_t)s * p.Hq + head) * (D + 2);
+    const float f = exp2f(w[D] - mu);
+    lt += w[D + 1] * f;
+    ot += w[d] * f;
+  }
+  T* O = (T*)p.o + (int64_t)head * p.hso;
+  O[d] = from_f32<T>(lt > 0.f ? ot / lt : 0.f);
+}
+
 template <typename T>
 static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t st) {
   const dim3 grid((p.Sq + AT_BQ - 1) / AT_BQ, p.Hq, B), block(256);
@@ -389,4 +495,46 @@ extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* 
     return check_launch("v3d_attention (decode)");
   }
   return dtype == V3D_BF16 ? launch_attn<bf16_t>(p, D, causal, B, st) : launch_attn<f16_t>(p, D, causal, B, st);
+}
+
+
+extern "C" int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits) {
+  return (int64_t)max_splits * Hq * (128 + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int Sk,
+                                    int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(q && k_cache && v_cache && o && workspace, "v3d_attention_decode: null pointer");
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_attention_decode: dtype must be f16 or bf16");
+  V3D_REQUIRE(Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DEC_MAXG, "v3d_attention_decode: bad head counts");
+  V3D_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0 && hsq % 8 == 0 && hsk % 8 == 0 && aligned16(q) && aligned16(k_cache) && aligned16(v_cache),
+              "v3d_attention_decode: alignment");
+  int n_split = (Sk + 127) / 128;                    // >= 128 keys per split keeps the merge cheap
+  const int cap = 1024 / Hkv;                        // ~4 workgroups per CU
+  if (n_split > cap) n_split = cap;
+  if (n_split < 1) n_split = 1;
+  V3D_REQUIRE(workspace_bytes >= v3d_attention_decode_workspace_bytes(Hq, n_split), "v3d_attention_decode: workspace too small for %d splits", n_split);
+  AttnArgs p{};
+  p.q = q; p.k = k_cache; p.v = v_cache; p.o = o;
+  p.ldk = ldk; p.ldv = ldv; p.hsq = hsq; p.hsk = hsk; p.hso = hso;
+  p.Sq = 1; p.Sk = Sk; p.Hq = Hq; p.group = Hq / Hkv; p.d_out = 128; p.q_pos0 = Sk - 1;
+  p.scale_log2 = scale * 1.44269504088896340736f;
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int G = Hq / Hkv;
+#define V3D_DEC(TT, GG) hipLaunchKernelGGL((attn_decode_split_kernel<TT, GG>), dim3(Hkv, n_split), dim3(256), 0, st, p, n_split, ws)
+#define V3D_DEC_G(TT)                                                                          \
+  switch (G) {                                                                                 \
+    case 1: V3D_DEC(TT, 1); break; case 2: V3D_DEC(TT, 2); break; case 4: V3D_DEC(TT, 4); break; \
+    case 7: V3D_DEC(TT, 7); break; case 8: V3D_DEC(TT, 8); break;                              \
+    default: set_error("v3d_attention_decode: group size %d unsupported (1,2,4,7,8)", G); return V3D_E_UNSUPPORTED; \
+  }
+  if (dtype == V3D_BF16) { V3D_DEC_G(bf16_t) } else { V3D_DEC_G(f16_t) }
+#undef V3D_DEC_G
+#undef V3D_DEC
+  if (int e = check_launch("v3d_attention_decode (split)")) return e;
+  if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_merge_kernel<bf16_t>), dim3(Hq), dim3(128), 0, st, p, n_split, ws);
+  else hipLaunchKernelGGL((attn_decode_merge_kernel<f16_t>), dim3(Hq), dim3(128), 0, st, p, n_split, ws);
+  return check_launch("v3d_attention_decode (merge)");
 }

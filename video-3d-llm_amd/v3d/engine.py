@@ -222,6 +222,7 @@ class Engine:
         self.l_last = z(8, l.hidden)
         self.logits = z(8, self.l_head.shape[0])
         self.kv_len = 0
+        self.dec_ws = ops.decode_workspace(l.heads, l.kv_heads, dev)
 
     # ------------------------------------------------------------------ ViT + projector (a9, a10)
     def encode_images(self, images):
@@ -289,7 +290,7 @@ class Engine:
         return x
 
     # ------------------------------------------------------------------ Qwen2 decoder (a18-a22)
-    def llm_forward(self, x, pos0):
+    def llm_forward(self, x, pos0, stamps=None):
         """Runs the decoder over rows x [S, hidden] (in place) at positions pos0.., appends K/V to the
         cache and returns the f32 logits of the LAST row only ([vocab]); the reference materialises all
         S rows of logits (modeling_qwen2.py:1190-1192) but generation reads only the last."""
@@ -305,11 +306,21 @@ class Engine:
             ops.rope_apply(qkv, nh + nkv, hd, self.rope, pos0=pos0)
             cache = self.kv[i]
             ops.copy_rows(qkv[:, nh * hd:], cache[pos0: pos0 + S], cols=2 * kvw)
-            ops.attention(qkv, cache, cache[:, kvw:], att, 1, S, pos0 + S, nh, nkv, hd, hd, qkv.stride(0), cache.stride(0),
-                          cache.stride(0), att.stride(0), 0, 0, 0, hd, hd, hd, True, pos0, scale)
+            attn = lambda: ops.attention(qkv, cache, cache[:, kvw:], att, 1, S, pos0 + S, nh, nkv, hd, hd, qkv.stride(0),
+                                         cache.stride(0), cache.stride(0), att.stride(0), 0, 0, 0, hd, hd, hd, True, pos0, scale)
+            if S == 1:
+                ops.attention_decode(qkv, cache, cache[:, kvw:], att, pos0 + 1, nh, nkv, scale, self.dec_ws)
+            elif stamps is not None and i == 1:
+                stamps["attn"](attn)      # bench: HIP events around one layer's launch
+            else:
+                attn()
             ops.gemm(att, L["wo"], res=x, epilogue=ops.EPI_RES, out=x)
             ops.rmsnorm(x, L["ln2"], l.eps, out=h)
-            ops.gemm(h, L["wgu"], epilogue=ops.EPI_SWIGLU, out=act)
+            gu = lambda: ops.gemm(h, L["wgu"], epilogue=ops.EPI_SWIGLU, out=act)
+            if stamps is not None and i == 1:
+                stamps["gemm"](gu)
+            else:
+                gu()
             ops.gemm(act, L["wd"], res=x, epilogue=ops.EPI_RES, out=x)
         self.kv_len = pos0 + S
         ops.rmsnorm(x[S - 1:], self.l_norm, l.eps, out=self.l_last[:1])

@@ -310,6 +310,19 @@ def attention_bshd(q, k, v, causal, scale=None, q_pos0=0, d_out=None):
                      q.stride(0), k.stride(0), out.stride(0), q.stride(2), k.stride(2), out.stride(2), causal, q_pos0, scale)
 
 
+def decode_workspace(Hq, Hkv, device):
+    n = lib().v3d_attention_decode_workspace_bytes(Hq, max(1, 1024 // Hkv))
+    return torch.empty(n // 4, dtype=torch.float32, device=device)
+
+
+def attention_decode(q, k_cache, v_cache, out, Sk, Hq, Hkv, scale, workspace, hd=128):
+    """One query row [Hq*hd] against caches [>=Sk, Hkv*hd (+...)] (row strides from the tensors)."""
+    check(lib().v3d_attention_decode(_p(q), _p(k_cache), _p(v_cache), _p(out), _code(q), Sk, Hq, Hkv, k_cache.stride(0),
+                                     v_cache.stride(0), hd, hd, hd, scale, _p(workspace), workspace.numel() * 4, _stream()),
+          "v3d_attention_decode")
+    return out
+
+
 # ------------------------------------------------------------------------------ data movement
 
 
