@@ -1,0 +1,59 @@
+"""GPU tests of the `llava` mirror surface: same names / call contracts as the reference, results against its goldens."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import v3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unproject_mirror_host_tensors(golden):
+    import llava.video_utils as vu
+    g = golden("unproject")
+    out = vu.unproject(torch.from_numpy(g["intrinsics"]), torch.from_numpy(g["poses"]), torch.from_numpy(g["depth"].astype(np.float32)))
+    assert not out.is_cuda
+    np.testing.assert_allclose(out.numpy(), g["world"], rtol=2e-6, atol=2e-6)
+
+
+def test_position_embedding_module(golden):
+    from llava.model.position_encoding import PositionEmbeddingSine3D
+    g = golden("sin3d_small")
+    pe = PositionEmbeddingSine3D(96)
+    out = pe(torch.from_numpy(g["xyz"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["pe96"], rtol=0, atol=5e-7)
+    g2, t = golden("sin3d_tokens_3584"), golden("sin3d_table_3584")
+    pe = PositionEmbeddingSine3D(3584)
+    assert np.array_equal(pe._dim_t.numpy(), t["dim_t"])
+    o16 = pe(torch.from_numpy(g2["ids"].astype(np.float32)).half().cuda()).float().cpu().numpy()
+    ref = g2["pe_f16"].astype(np.float32)
+    assert np.max(np.abs(o16 - ref)) <= 2.0 ** -10 and (o16 != ref).mean() < 2e-3
+
+
+def test_arch_mixin_methods(golden):
+    from llava.model.llava_arch import LlavaMetaForCausalLM
+
+    class M(LlavaMetaForCausalLM):
+        def __init__(self, newline):
+            self.config = types.SimpleNamespace(mm_spatial_pool_mode="bilinear", voxel_size=0.1, min_xyz_range=[-15, -15, -5],
+                                                max_xyz_range=[15, 15, 5])
+            self._m = types.SimpleNamespace(image_newline=newline)
+
+        def get_model(self):
+            return self._m
+
+        def get_vision_tower(self):
+            return types.SimpleNamespace(num_patches_per_side=27)
+
+    g = golden("add_token_per_grid")
+    m = M(torch.from_numpy(g["newline"]).cuda())
+    assert np.array_equal(m.add_token_per_grid(torch.from_numpy(g["feat"]).cuda()).cpu().numpy(), g["out"])
+    gp = golden("pool2d_bilinear")
+    np.testing.assert_allclose(m.get_2dPool(torch.from_numpy(gp["feat"]).cuda()).cpu().numpy(), gp["out_f32"], rtol=1e-6, atol=1e-6)
+    gc = golden("coord_pool")
+    x16 = torch.from_numpy(gc["coords_f16"]).cuda()
+    avg = m.average_coordinate_in_patch(x16)
+    assert np.array_equal(avg.cpu().numpy(), gc["avg_f16"])
+    assert np.array_equal(m.discrete_coords(avg).cpu().numpy(), gc["vox_f16"])
