@@ -92,6 +92,8 @@ def discrete_coords(xyz, min_xyz=(-15, -15, -5), max_xyz=(15, 15, 5), voxel_size
     N = x.numel() // 3
     vox = torch.empty_like(x)
     ids = torch.empty(x.shape, dtype=torch.int32, device=x.device) if want_ids else None
+    if N == 0:          # empty `box_input` (merge_video_dict yields torch.Tensor([]) when there are no boxes)
+        return (vox, ids) if want_ids else vox
     check(lib().v3d_discrete_coords(_p(x), _code(x), N, _f3(min_xyz), _f3(max_xyz), float(np.float32(voxel_size)),
                                     _p(vox), _p(ids), _stream()), "v3d_discrete_coords")
     return (vox, ids) if want_ids else vox
