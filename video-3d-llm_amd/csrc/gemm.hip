@@ -1,8 +1,12 @@
 // Dense 16-bit GEMM on MFMA for the ViT / projector / LLM linears (K10-K12, K15, K17):
 //     out[M, N'] = epilogue( A[M,K] . W[N,K]^T )        A, W: K-contiguous (nn.Linear layout)
 //
-// Tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 sub-tile as 4 x 4
-// v_mfma_f32_16x16x32 accumulators.  Both operand tiles are staged HBM -> LDS with
+// Two tile shapes, picked per problem by a small cost model (launch_gemm):
+//   gemm_kernel         128 x 128 x 64, 4 waves (2 x 2) of 64 x 64, two workgroups per CU - fine-grained, for
+//                       shapes whose 256 x 256 tile count quantises badly against the 256 CUs;
+//   gemm256x256_kernel  256 x 256 x 64, 8 waves (2 x 4) of 128 x 64, one workgroup per CU - twice the operand
+//                       reuse per LDS byte, ~1.15-1.35 PF on the path's large shapes.
+// Both operand tiles are staged HBM -> LDS with
 // global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 2-deep ring; the LDS image is
 // XOR-swizzled through the per-lane SOURCE address (the DMA's destination is lane-linear) so that
 // the ds_read_b128 fragment reads are bank-conflict free.  The accumulators are produced
@@ -12,6 +16,8 @@
 // Rounding points follow the reference (torch): the linear output (acc + bias, f32) is rounded to
 // the 16-bit dtype once; activation / gate product / residual add each take 16-bit inputs,
 // compute in f32 and round again.
+#include <stdlib.h>
+
 #include "v3d_common.h"
 
 namespace v3d {
@@ -124,30 +130,58 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Software pipeline over the two 32-deep k-halves of each tile: the fragment reads of one half are
+  // in flight under the 16 MFMAs of the other (two register sets), ONE barrier per K-step:
+  //   read half1(t) -> fb | lgkmcnt(8): fa landed | MFMA half0 (fa) | lgkmcnt(0) vmcnt(0) barrier
+  //   (tile t+1 visible, tile t fully read) | stage tile t+2 over tile t | read half0(t+1) -> fa | MFMA half1 (fb)
+  // hipcc's waitcnt pass only emits lgkmcnt(0) for this loop-carried pattern, so the fragment reads are
+  // inline asm (not tracked) and the counted waits are ours; every wait names the registers it
+  // retires as "+v" operands so no consumer can be scheduled above it (cdna guide 5.7, form ii).
   const int nt = p.K / BK;
+  using v4i = __attribute__((ext_vector_type(4))) int;
+  v4i fa[8], fb[8];      // [0..3] = A-tile (m) fragments, [4..7] = W-tile (n) fragments
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned offA = lds0 + (wm * 64) * (BK * 2), offW = lds0 + TILE_A_BYTES + (wn * 64) * (BK * 2);
+#define V3D_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define V3D_READ_HALF(f, buf, fo)                                         \
+  {                                                                       \
+    const unsigned aA = offA + (buf) * STAGE_BYTES + (fo), aW = offW + (buf) * STAGE_BYTES + (fo); \
+    V3D_DSR(f[0], aA, 0); V3D_DSR(f[1], aA, 2048); V3D_DSR(f[4], aW, 0); V3D_DSR(f[5], aW, 2048);  \
+    V3D_DSR(f[2], aA, 4096); V3D_DSR(f[3], aA, 6144); V3D_DSR(f[6], aW, 4096); V3D_DSR(f[7], aW, 6144); \
+  }
+#define V3D_WAIT(cnt, f)                                                                             \
+  asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), \
+               "+v"(f[6]), "+v"(f[7]) : : "memory")
+  auto mma = [&](const v4i* f) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        acc[ni][mi] = M16::run(__builtin_bit_cast(frag, f[4 + ni]), __builtin_bit_cast(frag, f[mi]), acc[ni][mi]);
+    __builtin_amdgcn_s_setprio(0);
+  };
   stage(0, 0);
-  __syncthreads();   // hipcc drains vmcnt before the barrier: tile 0 has landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nt > 1) stage(1, 1);
+  V3D_READ_HALF(fa, 0, fo0);
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) stage(cur ^ 1, t + 1);
-    const char* sA = smem + cur * STAGE_BYTES + (wm * 64) * (BK * 2);
-    const char* sW = smem + cur * STAGE_BYTES + TILE_A_BYTES + (wn * 64) * (BK * 2);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int fo = ks ? fo1 : fo0;
-      frag a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = *reinterpret_cast<const frag*>(sA + i * 16 * (BK * 2) + fo);
-        b[i] = *reinterpret_cast<const frag*>(sW + i * 16 * (BK * 2) + fo);
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = M16::run(b[ni], a[mi], acc[ni][mi]);
-    }
-    __syncthreads();   // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    V3D_READ_HALF(fb, cur, fo1);
+    V3D_WAIT("lgkmcnt(8)", fa);                 // the 8 older reads (fa) have landed, fb still in flight
+    mma(fa);
+    V3D_WAIT("vmcnt(0) lgkmcnt(0)", fb);        // fb landed (tile t fully read by this wave), tile t+1 landed
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) stage(cur, t + 2);
+    V3D_READ_HALF(fa, cur ^ 1, fo0);            // last step: stale bytes, never used
+    mma(fb);
   }
+  V3D_WAIT("lgkmcnt(0)", fa);
+#undef V3D_DSR
+#undef V3D_READ_HALF
+#undef V3D_WAIT
+  __syncthreads();   // every wave is done with the ring before the C tile overwrites it
 
   // ---- epilogue: accumulators -> LDS C tile (16-bit, bias added in f32 first) -> coalesced rows ----
   const T* bias = (const T*)p.bias;
@@ -207,6 +241,199 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
       c = vec_pack<T>(v);
     }
     *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + n0 + ch * 8) = c;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// v3: 256 x 256 x 64 tile, 512 threads = 8 waves (2 x 4), each wave 128 x 64 (8 x 4 accumulators).
+// Twice the operand reuse of the 64 x 64 wave tile: 24 ds_read_b128 feed 64 MFMAs per K-step, which
+// takes the LDS pipe (fragment reads + DMA writes) off the critical path.  Four phases of 16 MFMAs per
+// K-step; the fragment reads of phase p+1 are in flight under the MFMAs of phase p (two A and two B
+// register sets, counted lgkmcnt), one barrier and one 8-DMA stage per K-step on a 2-deep ring.
+// ------------------------------------------------------------------------------------------
+constexpr int B3M = 256, B3N = 256;
+constexpr int T3_BYTES = B3M * BK * 2;                  // 32 KiB per operand tile
+constexpr int S3_BYTES = 2 * T3_BYTES;                  // 64 KiB per stage
+constexpr int GEMM3_LDS_BYTES = 2 * S3_BYTES;           // 128 KiB
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using M16 = Mfma16<T>;
+  using frag = typename M16::frag;
+  using v4i = __attribute__((ext_vector_type(4))) int;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * B3M, n0 = tn * B3N;
+
+  // staging: wave w moves rows [32w, 32w+32) of both tiles: 4 + 4 DMAs of 8 rows
+  const uint16_t* a_src[4];
+  const uint16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int gm = m0 + row;
+    gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = (const uint16_t*)p.A + (int64_t)gm * p.lda + chunk * 8;
+    w_src[i] = (const uint16_t*)p.W + (int64_t)(n0 + row) * p.ldw + chunk * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * S3_BYTES + (wave * 32) * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(a_src[i] + kt * BK, base + i * 8 * (BK * 2));
+      glds16(w_src[i] + kt * BK, base + T3_BYTES + i * 8 * (BK * 2));
+    }
+  };
+
+  const int sw = (lane >> 1) & 7;
+  const int frow = (lane & 15) * (BK * 2);
+  const unsigned fo0 = frow + (((0 + (lane >> 4)) ^ sw) << 4);
+  const unsigned fo1 = frow + (((4 + (lane >> 4)) ^ sw) << 4);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned offA = lds0 + (wm * 128) * (BK * 2), offW = lds0 + T3_BYTES + (wn * 64) * (BK * 2);
+
+  f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  v4i A0[4], A1[4], B0[4], B1[4];
+#define V3D_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define V3D_RD_A_LO(f, base) { V3D_DSR(f[0], base, 0); V3D_DSR(f[1], base, 2048); V3D_DSR(f[2], base, 4096); V3D_DSR(f[3], base, 6144); }
+#define V3D_RD_A_HI(f, base) { V3D_DSR(f[0], base, 8192); V3D_DSR(f[1], base, 10240); V3D_DSR(f[2], base, 12288); V3D_DSR(f[3], base, 14336); }
+#define V3D_W4(cnt, f) asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+#define V3D_W8(cnt, f, g) asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : : "memory")
+#define V3D_MMA(FA, FB, MG)                                                                            \
+  {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
+        acc[ni][(MG) * 4 + i] = M16::run(__builtin_bit_cast(frag, FB[ni]), __builtin_bit_cast(frag, FA[i]), acc[ni][(MG) * 4 + i]); \
+    __builtin_amdgcn_s_setprio(0);                                                                     \
+  }
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (nt > 1) stage(1, 1);
+  {
+    const unsigned a = offA + fo0, w = offW + fo0;
+    V3D_RD_A_LO(A0, a);
+    V3D_RD_A_LO(B0, w);
+  }
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const unsigned a0 = offA + cur * S3_BYTES + fo0, a1 = offA + cur * S3_BYTES + fo1;
+    const unsigned w1 = offW + cur * S3_BYTES + fo1;
+    // phase 0: (k-half 0, rows 0..63)
+    V3D_RD_A_HI(A1, a0);
+    V3D_W8("lgkmcnt(4)", A0, B0);
+    V3D_MMA(A0, B0, 0);
+    // phase 1: (k-half 0, rows 64..127)
+    V3D_RD_A_LO(A0, a1);
+    V3D_RD_A_LO(B1, w1);
+    V3D_W4("lgkmcnt(8)", A1);
+    V3D_MMA(A1, B0, 1);
+    // phase 2: (k-half 1, rows 0..63)
+    V3D_RD_A_HI(A1, a1);
+    V3D_W8("lgkmcnt(4)", A0, B1);
+    V3D_MMA(A0, B1, 0);
+    // phase 3: (k-half 1, rows 64..127); tile t fully read, tile t+1 landed -> rendezvous, restage
+    V3D_W4("vmcnt(0) lgkmcnt(0)", A1);
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) stage(cur, t + 2);
+    {
+      const unsigned a = offA + (cur ^ 1) * S3_BYTES + fo0, w = offW + (cur ^ 1) * S3_BYTES + fo0;
+      V3D_RD_A_LO(A0, a);      // next tile's phase-0 fragments (last step: stale, unused)
+      V3D_RD_A_LO(B0, w);
+    }
+    V3D_MMA(A1, B1, 1);
+  }
+  V3D_W8("lgkmcnt(0)", A0, B0);
+#undef V3D_DSR
+#undef V3D_RD_A_LO
+#undef V3D_RD_A_HI
+#undef V3D_W4
+#undef V3D_W8
+#undef V3D_MMA
+  __syncthreads();
+
+  // epilogue in two 128-row halves (the 256 x 256 C tile does not fit the ring with padding)
+  constexpr int C3_ROW = B3N * 2 + 16;
+  const T* bias = (const T*)p.bias;
+  T* out = (T*)p.out;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (EPI >= EPI_BIAS && EPI <= EPI_BIAS_RES) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const int ml = mi * 16 + (lane & 15);
+          uint2 pk;
+          pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
+          pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
+          *reinterpret_cast<uint2*>(smem + ml * C3_ROW + nl * 2) = pk;
+        }
+      }
+    }
+    __syncthreads();
+    if (EPI == EPI_SWIGLU) {
+      // tile columns: per 128-column group [gate64 | up64]; two groups per tile -> 128 output columns
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 32 * i, c16 = tid & 15;       // 16 output chunks of 8 per row
+        const int grp = c16 >> 3, ch = c16 & 7;
+        const int gm = m0 + half * 128 + row;
+        const uint4 g = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + ch * 16);
+        const uint4 u = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + 128 + ch * 16);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu(vec_get<T>(g, j))) * vec_get<T>(u, j);
+        if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + tn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (tid >> 5) + 16 * i, ch = tid & 31;
+        const int gm = m0 + half * 128 + row;
+        if (gm < p.M) {
+          uint4 c = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + ch * 16);
+          if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+            float v[8];
+            uint4 rr = make_uint4(0, 0, 0, 0);
+            if (EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+              const int64_t rm = p.res_mod > 0 ? (gm % p.res_mod) : gm;
+              rr = *reinterpret_cast<const uint4*>((const T*)p.res + rm * p.ldr + n0 + ch * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float x = vec_get<T>(c, j);
+              v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : x + vec_get<T>(rr, j);
+            }
+            c = vec_pack<T>(v);
+          }
+          *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + n0 + ch * 8) = c;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -302,8 +529,52 @@ __global__ __launch_bounds__(256) void gemv_swiglu_kernel(const T* __restrict__ 
   }
 }
 
+static int gemm_variant() {   // 0 = auto, 1 = force 128x128, 3 = force 256x256 (where N allows); for A/B runs
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("V3D_GEMM_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+template <typename T>
+static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
+  p.tiles_m = (p.M + B3M - 1) / B3M;
+  p.tiles_n = p.N / B3N;
+#define V3D_GEMM3_CASE(E)                                                                                 \
+  case E: {                                                                                               \
+    auto k = gemm256x256_kernel<T, E>;                                                                    \
+    static bool attr_done = false;                                                                        \
+    if (!attr_done) {                                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS_BYTES); \
+      if (e != hipSuccess) { set_error("v3d_gemm: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
+      attr_done = true;                                                                                   \
+    }                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM3_LDS_BYTES, st, p);                \
+  } break;
+  switch (epi) {
+    V3D_GEMM3_CASE(EPI_NONE)
+    V3D_GEMM3_CASE(EPI_BIAS)
+    V3D_GEMM3_CASE(EPI_BIAS_GELU_ERF)
+    V3D_GEMM3_CASE(EPI_BIAS_GELU_TANH)
+    V3D_GEMM3_CASE(EPI_BIAS_RES)
+    V3D_GEMM3_CASE(EPI_RES)
+    V3D_GEMM3_CASE(EPI_SWIGLU)
+    default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
+  }
+#undef V3D_GEMM3_CASE
+  return check_launch("v3d_gemm (256x256)");
+}
+
 template <typename T>
 static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
+  // Tile choice (speed only): 256x256 runs ~1.27x the MFMA rate of 128x128 per tile but one workgroup per CU,
+  // so it loses when its tile count quantises badly against 256 CUs (e.g. 27 x 14 = 378 tiles).
+  const int var = gemm_variant();
+  if (p.N % B3N == 0 && var != 1) {
+    const int tiles3 = ((p.M + B3M - 1) / B3M) * (p.N / B3N);
+    const double t3 = (double)((tiles3 + 255) / 256) * 4.0 / 1.27;
+    const double t1 = (double)p.tiles_m * p.tiles_n / 256.0;
+    if (var == 3 || t3 < t1) return launch_gemm256x256<T>(p, epi, st);
+  }
 #define V3D_GEMM_CASE(E)                                                                                  \
   case E: {                                                                                               \
     auto k = gemm_kernel<T, E>;                                                                           \
