@@ -81,16 +81,7 @@ def scene_step(eng, ops, inp, stamps):
     stamps["pe"](lambda: ops.visual_tokens(feats, ids, eng.pe_table, eng.newline, out=x[TEXT_PRE:TEXT_PRE + n_vis]))  # K5-K8
     ops.embed_gather(eng.embed, inp["ids_post"], out=x[TEXT_PRE + n_vis:])
     logits = eng.llm_forward(x, 0, stamps=stamps)                                       # K13-K18 prefill
-    toks = []
-    tok = torch.argmax(logits).view(1)
-    for step in range(DECODE_STEPS):
-        toks.append(tok)
-        if step + 1 == DECODE_STEPS:
-            break
-        xe = ops.embed_gather(eng.embed, tok, out=eng.l_x[S + step: S + step + 1])
-        logits = eng.llm_forward(xe, S + step)
-        tok = torch.argmax(logits).view(1)
-    return torch.cat(toks)
+    return eng.decode_loop(logits, S, DECODE_STEPS)                                     # 16 greedy tokens, no EOS stop
 
 
 def cpu_baseline(threads):

@@ -189,6 +189,23 @@ int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache
                          int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
                          void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Decode-step linear (one activation row; K15/K17/K18 at q_len == 1): y = epilogue(W . f(x)), W [N,K] row
+ * stride ldw.  norm_weight != NULL fuses Qwen2RMSNorm (modeling_qwen2.py:85-90) in front: f(x) = w * T(x*rstd).
+ * epilogue: 0 NONE, 1 BIAS (y += bias), 2 RES (y = res + T(y)), 3 SWIGLU (tile-interleaved gate|up rows as
+ * v3d_gemm's SWIGLU; N' = N/2).  Weights are streamed once with non-temporal loads. */
+enum { V3D_DEC_NONE = 0, V3D_DEC_BIAS = 1, V3D_DEC_RES = 2, V3D_DEC_SWIGLU = 3 };
+int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const void* W, int64_t ldw,
+                      const void* bias, const void* res, void* out, int N, int K, int dtype, int epilogue,
+                      void* stream);
+
+/* Decode-step K14 + cache append in one launch: rotary at position `pos` on the n_q + n_kv heads at the start
+ * of the QKV row (in place), rotated k and v copied to cache_row = [k heads | v heads]. */
+int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
+                       const void* sin_table, int n_pos, int pos, void* cache_row, int dtype, void* stream);
+
+/* Greedy token choice: index of the maximum of x[0..n) (lowest index on ties, as torch.argmax). */
+int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* stream);
+
 /* ------------------------------------------------------------------ data movement ------- */
 
 /* out[r, 0:cols] = in[r, 0:cols] for strided rows (KV-cache append). */

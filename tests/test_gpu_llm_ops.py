@@ -204,3 +204,49 @@ def test_attention_decode_split_kv(ops, kind, Sk, H, KV):
     v = cache[:Sk, KV * D:].view(1, Sk, KV, D)
     want = ref_attention(q, k, v, True, 1 / math.sqrt(D), q_pos0=Sk - 1)
     close(out.view(1, 1, H, D), want, kind, ulps=2.0, floor=0.3)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_linear_decode_fused_variants(ops, kind):
+    """Decode-step linears: fused RMSNorm prologue, bias / residual / SwiGLU epilogues vs the oracle ops."""
+    dt = DT[kind]
+    g = torch.Generator().manual_seed(12)
+    K, N, I = 512, 384, 256
+    x = (torch.randn(K, generator=g)).to(dt)
+    lnw = (1 + 0.1 * torch.randn(K, generator=g)).to(dt)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt)
+    b = torch.randn(N, generator=g).to(dt)
+    r = torch.randn(N, generator=g).to(dt)
+    xn = L.rmsnorm(x[None], lnw, 1e-6)[0]
+    out = torch.empty(N, dtype=dt, device="cuda")
+    ops.linear_decode(x.cuda(), w.cuda(), out, norm_weight=lnw.cuda(), eps=1e-6, bias=b.cuda(), epilogue=ops.DEC_BIAS)
+    close(out, (xn.float() @ w.float().t() + b.float()).to(dt), kind, ulps=2.5)
+    ops.linear_decode(x.cuda(), w.cuda(), out, res=r.cuda(), epilogue=ops.DEC_RES)
+    close(out, (r.float() + (x.float() @ w.float().t()).to(dt).float()).to(dt), kind, ulps=2.5, floor=1.0)
+    ops.linear_decode(x.cuda(), w.cuda(), out)
+    close(out, (x.float() @ w.float().t()).to(dt), kind, ulps=2.5)
+    wg = (torch.randn(I, K, generator=g) * 0.05).to(dt)
+    wu = (torch.randn(I, K, generator=g) * 0.05).to(dt)
+    want = (F.silu((xn.float() @ wg.float().t()).to(dt).float()).to(dt).float() * (xn.float() @ wu.float().t()).to(dt).float()).to(dt)
+    act = torch.empty(I, dtype=dt, device="cuda")
+    ops.linear_decode(x.cuda(), ops.interleave_gate_up(wg, wu).cuda(), act, norm_weight=lnw.cuda(), eps=1e-6, epilogue=ops.DEC_SWIGLU)
+    close(act, want, kind, ulps=3.0, floor=0.3)
+
+
+def test_rope_kv_append_and_argmax(ops):
+    dt = torch.bfloat16
+    H, KV, D = 4, 2, 128
+    table = ops.RopeTable(D, 512, 1e6, dt, "cuda")
+    row = torch.randn((H + 2 * KV) * D).to(dt)
+    ref = row.clone().cuda().view(1, -1)
+    ops.rope_apply(ref, H + KV, D, table, pos0=77)
+    got = row.clone().cuda()
+    cache_row = torch.zeros(2 * KV * D, dtype=dt, device="cuda")
+    ops.rope_kv_append(got, H, KV, D, table, 77, cache_row)
+    assert torch.equal(got, ref[0])
+    assert torch.equal(cache_row, ref[0, H * D:])
+    x = torch.randn(152064).to(dt)
+    x[77777] = x[1234] = 50.0           # tie -> lowest index
+    idx = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.argmax(x.cuda(), idx)
+    assert int(idx) == 1234 == int(torch.argmax(x.float()))

@@ -427,17 +427,38 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, int 
 template <typename T>
 __global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, int n_split, const float* __restrict__ ws) {
   constexpr int D = 128;
+  __shared__ float sm_f[1024], sm_lsum;
   const int head = blockIdx.x, d = threadIdx.x;
+  // per-split (max, sum) pairs -> LDS once, then every thread reuses the rescale factors
   float mm = -INFINITY;
-  for (int s = 0; s < n_split; ++s) mm = fmaxf(mm, ws[((size_t)s * p.Hq + head) * (D + 2) + D]);
-  const float mu = mm == -INFINITY ? 0.f : mm;
-  float lt = 0.f, ot = 0.f;
-  for (int s = 0; s < n_split; ++s) {
-    const float* w = ws + ((size_t)s * p.Hq + head) * (D + 2);
-    const float f = exp2f(w[D] - mu);
-    lt += w[D + 1] * f;
-    ot += w[d] * f;
+  for (int s = d; s < n_split; s += 128) {
+    const float m = ws[((size_t)s * p.Hq + head) * (D + 2) + D];
+    sm_f[s] = m;
+    mm = fmaxf(mm, m);
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mm = fmaxf(mm, __shfl_xor(mm, off));
+  __shared__ float sm_m2[2];
+  if ((d & 63) == 0) sm_m2[d >> 6] = mm;
+  __syncthreads();
+  mm = fmaxf(sm_m2[0], sm_m2[1]);
+  const float mu = mm == -INFINITY ? 0.f : mm;
+  float lpart = 0.f;
+  for (int s = d; s < n_split; s += 128) {
+    const float f = exp2f(sm_f[s] - mu);
+    lpart += ws[((size_t)s * p.Hq + head) * (D + 2) + D + 1] * f;
+    sm_f[s] = f;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) lpart += __shfl_xor(lpart, off);
+  __syncthreads();
+  if ((d & 63) == 0) sm_m2[d >> 6] = lpart;
+  __syncthreads();
+  const float lt = sm_m2[0] + sm_m2[1];
+  float ot = 0.f;
+#pragma unroll 8
+  for (int s = 0; s < n_split; ++s) ot = fmaf(ws[((size_t)s * p.Hq + head) * (D + 2) + d], sm_f[s], ot);   // independent, coalesced loads
+  (void)sm_lsum;
   T* O = (T*)p.o + (int64_t)head * p.hso;
   O[d] = from_f32<T>(lt > 0.f ? ot / lt : 0.f);
 }

@@ -323,9 +323,33 @@ class Engine:
                 gu()
             ops.gemm(act, L["wd"], res=x, epilogue=ops.EPI_RES, out=x)
         self.kv_len = pos0 + S
-        ops.rmsnorm(x[S - 1:], self.l_norm, l.eps, out=self.l_last[:1])
-        ops.gemm(self.l_last[:1], self.l_head, out=self.logits[:1])
+        return self._head(x[S - 1:])
+
+    def _head(self, x_row):
+        """final RMSNorm + LM head on ONE row (K18: only the last position feeds generation)."""
+        l = self.cfg.llm
+        ops.rmsnorm(x_row, self.l_norm, l.eps, out=self.l_last[:1])
+        ops.linear_decode(self.l_last[0], self.l_head, self.logits[0])
         return self.logits[0, : l.vocab]
+
+    def decode_forward(self, x_row, pos):
+        """One new token (x_row [1, hidden], in place) at position `pos`: 7 launches per layer, no host sync.
+        RMSNorms are fused into the QKV / gate-up linears, rotary + cache append into one kernel."""
+        l = self.cfg.llm
+        hd, nh, nkv = self.hd, l.heads, l.kv_heads
+        kvw = nkv * hd
+        scale = 1.0 / math.sqrt(hd)
+        xr, qkv, att, act = x_row[0], self.l_qkv[0], self.l_att[0], self.l_act[0]
+        for i, L in enumerate(self.l_layers):
+            cache = self.kv[i]
+            ops.linear_decode(xr, L["wqkv"], qkv, norm_weight=L["ln1"], eps=l.eps, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
+            ops.rope_kv_append(qkv, nh, nkv, hd, self.rope, pos, cache[pos])
+            ops.attention_decode(qkv, cache, cache[:, kvw:], att, pos + 1, nh, nkv, scale, self.dec_ws)
+            ops.linear_decode(att, L["wo"], xr, res=xr, epilogue=ops.DEC_RES)
+            ops.linear_decode(xr, L["wgu"], act, norm_weight=L["ln2"], eps=l.eps, epilogue=ops.DEC_SWIGLU)
+            ops.linear_decode(act, L["wd"], xr, res=xr, epilogue=ops.DEC_RES)
+        self.kv_len = pos + 1
+        return self._head(x_row)
 
     def last_hidden(self):
         return self.l_last[0]
@@ -340,15 +364,20 @@ class Engine:
         x = self.build_inputs_embeds(input_ids, feats, ids)
         S = x.shape[0]
         logits = self.llm_forward(x, 0)
-        out = []
-        tok = torch.argmax(logits).view(1)
+        return self.decode_loop(logits, S, max_new_tokens, eos_token_id)
+
+    def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None):
+        """Greedy loop; token ids stay on the device (argmax kernel -> embedding gather), the host only
+        synchronises per step when an EOS id has to be checked."""
+        toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
+        n = 0
         for step in range(max_new_tokens):
-            out.append(tok)
-            if eos_token_id is not None and int(tok) == eos_token_id:
+            ops.argmax(logits, toks[step: step + 1])
+            n = step + 1
+            if eos_token_id is not None and int(toks[step]) == eos_token_id:
                 break
             if step + 1 == max_new_tokens:
                 break
-            xe = ops.embed_gather(self.embed, tok, out=self.l_x[S + step: S + step + 1])
-            logits = self.llm_forward(xe, S + step)
-            tok = torch.argmax(logits).view(1)
-        return torch.cat(out)
+            xe = ops.embed_gather(self.embed, toks[step: step + 1], out=self.l_x[S + step: S + step + 1])
+            logits = self.decode_forward(xe, S + step)
+        return toks[:n]

@@ -325,6 +325,28 @@ def attention_decode(q, k_cache, v_cache, out, Sk, Hq, Hkv, scale, workspace, hd
     return out
 
 
+DEC_NONE, DEC_BIAS, DEC_RES, DEC_SWIGLU = range(4)
+
+
+def linear_decode(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=None, epilogue=DEC_NONE):
+    """One activation row x [K] against w [N,K]; optional fused RMSNorm in front (see include/v3d.h)."""
+    N, K = w.shape
+    check(lib().v3d_linear_decode(_p(x), _p(norm_weight), eps, _p(w), w.stride(0), _p(bias), _p(res), _p(out), N, K,
+                                  _code(x), epilogue, _stream()), "v3d_linear_decode")
+    return out
+
+
+def rope_kv_append(qkv_row, n_q, n_kv, hd, table, pos, cache_row):
+    check(lib().v3d_rope_kv_append(_p(qkv_row), n_q, n_kv, hd, _p(table.cos), _p(table.sin), table.n_pos, pos,
+                                   _p(cache_row), _code(qkv_row), _stream()), "v3d_rope_kv_append")
+
+
+def argmax(x, out):
+    """out: int64 device tensor of one element."""
+    check(lib().v3d_argmax(_p(x), x.numel(), _code(x), _p(out), _stream()), "v3d_argmax")
+    return out
+
+
 # ------------------------------------------------------------------------------ data movement
 
 
