@@ -168,21 +168,25 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       }
       // ---- mask + online softmax (lane = one query; keys of reg r: (r&3) + 8(r>>2) + 4h) ----
       const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > p.q_pos0 + q0 + wave * 32) || (kv0 + AT_BKV > p.Sk);
+      if (need_mask) {   // wave-uniform; only diagonal / tail tiles pay for it (compare + select per score)
+        int last = p.Sk - 1;
+        if (CAUSAL) last = q_pos < last ? q_pos : last;
+        const int limit = last - kv0 - 4 * h;            // visible iff tile-local key offset <= limit
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            s[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : s[kt][r];
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (need_mask) {
-            const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if ((CAUSAL && key > q_pos) || key >= p.Sk) s[kt][r] = -INFINITY;
-          }
-          mx = fmaxf(mx, s[kt][r]);
-        }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run, mx);
       const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = exp2f((m_run - m_use) * sc);          // m_run = -inf -> 0
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * sc);   // v_exp_f32; m_run = -inf -> 0
       const float mb = m_use * sc;
       float ls = 0.f;
       Frag16 pf[4];
@@ -193,17 +197,19 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
           float e[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            e[j] = exp2f(s[kt][8 * s2 + j] * sc - mb);
+            e[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * s2 + j], sc, -mb));
             ls += e[j];
           }
           pf[2 * kt + s2].u = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
         }
       l_run = l_run * alpha + ls;
       m_run = m_new;
+      if (__any(alpha != 1.0f)) {     // wave-uniform: once the running max has settled the rescale is skipped
 #pragma unroll
-      for (int i = 0; i < DT; ++i)
+        for (int i = 0; i < DT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
       // ---- O^T += V^T . P^T ----
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {

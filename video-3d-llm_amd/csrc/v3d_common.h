@@ -45,11 +45,9 @@ template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float x) {
   f16_t r; r.v = __half_as_ushort(__float2half_rn(x)); return r;
 }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) {
-  // round-to-nearest-even; NaN stays NaN (a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
-  uint32_t u = __float_as_uint(x);
+  // plain cast: round-to-nearest-even, NaN stays NaN; lowers to ONE v_cvt_pk_bf16_f32 on gfx950
   bf16_t r;
-  if ((u & 0x7fffffffu) > 0x7f800000u) { r.v = 0x7fc0; return r; }
-  r.v = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  r.v = __builtin_bit_cast(uint16_t, static_cast<__bf16>(x));
   return r;
 }
 
@@ -78,10 +76,14 @@ template <> __device__ __forceinline__ float vec_get<bf16_t>(const uint4& r, int
 
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) {
-  return (uint32_t)from_f32<f16_t>(lo).v | ((uint32_t)from_f32<f16_t>(hi).v << 16);
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 v = {static_cast<_Float16>(lo), static_cast<_Float16>(hi)};
+  return __builtin_bit_cast(uint32_t, v);
 }
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
-  return (uint32_t)from_f32<bf16_t>(lo).v | ((uint32_t)from_f32<bf16_t>(hi).v << 16);
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 v = {static_cast<__bf16>(lo), static_cast<__bf16>(hi)};     // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> __device__ __forceinline__ uint4 vec_pack(const float* v);
