@@ -252,17 +252,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 // K-step; the fragment reads of phase p+1 are in flight under the MFMAs of phase p (two A and two B
 // register sets, counted lgkmcnt), one barrier and one 8-DMA stage per K-step on a 2-deep ring.
 // ------------------------------------------------------------------------------------------
-constexpr int B3M = 256, B3N = 256;
-constexpr int T3_BYTES = B3M * BK * 2;                  // 32 KiB per operand tile
+constexpr int B3N = 256;
+constexpr int T3_BYTES = 256 * BK * 2;                  // 32 KiB per operand tile (A tile uses BM rows of it)
 constexpr int S3_BYTES = 2 * T3_BYTES;                  // 64 KiB per stage
 constexpr int GEMM3_LDS_BYTES = 2 * S3_BYTES;           // 128 KiB
 
-template <typename T, int EPI>
+// MT = 16-row accumulator tiles per wave along M: 8 -> BM = 256, 6 -> BM = 192 (picked so that the tile count
+// fills whole rounds of the 256 CUs, e.g. M = 6794, N = 3584: 27 x 14 = 378 tiles (74 %) vs 36 x 14 = 504 (98 %)).
+template <typename T, int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using M16 = Mfma16<T>;
   using frag = typename M16::frag;
   using v4i = __attribute__((ext_vector_type(4))) int;
+  constexpr int MG = MT / 2;              // m-tiles per phase
+  constexpr int WROWS = MT * 16;          // rows per wave
+  constexpr int BM = 2 * WROWS;
+  constexpr int APW = BM / 8 / 8;         // A DMA pieces (8 rows) per wave: 4 or 3
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -270,57 +276,65 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   const int wm = wave >> 2, wn = wave & 3;
   int tm, tn;
   tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-  const int m0 = tm * B3M, n0 = tn * B3N;
+  const int m0 = tm * BM, n0 = tn * B3N;
 
-  // staging: wave w moves rows [32w, 32w+32) of both tiles: 4 + 4 DMAs of 8 rows
-  const uint16_t* a_src[4];
+  const uint16_t* a_src[APW];
   const uint16_t* w_src[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
+  for (int i = 0; i < APW; ++i) {
+    const int row = wave * (APW * 8) + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     int gm = m0 + row;
     gm = gm < p.M ? gm : p.M - 1;
     a_src[i] = (const uint16_t*)p.A + (int64_t)gm * p.lda + chunk * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     w_src[i] = (const uint16_t*)p.W + (int64_t)(n0 + row) * p.ldw + chunk * 8;
   }
   auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * S3_BYTES + (wave * 32) * (BK * 2);
+    char* ba = smem + buf * S3_BYTES + (wave * APW * 8) * (BK * 2);
+    char* bw = smem + buf * S3_BYTES + T3_BYTES + (wave * 32) * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(a_src[i] + kt * BK, base + i * 8 * (BK * 2));
-      glds16(w_src[i] + kt * BK, base + T3_BYTES + i * 8 * (BK * 2));
-    }
+    for (int i = 0; i < APW; ++i) glds16(a_src[i] + kt * BK, ba + i * 8 * (BK * 2));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(w_src[i] + kt * BK, bw + i * 8 * (BK * 2));
   };
 
+  // all wave row bases are multiples of 16, so ((row>>1)&7) == ((lane>>1)&7)
   const int sw = (lane >> 1) & 7;
   const int frow = (lane & 15) * (BK * 2);
   const unsigned fo0 = frow + (((0 + (lane >> 4)) ^ sw) << 4);
   const unsigned fo1 = frow + (((4 + (lane >> 4)) ^ sw) << 4);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned offA = lds0 + (wm * 128) * (BK * 2), offW = lds0 + T3_BYTES + (wn * 64) * (BK * 2);
+  const unsigned offA = lds0 + (wm * WROWS) * (BK * 2), offW = lds0 + T3_BYTES + (wn * 64) * (BK * 2);
+  const unsigned offA_hi = offA + MG * 2048;             // second group of m-tiles
 
-  f32x4 acc[4][8];   // [nt][mt]
+  f32x4 acc[4][MT];   // [nt][mt]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   v4i A0[4], A1[4], B0[4], B1[4];
 #define V3D_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
-#define V3D_RD_A_LO(f, base) { V3D_DSR(f[0], base, 0); V3D_DSR(f[1], base, 2048); V3D_DSR(f[2], base, 4096); V3D_DSR(f[3], base, 6144); }
-#define V3D_RD_A_HI(f, base) { V3D_DSR(f[0], base, 8192); V3D_DSR(f[1], base, 10240); V3D_DSR(f[2], base, 12288); V3D_DSR(f[3], base, 14336); }
+#define V3D_RD4(f, base) { V3D_DSR(f[0], base, 0); V3D_DSR(f[1], base, 2048); V3D_DSR(f[2], base, 4096); V3D_DSR(f[3], base, 6144); }
+#define V3D_RD3(f, base) { V3D_DSR(f[0], base, 0); V3D_DSR(f[1], base, 2048); V3D_DSR(f[2], base, 4096); }
+#define V3D_RDA(f, base) { if constexpr (MG == 4) V3D_RD4(f, base) else V3D_RD3(f, base) }
 #define V3D_W4(cnt, f) asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
 #define V3D_W8(cnt, f, g) asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : : "memory")
-#define V3D_MMA(FA, FB, MG)                                                                            \
+#define V3D_MMA(FA, FB, G)                                                                             \
   {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+    _Pragma("unroll") for (int i = 0; i < MG; ++i)                                                     \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
-        acc[ni][(MG) * 4 + i] = M16::run(__builtin_bit_cast(frag, FB[ni]), __builtin_bit_cast(frag, FA[i]), acc[ni][(MG) * 4 + i]); \
+        acc[ni][(G) * MG + i] = M16::run(__builtin_bit_cast(frag, FB[ni]), __builtin_bit_cast(frag, FA[i]), acc[ni][(G) * MG + i]); \
     __builtin_amdgcn_s_setprio(0);                                                                     \
   }
 
+  if constexpr (MG == 3) { A0[3] = v4i{0, 0, 0, 0}; A1[3] = v4i{0, 0, 0, 0}; }
   const int nt = p.K / BK;
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -328,47 +342,48 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   if (nt > 1) stage(1, 1);
   {
     const unsigned a = offA + fo0, w = offW + fo0;
-    V3D_RD_A_LO(A0, a);
-    V3D_RD_A_LO(B0, w);
+    V3D_RDA(A0, a);
+    V3D_RD4(B0, w);
   }
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    const unsigned a0 = offA + cur * S3_BYTES + fo0, a1 = offA + cur * S3_BYTES + fo1;
+    const unsigned ah0 = offA_hi + cur * S3_BYTES + fo0, al1 = offA + cur * S3_BYTES + fo1, ah1 = offA_hi + cur * S3_BYTES + fo1;
     const unsigned w1 = offW + cur * S3_BYTES + fo1;
-    // phase 0: (k-half 0, rows 0..63)
-    V3D_RD_A_HI(A1, a0);
-    V3D_W8("lgkmcnt(4)", A0, B0);
+    // phase 0: k-half 0, first group of m-tiles
+    V3D_RDA(A1, ah0);
+    if constexpr (MG == 4) V3D_W8("lgkmcnt(4)", A0, B0); else V3D_W8("lgkmcnt(3)", A0, B0);
     V3D_MMA(A0, B0, 0);
-    // phase 1: (k-half 0, rows 64..127)
-    V3D_RD_A_LO(A0, a1);
-    V3D_RD_A_LO(B1, w1);
-    V3D_W4("lgkmcnt(8)", A1);
+    // phase 1: k-half 0, second group
+    V3D_RDA(A0, al1);
+    V3D_RD4(B1, w1);
+    if constexpr (MG == 4) V3D_W4("lgkmcnt(8)", A1); else V3D_W4("lgkmcnt(7)", A1);
     V3D_MMA(A1, B0, 1);
-    // phase 2: (k-half 1, rows 0..63)
-    V3D_RD_A_HI(A1, a1);
-    V3D_W8("lgkmcnt(4)", A0, B1);
+    // phase 2: k-half 1, first group
+    V3D_RDA(A1, ah1);
+    if constexpr (MG == 4) V3D_W8("lgkmcnt(4)", A0, B1); else V3D_W8("lgkmcnt(3)", A0, B1);
     V3D_MMA(A0, B1, 0);
-    // phase 3: (k-half 1, rows 64..127); tile t fully read, tile t+1 landed -> rendezvous, restage
+    // phase 3: k-half 1, second group; tile t fully read, tile t+1 landed -> rendezvous, restage
     V3D_W4("vmcnt(0) lgkmcnt(0)", A1);
     __builtin_amdgcn_s_barrier();
     if (t + 2 < nt) stage(cur, t + 2);
     {
       const unsigned a = offA + (cur ^ 1) * S3_BYTES + fo0, w = offW + (cur ^ 1) * S3_BYTES + fo0;
-      V3D_RD_A_LO(A0, a);      // next tile's phase-0 fragments (last step: stale, unused)
-      V3D_RD_A_LO(B0, w);
+      V3D_RDA(A0, a);      // next tile's phase-0 fragments (last step: stale, unused)
+      V3D_RD4(B0, w);
     }
     V3D_MMA(A1, B1, 1);
   }
   V3D_W8("lgkmcnt(0)", A0, B0);
 #undef V3D_DSR
-#undef V3D_RD_A_LO
-#undef V3D_RD_A_HI
+#undef V3D_RD4
+#undef V3D_RD3
+#undef V3D_RDA
 #undef V3D_W4
 #undef V3D_W8
 #undef V3D_MMA
   __syncthreads();
 
-  // epilogue in two 128-row halves (the 256 x 256 C tile does not fit the ring with padding)
+  // epilogue in two halves of WROWS rows (the whole C tile does not fit the ring with padding)
   constexpr int C3_ROW = B3N * 2 + 16;
   const T* bias = (const T*)p.bias;
   T* out = (T*)p.out;
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
           for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
         }
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
           const int ml = mi * 16 + (lane & 15);
           uint2 pk;
           pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
@@ -396,11 +411,9 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
     __syncthreads();
     if (EPI == EPI_SWIGLU) {
       // tile columns: per 128-column group [gate64 | up64]; two groups per tile -> 128 output columns
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 4) + 32 * i, c16 = tid & 15;       // 16 output chunks of 8 per row
-        const int grp = c16 >> 3, ch = c16 & 7;
-        const int gm = m0 + half * 128 + row;
+      for (int row = tid >> 4; row < WROWS; row += 32) {
+        const int c16 = tid & 15, grp = c16 >> 3, ch = c16 & 7;
+        const int gm = m0 + half * WROWS + row;
         const uint4 g = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + ch * 16);
         const uint4 u = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + 128 + ch * 16);
         float v[8];
@@ -409,10 +422,9 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
         if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + tn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = (tid >> 5) + 16 * i, ch = tid & 31;
-        const int gm = m0 + half * 128 + row;
+      for (int row = tid >> 5; row < WROWS; row += 16) {
+        const int ch = tid & 31;
+        const int gm = m0 + half * WROWS + row;
         if (gm < p.M) {
           uint4 c = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + ch * 16);
           if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES) {
@@ -535,13 +547,14 @@ static int gemm_variant() {   // 0 = auto, 1 = force 128x128, 3 = force 256x256 
   return v;
 }
 
-template <typename T>
+template <typename T, int MT>
 static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
-  p.tiles_m = (p.M + B3M - 1) / B3M;
+  constexpr int BM = MT * 32;
+  p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / B3N;
 #define V3D_GEMM3_CASE(E)                                                                                 \
   case E: {                                                                                               \
-    auto k = gemm256x256_kernel<T, E>;                                                                    \
+    auto k = gemm256x256_kernel<T, E, MT>;                                                                \
     static bool attr_done = false;                                                                        \
     if (!attr_done) {                                                                                     \
       hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM3_LDS_BYTES); \
@@ -561,7 +574,7 @@ static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
     default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
   }
 #undef V3D_GEMM3_CASE
-  return check_launch("v3d_gemm (256x256)");
+  return check_launch("v3d_gemm (256-wide)");
 }
 
 template <typename T>
@@ -570,10 +583,15 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
   // so it loses when its tile count quantises badly against 256 CUs (e.g. 27 x 14 = 378 tiles).
   const int var = gemm_variant();
   if (p.N % B3N == 0 && var != 1) {
-    const int tiles3 = ((p.M + B3M - 1) / B3M) * (p.N / B3N);
-    const double t3 = (double)((tiles3 + 255) / 256) * 4.0 / 1.27;
+    // cost in units of "one 128x128 tile on a whole CU at the 128x128 kernel's rate"
+    const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
+    const double t256 = (double)((tiles256 + 255) / 256) * 4.0 / 1.27;
+    const double t192 = (double)((tiles192 + 255) / 256) * 3.0 / 1.22;
     const double t1 = (double)p.tiles_m * p.tiles_n / 256.0;
-    if (var == 3 || t3 < t1) return launch_gemm256x256<T>(p, epi, st);
+    if (var == 4) return launch_gemm256x256<T, 6>(p, epi, st);
+    if (var == 3) return launch_gemm256x256<T, 8>(p, epi, st);
+    if (t192 < t256 && t192 < t1) return launch_gemm256x256<T, 6>(p, epi, st);
+    if (t256 < t1) return launch_gemm256x256<T, 8>(p, epi, st);
   }
 #define V3D_GEMM_CASE(E)                                                                                  \
   case E: {                                                                                               \
