@@ -136,7 +136,8 @@ int v3d_embed_gather(const void* table, int64_t vocab, int C, const int64_t* ids
  *                   [128t, 128t+64) = gate rows [64t, 64t+64), rows [128t+64, 128t+128) = the up rows. */
 enum {
   V3D_EPI_NONE = 0, V3D_EPI_BIAS = 1, V3D_EPI_BIAS_GELU_ERF = 2, V3D_EPI_BIAS_GELU_TANH = 3,
-  V3D_EPI_BIAS_RES = 4, V3D_EPI_RES = 5, V3D_EPI_SWIGLU = 6
+  V3D_EPI_BIAS_RES = 4, V3D_EPI_RES = 5, V3D_EPI_SWIGLU = 6,
+  V3D_EPI_BIAS_RELU = 7   /* out = relu(acc + bias)   grounding head, llava_qwen.py:93-104 */
 };
 int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* res,
              int64_t ldr, int res_mod, void* out, int64_t ldo, int M, int N, int K, int dtype, int epilogue,
@@ -205,6 +206,23 @@ int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, int head_di
 
 /* Greedy token choice: index of the maximum of x[0..n) (lowest index on ties, as torch.argmax). */
 int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* stream);
+
+/* ------------------------------------------------------------------ grounding (K19, K20) - */
+
+/* K19  llava_arch.py:357-372, object_feature_type 'patch14': mask[o, f, py, px] = 1 iff at least `thresh`
+ * (= int(14*14*0.5)) pixels of the cell x cell ViT patch lie inside box o = (centre xyz, size xyz).
+ * coords [F,S,S,3] dtype (first S-6 rows/cols used), boxes [n,6] dtype -> mask uint8 [n, F*g*g], g = (S-6)/cell. */
+int v3d_object_patch_mask(const void* coords, int dtype, int F, int S, int cell, const void* boxes, int n_obj,
+                          int thresh, uint8_t* mask, void* stream);
+
+/* llava_arch.py:482-501: out[o] = mean of the rows t of feat [T,C] with mask[o,t] != 0 (zeros if none)
+ * (+ add[o] if add != NULL: the box-centre PE). */
+int v3d_masked_mean(const void* feat, const uint8_t* mask, int n_obj, int T, int C, const void* add, void* out,
+                    int dtype, void* stream);
+
+/* K20  predict_box 'infonce', llava_qwen.py:298-300: scores[i] = <normalize(obj[i]), normalize(query)>. */
+int v3d_ground_scores(const void* obj, int64_t ldo, int n_rows, const void* query, int C, void* scores, int dtype,
+                      void* stream);
 
 /* ------------------------------------------------------------------ data movement ------- */
 

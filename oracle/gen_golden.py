@@ -413,6 +413,65 @@ def g_vit():
     save("siglip_layer", pixels=pix.numpy(), **{k: v.numpy() for k, v in {**wl, **we, **wp}.items()}, **out)
 
 
+def g_objects():
+    """Object-proposal patch masks + masked-mean features + box-centre PE (llava_arch.py:351-376, 416-420,
+    479-501, object_feature_type 'patch14-pe') and the infonce grounding head (llava_qwen.py:294-300).
+    The two llava_arch blocks sit inside prepare_inputs_labels_for_multimodal, so their own source lines are
+    executed here (read at run time, nothing copied) in a namespace holding the tensors they expect."""
+    import textwrap
+    import torch.nn.functional as F
+    from llava.model.position_encoding import PositionEmbeddingSine3D
+    with open(REF + "/llava/model/llava_arch.py") as f:
+        lines = f.read().split("\n")
+    a0 = next(i for i, l in enumerate(lines) if 'object_boxes = video_dict["objects"][0]' in l)
+    a1 = next(i for i, l in enumerate(lines) if "use_mrope_position_embedding = False" in l)
+    b0 = next(i for i, l in enumerate(lines) if "object_features = []" in l and i > a1)
+    b1 = next(i for i, l in enumerate(lines) if "object_features += box_center_features" in l) + 1
+    blk_a = textwrap.dedent("\n".join(lines[a0:a1]))
+    blk_b = textwrap.dedent("\n".join(lines[b0:b1]))
+    C, Fr = 96, 2
+    g = torch.Generator().manual_seed(51)
+    m = make_arch(dict(DEFAULT_CFG, object_feature_type="patch14-pe"))
+    pe = PositionEmbeddingSine3D(C)
+    m.model.world_position_embedding = pe
+    out = {}
+    coords = (torch.rand(Fr, 384, 384, 3, generator=g) - 0.5) * torch.tensor([8.0, 8.0, 3.0])
+    # piecewise-constant regions so that some 14x14 patches fall wholly inside boxes
+    coords = coords.view(Fr, 48, 8, 48, 8, 3)[:, :, :1, :, :1, :].expand(Fr, 48, 8, 48, 8, 3).reshape(Fr, 384, 384, 3).contiguous()
+    coords = coords.half().float()          # fp16-representable so one stored array serves both dtypes
+    boxes = torch.cat([(torch.rand(9, 3, generator=g) - 0.5) * torch.tensor([6.0, 6.0, 2.0]), torch.rand(9, 3, generator=g) * 4 + 0.5], 1)
+    boxes[8] = torch.tensor([50.0, 50.0, 50.0, 0.1, 0.1, 0.1])        # selects nothing -> zero feature
+    feats = torch.randn(Fr, 729, C, generator=g)
+    for name, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        ns = dict(torch=torch, self=m, video_dict={"world_coords": coords.to(dt)[None], "objects": boxes.to(dt)[None]},
+                  int=int)
+        exec(compile(blk_a, "<llava_arch object masks>", "exec"), ns)
+        centers = m.discrete_coords(ns["object_boxes_center"], None)           # :418-420
+        enc = feats.to(dt)
+        ns.update(image_features=[m.get_2dPool(enc)], encoded_image_features=[enc.flatten(0, 1)[None].squeeze(0).view(Fr, 729, C)],
+                  use_mlp_pe=False, use_sin3d_pe=True, object_boxes_center=centers)
+        exec(compile(blk_b, "<llava_arch object features>", "exec"), ns)
+        out["mask_" + name] = torch.stack(ns["object_patch"]).numpy()
+        out["objfeat_" + name] = ns["object_features"].float().numpy()
+        out["centers_" + name] = centers.float().numpy()
+    # infonce head (llava_qwen.py:87-104, 294-300)
+    torch.manual_seed(52)
+    H = 96
+    head_obj = torch.nn.Sequential(torch.nn.Linear(H, H), torch.nn.ReLU(), torch.nn.LayerNorm(H), torch.nn.Linear(H, H))
+    head_q = torch.nn.Sequential(torch.nn.Linear(H, H), torch.nn.ReLU(), torch.nn.LayerNorm(H), torch.nn.Linear(H, H))
+    zero_t = torch.randn(H)
+    objf = torch.from_numpy(out["objfeat_f32"])
+    q = torch.randn(1, H)
+    with torch.no_grad():
+        of = torch.cat([objf, zero_t[None]], 0)
+        scores = (F.normalize(head_obj(of)) * F.normalize(head_q(q))).sum(-1)
+    hw = {"ho." + k: v.detach().numpy() for k, v in head_obj.state_dict().items()}
+    hw.update({"hq." + k: v.detach().numpy() for k, v in head_q.state_dict().items()})
+    d = torch.arange(C // 3, dtype=torch.float32)
+    save("objects", coords=coords.half().numpy(), boxes=boxes.numpy(), feats=feats.numpy(), zero_target=zero_t.numpy(),
+         query=q.numpy(), scores=scores.numpy(), dim_t=(10000 ** (2 * (d // 2) / (C // 3))).numpy(), **hw, **out)
+
+
 GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}
 
 

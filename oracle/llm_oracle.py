@@ -177,3 +177,52 @@ def projector(x, w, pfx="model.mm_projector."):
     """mlp2x_gelu, multimodal_projector/builder.py:41-48: Linear -> nn.GELU() (erf) -> Linear."""
     h = F.gelu(F.linear(x, w[pfx + "0.weight"], w[pfx + "0.bias"]))
     return F.linear(h, w[pfx + "2.weight"], w[pfx + "2.bias"])
+
+
+# ----------------------------------------------------------------------------- object proposals / grounding
+
+
+def object_patch_mask(world_coords, boxes, cell=14, thresh_frac=0.5):
+    """llava/model/llava_arch.py:351-376, object_feature_type 'patch14': per proposal box, the ViT patches
+    (27 x 27 cells of 14 x 14 pixels over the first 378 rows/cols) with >= int(14*14*0.5) pixels inside the box.
+    world_coords [F,384,384,3], boxes [n,6] (centre, size), both in the model dtype -> bool [n,F,27,27]."""
+    F_ = world_coords.shape[0]
+    g = 378 // cell
+    wc = world_coords[:, :378, :378, :].reshape(-1, g, cell, g, cell, 3).transpose(2, 3).flatten(3, 4)
+    out = []
+    for box in boxes:
+        lo = box[:3] - box[3:] / 2
+        hi = box[:3] + box[3:] / 2
+        inside = torch.all((lo <= wc) & (wc <= hi), dim=-1)
+        out.append(inside.sum(dim=3) >= int(cell * cell * thresh_frac))
+    return torch.stack(out) if out else torch.zeros((0, F_, g, g), dtype=torch.bool)
+
+
+def object_features(encoded, masks, centre_pe=None):
+    """llava_arch.py:479-501: mean of the projector rows of the selected patches (zeros if none), plus the
+    3-D PE of the (discretised) box centre.  encoded [F,729,C]; masks bool [n,F,27,27]; centre_pe [n,C] or None."""
+    C = encoded.shape[-1]
+    feats = []
+    for m in masks:
+        sel = encoded[m.view(-1, 729)]
+        feats.append(sel.mean(dim=0) if len(sel) else torch.zeros(C, dtype=encoded.dtype))
+    f = torch.stack(feats)
+    if centre_pe is not None:
+        f = f + centre_pe
+    return f
+
+
+def ground_head(x, w, pfx):
+    """nn.Sequential(Linear, ReLU, LayerNorm, Linear), llava_qwen.py:93-104."""
+    h = F.relu(F.linear(x, w[pfx + "0.weight"], w[pfx + "0.bias"]))
+    h = F.layer_norm(h, (h.shape[-1],), w[pfx + "2.weight"], w[pfx + "2.bias"], 1e-5)
+    return F.linear(h, w[pfx + "3.weight"], w[pfx + "3.bias"])
+
+
+def infonce_scores(object_feats, zero_target, query_hidden, w, obj_pfx="ground_head_obj.", q_pfx="ground_head_query."):
+    """predict_box, ground_head_type 'infonce', llava_qwen.py:294-300: cosine similarity of the projected
+    object features (+ the learned zero-target row) with the projected <ground> hidden state -> [n+1]."""
+    of = torch.cat([object_feats, zero_target[None]], 0)
+    o = F.normalize(ground_head(of.to(query_hidden.dtype), w, obj_pfx))
+    q = F.normalize(ground_head(query_hidden, w, q_pfx))
+    return (o * q).sum(dim=-1)

@@ -64,3 +64,28 @@ def scene_forward(sd, cfg, input_ids, images, world_coords, dtype, max_new_token
     out["tokens"] = toks
     out["step_logits"] = step_logits
     return out
+
+
+def scene_ground(sd, cfg, input_ids, ground_index, images, world_coords, objects, dtype):
+    """ScanRefer-style forward: prefill + object-proposal features + infonce scores
+    (llava_arch.py:351-376, 479-501; llava_qwen.py:280-300)."""
+    w = {k: v.to(dtype) for k, v in sd.items()}
+    coords = world_coords.to(dtype)
+    boxes = objects.to(dtype)
+    tower = L.siglip_tower(images.to(dtype), w, cfg["vit_layers"], cfg["vit_heads"])
+    feats = L.projector(tower, w)
+    ids, vis = visual_sequence(w, coords, feats, dtype)
+    x = inputs_embeds(w, input_ids, vis, dtype)[None]
+    _, hidden, _ = L.qwen2_model(x, w, cfg)
+    at = input_ids.tolist().index(IMAGE_TOKEN_INDEX)
+    gpos = ground_index if ground_index < at else ground_index + vis.shape[0] - 1
+    masks = L.object_patch_mask(coords, boxes)
+    kind = KIND[dtype]
+    centres = torch.from_numpy(O.discrete_coords(_np(boxes[:, :3]), kind)).to(dtype)
+    C = feats.shape[-1]
+    d = torch.arange(C // 3, dtype=torch.float32)
+    dim_t = (10000 ** (2 * (d // 2) / (C // 3))).numpy()
+    pe = torch.from_numpy(O.sin3d_pe(_np(centres)[None], C, kind, dim_t=dim_t)[0]).to(dtype)
+    objf = L.object_features(feats, masks, pe)
+    scores = L.infonce_scores(objf, w["ground_head_zero_target"], hidden[0, gpos][None], w)
+    return dict(masks=masks, objf=objf, scores=scores, query=hidden[0, gpos])

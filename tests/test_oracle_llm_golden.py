@@ -61,3 +61,26 @@ def test_kv_cache_decode_matches_full_prefill(golden):
     pre, kv = L.qwen2_layer(x[:, :39], w, "", 2, 1, torch.arange(39), 1e6, 1e-6)
     last, _ = L.qwen2_layer(x[:, 39:], w, "", 2, 1, torch.arange(39, 40), 1e6, 1e-6, past_kv=kv)
     torch.testing.assert_close(last, full[:, 39:], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_object_masks_and_features(golden, name, dt):
+    """K19 against the reference's own lines (executed by the generator): masks bit-exact, features to 1 ulp16."""
+    g = golden("objects")
+    coords = torch.from_numpy(g["coords"]).to(dt)
+    boxes = torch.from_numpy(g["boxes"]).to(dt)
+    masks = L.object_patch_mask(coords, boxes)
+    assert np.array_equal(masks.numpy(), g["mask_" + name])
+    centres = torch.from_numpy(O.discrete_coords(boxes[:, :3].float().numpy(), name)).to(dt)
+    assert np.array_equal(centres.float().numpy(), g["centers_" + name])
+    pe = torch.from_numpy(O.sin3d_pe(centres.float().numpy()[None], 96, name, dim_t=g["dim_t"])[0]).to(dt)
+    f = L.object_features(torch.from_numpy(g["feats"]).to(dt), masks, pe)
+    np.testing.assert_allclose(f.float().numpy(), g["objfeat_" + name], rtol=0, atol=2e-6 if name == "f32" else 2e-3)
+
+
+def test_infonce_scores(golden):
+    g = golden("objects")
+    w = {k: torch.from_numpy(g[k]) for k in g.files if k.startswith(("ho.", "hq."))}
+    s = L.infonce_scores(torch.from_numpy(g["objfeat_f32"]), torch.from_numpy(g["zero_target"]), torch.from_numpy(g["query"]),
+                         w, "ho.", "hq.")
+    np.testing.assert_allclose(s.numpy(), g["scores"], rtol=1e-6, atol=1e-7)

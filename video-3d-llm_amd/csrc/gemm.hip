@@ -80,7 +80,8 @@ __device__ __forceinline__ void tile_of_block(int bid, int nblocks, int tiles_m,
   tn = in_g / gsz;
 }
 
-enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU_ERF = 2, EPI_BIAS_GELU_TANH = 3, EPI_BIAS_RES = 4, EPI_RES = 5, EPI_SWIGLU = 6 };
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU_ERF = 2, EPI_BIAS_GELU_TANH = 3, EPI_BIAS_RES = 4, EPI_RES = 5, EPI_SWIGLU = 6, EPI_BIAS_RELU = 7 };
+__host__ __device__ constexpr bool epi_has_bias(int e) { return (e >= EPI_BIAS && e <= EPI_BIAS_RES) || e == EPI_BIAS_RELU; }
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   for (int ni = 0; ni < 4; ++ni) {
     const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (EPI >= EPI_BIAS && EPI <= EPI_BIAS_RES) {
+    if (epi_has_bias(EPI)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
     }
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
     const int gm = m0 + row;
     if (gm >= p.M) continue;
     uint4 c = *reinterpret_cast<const uint4*>(smem + row * C_ROW_BYTES + ch * 16);
-    if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+    if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES || EPI == EPI_BIAS_RELU) {
       float v[8];
       uint4 rr = make_uint4(0, 0, 0, 0);
       if (EPI == EPI_BIAS_RES || EPI == EPI_RES) {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float x = vec_get<T>(c, j);
-        v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : x + vec_get<T>(rr, j);
+        v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + vec_get<T>(rr, j);
       }
       c = vec_pack<T>(v);
     }
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
       for (int ni = 0; ni < 4; ++ni) {
         const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (EPI >= EPI_BIAS && EPI <= EPI_BIAS_RES) {
+        if (epi_has_bias(EPI)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
         }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
         const int gm = m0 + half * WROWS + row;
         if (gm < p.M) {
           uint4 c = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + ch * 16);
-          if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+          if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES || EPI == EPI_BIAS_RELU) {
             float v[8];
             uint4 rr = make_uint4(0, 0, 0, 0);
             if (EPI == EPI_BIAS_RES || EPI == EPI_RES) {
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               const float x = vec_get<T>(c, j);
-              v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : x + vec_get<T>(rr, j);
+              v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + vec_get<T>(rr, j);
             }
             c = vec_pack<T>(v);
           }
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ A, cons
         x = round_to<T>(x);
         if (epi == EPI_BIAS_GELU_ERF) x = gelu_erf(x);
         if (epi == EPI_BIAS_GELU_TANH) x = gelu_tanh(x);
+        if (epi == EPI_BIAS_RELU) x = fmaxf(x, 0.f);
         if (epi == EPI_BIAS_GELU_ERF || epi == EPI_BIAS_GELU_TANH) x = round_to<T>(x);
         if (res) x = x + to_f32(res[(int64_t)(res_mod > 0 ? m % res_mod : m) * ldr + n]);
         out[(int64_t)m * ldo + n] = from_f32<T>(x);
@@ -571,6 +573,7 @@ static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
     V3D_GEMM3_CASE(EPI_BIAS_RES)
     V3D_GEMM3_CASE(EPI_RES)
     V3D_GEMM3_CASE(EPI_SWIGLU)
+    V3D_GEMM3_CASE(EPI_BIAS_RELU)
     default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
   }
 #undef V3D_GEMM3_CASE
@@ -612,6 +615,7 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
     V3D_GEMM_CASE(EPI_BIAS_RES)
     V3D_GEMM_CASE(EPI_RES)
     V3D_GEMM_CASE(EPI_SWIGLU)
+    V3D_GEMM_CASE(EPI_BIAS_RELU)
     default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
   }
 #undef V3D_GEMM_CASE
@@ -627,7 +631,7 @@ static int launch_gemv(const GemmArgs& p, int epi, hipStream_t st) {
     hipLaunchKernelGGL((gemv_swiglu_kernel<T, 8>), dim3(blocks), dim3(256), 0, st, (const T*)p.A, (const T*)p.W,
                        (T*)p.out, p.M, p.N, p.K, p.lda, p.ldw, p.ldo);
   } else {
-    const bool has_bias = epi >= EPI_BIAS && epi <= EPI_BIAS_RES;
+    const bool has_bias = epi_has_bias(epi);
     const bool has_res = epi == EPI_BIAS_RES || epi == EPI_RES;
     hipLaunchKernelGGL((gemv_kernel<T, 8>), dim3(blocks), dim3(256), 0, st, (const T*)p.A, (const T*)p.W,
                        has_bias ? (const T*)p.bias : nullptr, has_res ? (const T*)p.res : nullptr, (T*)p.out, p.M, p.N,
@@ -649,7 +653,7 @@ extern "C" int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   V3D_REQUIRE(N % BN == 0 && K % BK == 0, "v3d_gemm: N=%d must be a multiple of %d and K=%d of %d (pad the weights)", N, BN, K, BK);
   V3D_REQUIRE(lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0 && ldo % 8 == 0, "v3d_gemm: leading dimensions must be >= K and multiples of 8");
   V3D_REQUIRE(aligned16(A) && aligned16(W) && aligned16(out), "v3d_gemm: pointers must be 16-byte aligned");
-  const bool need_bias = epilogue >= EPI_BIAS && epilogue <= EPI_BIAS_RES;
+  const bool need_bias = epi_has_bias(epilogue);
   const bool need_res = epilogue == EPI_BIAS_RES || epilogue == EPI_RES;
   V3D_REQUIRE(!need_bias || bias, "v3d_gemm: epilogue %d needs a bias", epilogue);
   V3D_REQUIRE(!need_res || (res && aligned16(res) && ldr % 8 == 0), "v3d_gemm: epilogue %d needs an aligned residual", epilogue);

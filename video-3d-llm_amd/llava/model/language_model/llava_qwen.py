@@ -3,8 +3,11 @@
 Mirrors the call contract the 3-D eval drivers use (llava_qwen.py:208-236, model_scanqa.py:173-185):
     model.generate(input_ids, images=[1,F,3,384,384], modalities="video", video_dict={"world_coords": [1,F,384,384,3], ...},
                    do_sample=False, num_beams=1, max_new_tokens=N, use_cache=True)  -> LongTensor [1, n_new]
-Weights come in under the reference's state-dict keys (Engine docstring).  Sampling, beams and the
-grounding head (`use_object_proposals`) are not on the accelerated path yet.
+and the grounding call of ScanRefer / Multi3DRefer (model_scanrefer.py:165-173):
+    _, scores = model(input_ids, images=..., modalities="video", video_dict=..., labels=labels,
+                      use_object_proposals=True, box_labels=None)            -> scores [n_obj + 1]
+Weights come in under the reference's state-dict keys (Engine docstring; ground_head_{obj,query}.*,
+ground_head_zero_target for the infonce head).  Sampling and beams are not on the accelerated path.
 """
 import types
 
@@ -29,6 +32,24 @@ class LlavaQwenForCausalLM(nn.Module):
     @property
     def device(self):
         return self._device
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, images=None, modalities=("image",), video_dict=None, labels=None,
+                use_object_proposals=False, box_labels=None, **kw):
+        """Only the inference grounding call is provided: returns (None, scores) like predict_box with
+        box_labels=None (llava_qwen.py:176-205, 239-331)."""
+        if not use_object_proposals or box_labels is not None:
+            raise NotImplementedError("training / plain-LM forward is outside the accelerated path; use generate()")
+        gt = getattr(self.config, "ground_token_ids", None)
+        if gt is None:
+            raise ValueError("config.ground_token_ids is needed to locate the <ground> label")
+        loc = ((labels[0] >= gt[0]) & (labels[0] <= gt[-1])).nonzero().flatten()
+        if loc.numel() != 1:
+            raise ValueError("exactly one <ground> label token expected")
+        frames = images[0] if images.dim() == 5 else images
+        scores = self.engine.ground_scores(input_ids[0].cpu(), int(loc[0]), frames.to(self._device),
+                                           video_dict["world_coords"][0].to(self._device), video_dict["objects"][0])
+        return None, scores
 
     @torch.no_grad()
     def generate(self, inputs=None, images=None, image_sizes=None, modalities=("image",), video_dict=None,

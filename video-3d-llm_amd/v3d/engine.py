@@ -58,7 +58,7 @@ class EngineConfig:
     voxel_size: float = 0.1
 
 
-def random_state_dict(cfg: EngineConfig, dtype, device, seed=0, std=0.02):
+def random_state_dict(cfg: EngineConfig, dtype, device, seed=0, std=0.02, ground_head=False):
     """Random-init weights at the configured widths under the reference's state-dict keys."""
     g = torch.Generator(device=device).manual_seed(seed)
 
@@ -108,6 +108,12 @@ def random_state_dict(cfg: EngineConfig, dtype, device, seed=0, std=0.02):
         sd[p + "post_attention_layernorm.weight"] = 1 + rn(l.hidden)
     sd["model.norm.weight"] = 1 + rn(l.hidden)
     sd["lm_head.weight"] = rn(l.vocab, l.hidden)
+    if ground_head:
+        for pfx in ("ground_head_obj.", "ground_head_query."):
+            sd[pfx + "0.weight"], sd[pfx + "0.bias"] = rn(l.hidden, l.hidden), rn(l.hidden)
+            sd[pfx + "2.weight"], sd[pfx + "2.bias"] = 1 + rn(l.hidden), rn(l.hidden)
+            sd[pfx + "3.weight"], sd[pfx + "3.bias"] = rn(l.hidden, l.hidden), rn(l.hidden)
+        sd["ground_head_zero_target"] = rn(l.hidden, s=1.0)
     return sd
 
 
@@ -140,6 +146,9 @@ class Engine:
         sd = {k: t.to(device=device, dtype=dtype) for k, t in state_dict.items()}
         self._prep_vit(sd)
         self._prep_llm(sd)
+        self.ground = None
+        if "ground_head_obj.0.weight" in sd:         # infonce grounding head (llava_qwen.py:87-104), optional
+            self.ground = {k: sd[k].contiguous() for k in sd if k.startswith("ground_head_")}
         self.newline = sd["model.image_newline"].contiguous()
         self.embed = sd["model.embed_tokens.weight"].contiguous()
         n_ids = int(round((max(cfg.max_xyz[0] - cfg.min_xyz[0], cfg.max_xyz[1] - cfg.min_xyz[1],
@@ -353,6 +362,39 @@ class Engine:
 
     def last_hidden(self):
         return self.l_last[0]
+
+    # ------------------------------------------------------------------ grounding (a24)
+    @torch.no_grad()
+    def ground_scores(self, input_ids, ground_index, images, world_coords, objects):
+        """ScanRefer / Multi3DRefer forward (model_scanrefer.py:165-173 -> llava_qwen.forward(use_object_proposals=True)
+        -> predict_box, infonce head): one prefill, scores [n_obj + 1] (last = the zero-target).
+        ground_index: index IN input_ids of the <ground> label token whose hidden state is the query."""
+        if self.ground is None:
+            raise V3DError("this engine was built without ground_head_* weights")
+        l, g = self.cfg.llm, self.ground
+        H = l.hidden
+        coords = world_coords.to(self.dtype)
+        boxes = objects.to(device=self.device, dtype=self.dtype).contiguous()
+        feats = self.encode_images(images)
+        ids = self.voxel_ids(coords)
+        x = self.build_inputs_embeds(input_ids, feats, ids)
+        at = input_ids.tolist().index(-200)
+        n_vis = feats.shape[0] * self.cfg.pool_out * (self.cfg.pool_out + 1)
+        gpos = ground_index if ground_index < at else ground_index + n_vis - 1
+        self.llm_forward(x, 0)
+        query = ops.rmsnorm(x[gpos: gpos + 1], self.l_norm, l.eps, out=self.l_last[1:2])        # outputs[0][ground_locations]
+        mask = ops.object_patch_mask(coords, boxes)                                               # K19
+        centres = ops.discrete_coords(boxes[:, :3].contiguous(), self.cfg.min_xyz, self.cfg.max_xyz, self.cfg.voxel_size)
+        pe = ops.sin3d_pe(centres[None], H, dim_t=self.pe_table.dim_t)[0]
+        objf = ops.masked_mean(feats.reshape(-1, H), mask.view(mask.shape[0], -1), add=pe)
+        of = torch.cat([objf, g["ground_head_zero_target"][None]], 0).contiguous()
+
+        def head(xin, pfx):
+            h = ops.gemm(xin, g[pfx + "0.weight"], bias=g[pfx + "0.bias"], epilogue=ops.EPI_BIAS_RELU)
+            hn = ops.layernorm(h, g[pfx + "2.weight"], g[pfx + "2.bias"], 1e-5)
+            return ops.gemm(hn, g[pfx + "3.weight"], bias=g[pfx + "3.bias"], epilogue=ops.EPI_BIAS)
+
+        return ops.ground_scores(head(of, "ground_head_obj."), head(query, "ground_head_query.")[0])      # K20
 
     # ------------------------------------------------------------------ generate (a23)
     @torch.no_grad()

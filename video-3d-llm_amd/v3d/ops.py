@@ -215,7 +215,7 @@ def greedy_cover(keys, scene_voxels, max_frames=32):
 
 # ------------------------------------------------------------------------------ dense linears
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_ERF, EPI_BIAS_GELU_TANH, EPI_BIAS_RES, EPI_RES, EPI_SWIGLU = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU_ERF, EPI_BIAS_GELU_TANH, EPI_BIAS_RES, EPI_RES, EPI_SWIGLU, EPI_BIAS_RELU = range(8)
 
 
 def gemm(a, w, bias=None, res=None, epilogue=EPI_NONE, out=None, res_mod=0):
@@ -344,6 +344,38 @@ def rope_kv_append(qkv_row, n_q, n_kv, hd, table, pos, cache_row):
 def argmax(x, out):
     """out: int64 device tensor of one element."""
     check(lib().v3d_argmax(_p(x), x.numel(), _code(x), _p(out), _stream()), "v3d_argmax")
+    return out
+
+
+# ------------------------------------------------------------------------------ grounding
+
+
+def object_patch_mask(coords, boxes, cell=14, thresh=None):
+    """coords [F,S,S,3], boxes [n,6] (same dtype) -> uint8 [n, F, g, g]."""
+    c, b = _dev(coords, "coords"), _dev(boxes, "boxes").to(coords.dtype)
+    F_, S = c.shape[0], c.shape[1]
+    g = (S - 6) // cell
+    n = b.shape[0]
+    thresh = int(cell * cell * 0.5) if thresh is None else thresh
+    mask = torch.zeros((n, F_, g, g), dtype=torch.uint8, device=c.device)
+    check(lib().v3d_object_patch_mask(_p(c), _code(c), F_, S, cell, _p(b), n, thresh, _p(mask), _stream()), "v3d_object_patch_mask")
+    return mask
+
+
+def masked_mean(feat, mask, add=None):
+    """feat [T,C]; mask uint8 [n, T(flattened)] -> [n, C]."""
+    f = _dev(feat, "feat")
+    T_, C = f.shape
+    n = mask.shape[0]
+    out = torch.empty((n, C), dtype=f.dtype, device=f.device)
+    check(lib().v3d_masked_mean(_p(f), _p(mask), n, T_, C, _p(add), _p(out), _code(f), _stream()), "v3d_masked_mean")
+    return out
+
+
+def ground_scores(obj, query):
+    n, C = obj.shape
+    out = torch.empty(n, dtype=obj.dtype, device=obj.device)
+    check(lib().v3d_ground_scores(_p(obj), obj.stride(0), n, _p(query), C, _p(out), _code(obj), _stream()), "v3d_ground_scores")
     return out
 
 
