@@ -381,25 +381,42 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
   }
-  for (int key = k_begin + slot; key < k_end; key += 16) {
-    const uint4 k4 = *reinterpret_cast<const uint4*>(K + (int64_t)key * p.ldk + cl * 8);
-    const uint4 v4 = *reinterpret_cast<const uint4*>(V + (int64_t)key * p.ldv + cl * 8);
-    float kf[8], vf[8];
+  for (int kb = k_begin; kb < k_end; kb += 64) {
+    // four independent (K,V) row loads per lane in flight before any arithmetic (memory-level parallelism)
+    uint4 k4[4], v4[4];
+    bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { kf[j] = vec_get<T>(k4, j); vf[j] = vec_get<T>(v4, j); }
+    for (int it = 0; it < 4; ++it) {
+      const int key = kb + slot + 16 * it;
+      ok[it] = key < k_end;
+      const int kc = ok[it] ? key : k_begin;
+      k4[it] = *reinterpret_cast<const uint4*>(K + (int64_t)kc * p.ldk + cl * 8);
+      v4[it] = *reinterpret_cast<const uint4*>(V + (int64_t)kc * p.ldv + cl * 8);
+    }
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float s = 0.f;
+    for (int it = 0; it < 4; ++it) {
+      float kf[8], vf[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s = fmaf(qv[g][j], kf[j], s);
-      s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-      const float m_new = fmaxf(m[g], s);
-      const float alpha = exp2f(m[g] - m_new);
-      const float e = exp2f(s - m_new);
-      l[g] = l[g] * alpha + e;
+      for (int j = 0; j < 8; ++j) { kf[j] = vec_get<T>(k4[it], j); vf[j] = vec_get<T>(v4[it], j); }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[g][j] = fmaf(e, vf[j], acc[g][j] * alpha);
-      m[g] = m_new;
+      for (int g = 0; g < G; ++g) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(qv[g][j], kf[j], s);
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        s = ok[it] ? s : -INFINITY;
+        if (s > m[g]) {                      // running max moved (rare after the first keys): rescale this head
+          const float alpha = __builtin_amdgcn_exp2f(m[g] - s);     // m = -inf -> 0
+          l[g] *= alpha;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[g][j] *= alpha;
+          m[g] = s;
+        }
+        const float e = ok[it] ? __builtin_amdgcn_exp2f(s - m[g]) : 0.f;
+        l[g] += e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = fmaf(e, vf[j], acc[g][j]);
+      }
     }
   }
   // merge the 16 key slots
@@ -537,7 +554,7 @@ extern "C" int v3d_attention_decode(const void* q, const void* k_cache, const vo
   V3D_REQUIRE(Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DEC_MAXG, "v3d_attention_decode: bad head counts");
   V3D_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0 && hsq % 8 == 0 && hsk % 8 == 0 && aligned16(q) && aligned16(k_cache) && aligned16(v_cache),
               "v3d_attention_decode: alignment");
-  int n_split = (Sk + 127) / 128;                    // >= 128 keys per split keeps the merge cheap
+  int n_split = (Sk + 63) / 64;                      // >= 64 keys per split: 4 x 107 workgroups at S = 6.8k
   const int cap = 1024 / Hkv;                        // ~4 workgroups per CU
   if (n_split > cap) n_split = cap;
   if (n_split < 1) n_split = 1;

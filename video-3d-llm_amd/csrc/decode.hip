@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void linear_decode_kernel(const T* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = reinterpret_cast<const uint4*>(W + (int64_t)rows[r] * ldw);
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 4
     for (int k = lane; k < kv; k += 64) {
       uint4 w4[4];
 #pragma unroll
