@@ -14,6 +14,8 @@
 //                               -> O^T keeps the query on the lane: the online-softmax rescale
 //                               is a per-lane multiply.
 // The O tile is transposed once through LDS on the way out.
+#include <stdlib.h>
+
 #include "v3d_common.h"
 
 namespace v3d {
@@ -554,7 +556,9 @@ extern "C" int v3d_attention_decode(const void* q, const void* k_cache, const vo
   V3D_REQUIRE(Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DEC_MAXG, "v3d_attention_decode: bad head counts");
   V3D_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0 && hsq % 8 == 0 && hsk % 8 == 0 && aligned16(q) && aligned16(k_cache) && aligned16(v_cache),
               "v3d_attention_decode: alignment");
-  int n_split = (Sk + 63) / 64;                      // >= 64 keys per split: 4 x 107 workgroups at S = 6.8k
+  static int kps = 0;
+  if (!kps) { const char* e = getenv("V3D_DEC_KEYS_PER_SPLIT"); kps = e ? atoi(e) : 64; }
+  int n_split = (Sk + kps - 1) / kps;                // >= 64 keys per split: 4 x 107 workgroups at S = 6.8k
   const int cap = 1024 / Hkv;                        // ~4 workgroups per CU
   if (n_split > cap) n_split = cap;
   if (n_split < 1) n_split = 1;

@@ -129,6 +129,11 @@ def _pad1(b, n):
     return out
 
 
+class SceneContext:
+    """Buffers that belong to one (scene, question) in flight: inputs_embeds / residual stream, KV cache,
+    last-row hidden + logits, the decode step's row buffers and split-KV workspace."""
+
+
 class Engine:
     VIT_DP = 96      # SigLIP head dim 72, zero padded to the attention kernel's 96
 
@@ -224,14 +229,43 @@ class Engine:
         self.v_qkv, self.v_att, self.v_mlp = z(T, self.v_nqkv), z(T, self.v_Hp), z(T, self.v_Ip)
         self.p_h, self.feat = z(T, l.hidden), z(T, l.hidden)
         S = l.max_pos
-        self.l_x, self.l_h = z(S, l.hidden), z(S, l.hidden)
+        self.l_h = z(S, l.hidden)                      # prefill scratch (one prefill runs at a time)
         self.l_qkv, self.l_att, self.l_act = z(S, self.l_nqkv), z(S, l.hidden), z(S, l.inter)
-        kvw = 2 * l.kv_heads * self.hd
-        self.kv = [z(S, kvw) for _ in range(l.layers)]
-        self.l_last = z(8, l.hidden)
-        self.logits = z(8, self.l_head.shape[0])
-        self.kv_len = 0
-        self.dec_ws = ops.decode_workspace(l.heads, l.kv_heads, dev)
+        self.ctx = self.new_context()                  # per-scene state (sequence buffer, KV cache, decode rows)
+
+    def new_context(self):
+        """Per-scene state.  A second context lets the decode of scene i (HBM-bound weight streaming) run on
+        another stream while scene i+1's ViT / prefill (MFMA-bound) occupies the matrix cores."""
+        l = self.cfg.llm
+        dt, dev = self.dtype, self.device
+        z = lambda *s: torch.zeros(s, dtype=dt, device=dev)
+        c = SceneContext()
+        c.l_x = z(l.max_pos, l.hidden)
+        c.kv = [z(l.max_pos, 2 * l.kv_heads * self.hd) for _ in range(l.layers)]
+        c.l_last, c.logits = z(8, l.hidden), z(8, self.l_head.shape[0])
+        c.d_qkv, c.d_att, c.d_act = z(self.l_nqkv), z(l.hidden), z(l.inter)
+        c.dec_ws = ops.decode_workspace(l.heads, l.kv_heads, dev)
+        c.kv_len = 0
+        return c
+
+    def use(self, ctx):
+        """Select the context subsequent launches read/write (host-side pointer switch only)."""
+        self.ctx = ctx
+        return ctx
+
+    l_x = property(lambda self: self.ctx.l_x)
+    kv = property(lambda self: self.ctx.kv)
+    l_last = property(lambda self: self.ctx.l_last)
+    logits = property(lambda self: self.ctx.logits)
+    dec_ws = property(lambda self: self.ctx.dec_ws)
+
+    @property
+    def kv_len(self):
+        return self.ctx.kv_len
+
+    @kv_len.setter
+    def kv_len(self, v):
+        self.ctx.kv_len = v
 
     # ------------------------------------------------------------------ ViT + projector (a9, a10)
     def encode_images(self, images):
@@ -348,7 +382,7 @@ class Engine:
         hd, nh, nkv = self.hd, l.heads, l.kv_heads
         kvw = nkv * hd
         scale = 1.0 / math.sqrt(hd)
-        xr, qkv, att, act = x_row[0], self.l_qkv[0], self.l_att[0], self.l_act[0]
+        xr, qkv, att, act = x_row[0], self.ctx.d_qkv, self.ctx.d_att, self.ctx.d_act
         for i, L in enumerate(self.l_layers):
             cache = self.kv[i]
             ops.linear_decode(xr, L["wqkv"], qkv, norm_weight=L["ln1"], eps=l.eps, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
