@@ -24,91 +24,108 @@ __device__ __forceinline__ uint4 ldg_nt(const uint4* p) {
   return r;
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void linear_decode_kernel(const T* __restrict__ x, const T* __restrict__ norm_w, float eps,
-                                                            const T* __restrict__ W, int64_t ldw, const T* __restrict__ bias,
-                                                            const T* __restrict__ res, T* __restrict__ out, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float red[4];
-  uint4* xs = reinterpret_cast<uint4*>(smem);            // K/8 chunks of the (normalised) activation row, 16 bit
+// Workgroup = 4 waves = FOUR weight rows; the K range is split over the 256 threads (chunk k = tid + 256 i), so
+// every row is streamed by all four waves at once: N/4 workgroups (1152 for the QKV linear) keep the whole chip
+// loading even for the small linears, and each thread has 8 independent 16-byte loads in flight.
+// <= 64 VGPRs on purpose: one wave of this kernel then fits on every SIMD beside two resident 224-register GEMM
+// waves, so the decode step of one scene streams weights while another scene's prefill owns the matrix cores.
+// NORM (fused Qwen2RMSNorm, modeling_qwen2.py:85-90) needs K <= 4096: the thread keeps its 2 chunks of x in
+// registers between the sum-of-squares pass and the multiply pass.
+template <typename T, int EPI, bool NORM>
+__global__ __launch_bounds__(256, 8) void linear_decode_kernel(const T* __restrict__ x, const T* __restrict__ norm_w, float eps,
+                                                               const T* __restrict__ W, int64_t ldw, const T* __restrict__ bias,
+                                                               const T* __restrict__ res, T* __restrict__ out, int N, int K) {
+  __shared__ float red[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kv = K / 8;
-
-  // ---- stage x (optionally RMS-normalised: modeling_qwen2.py:85-90 rounding points) ----
-  float ss = 0.f;
-  for (int k = tid; k < kv; k += 256) {
-    const uint4 v = reinterpret_cast<const uint4*>(x)[k];
-    xs[k] = v;
-    if (norm_w) {
+  int rows[4];
+  int o0;
+  if (EPI == DEC_EPI_SWIGLU) {
+    o0 = blockIdx.x * 2;                                   // two outputs = two (gate, up) row pairs
+    rows[0] = (o0 >> 6) * 128 + (o0 & 63); rows[1] = rows[0] + 64;
+    rows[2] = ((o0 + 1) >> 6) * 128 + ((o0 + 1) & 63); rows[3] = rows[2] + 64;
+  } else {
+    o0 = blockIdx.x * 4;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(v, j); ss = fmaf(f, f, ss); }
-    }
+    for (int r = 0; r < 4; ++r) rows[r] = o0 + r;
   }
-  if (norm_w) {
+  const uint4* xr = reinterpret_cast<const uint4*>(x);
+  uint4 xn[2];
+  if (NORM) {                                              // kv <= 512: chunks tid and tid + 256
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = tid + 256 * i;
+      xn[i] = k < kv ? xr[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(xn[i], j); ss = fmaf(f, f, ss); }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) red[wave] = ss;
+    if (lane == 0) red[0][wave] = ss;
     __syncthreads();
-    const float r = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
-    for (int k = tid; k < kv; k += 256) {
-      const uint4 v = xs[k], w = reinterpret_cast<const uint4*>(norm_w)[k];
-      float y[8];
+    const float r = 1.0f / sqrtf((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)K + eps);
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(w, j) * round_to<T>(vec_get<T>(v, j) * r);
-      xs[k] = vec_pack<T>(y);
+    for (int i = 0; i < 2; ++i) {
+      const int k = tid + 256 * i;
+      if (k < kv) {
+        const uint4 w = reinterpret_cast<const uint4*>(norm_w)[k];
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(w, j) * round_to<T>(vec_get<T>(xn[i], j) * r);
+        xn[i] = vec_pack<T>(y);
+      }
     }
   }
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const uint4* w0 = reinterpret_cast<const uint4*>(W + (int64_t)rows[0] * ldw);
+  const uint4* w1 = reinterpret_cast<const uint4*>(W + (int64_t)rows[1] * ldw);
+  const uint4* w2 = reinterpret_cast<const uint4*>(W + (int64_t)rows[2] * ldw);
+  const uint4* w3 = reinterpret_cast<const uint4*>(W + (int64_t)rows[3] * ldw);
+  auto fma8 = [&](const uint4& xv, const uint4& a, const uint4& b, const uint4& c, const uint4& d) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = vec_get<T>(xv, j);
+      s[0] = fmaf(vec_get<T>(a, j), xf, s[0]);
+      s[1] = fmaf(vec_get<T>(b, j), xf, s[1]);
+      s[2] = fmaf(vec_get<T>(c, j), xf, s[2]);
+      s[3] = fmaf(vec_get<T>(d, j), xf, s[3]);
+    }
+  };
+  if (NORM) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = tid + 256 * i;
+      if (k < kv) fma8(xn[i], ldg_nt(w0 + k), ldg_nt(w1 + k), ldg_nt(w2 + k), ldg_nt(w3 + k));
+    }
+  } else {
+#pragma unroll 2
+    for (int k = tid; k < kv; k += 256) fma8(xr[k], ldg_nt(w0 + k), ldg_nt(w1 + k), ldg_nt(w2 + k), ldg_nt(w3 + k));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[r][wave] = s[r];
+  }
   __syncthreads();
-
-  // ---- stream weight rows: 4 rows per wave-iteration ----
-  const int n_out = EPI == DEC_EPI_SWIGLU ? N / 2 : N;
-  const int per_iter = EPI == DEC_EPI_SWIGLU ? 2 : 4;                 // outputs per wave-iteration
-  const int wave_global = blockIdx.x * 4 + wave, n_waves = gridDim.x * 4;
-  for (int o0 = wave_global * per_iter; o0 < n_out; o0 += n_waves * per_iter) {
-    int rows[4];
-    if (EPI == DEC_EPI_SWIGLU) {
-      const int j0 = o0, j1 = o0 + 1;                                  // per_iter = 2 outputs: gate/up row pairs
-      rows[0] = (j0 >> 6) * 128 + (j0 & 63); rows[1] = rows[0] + 64;
-      rows[2] = (j1 >> 6) * 128 + (j1 & 63); rows[3] = rows[2] + 64;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rows[r] = o0 + r;
+  if (EPI == DEC_EPI_SWIGLU) {
+    if (tid < 2) {
+      const float g = round_to<T>(red[2 * tid][0] + red[2 * tid][1] + red[2 * tid][2] + red[2 * tid][3]);
+      const float u = round_to<T>(red[2 * tid + 1][0] + red[2 * tid + 1][1] + red[2 * tid + 1][2] + red[2 * tid + 1][3]);
+      out[o0 + tid] = from_f32<T>(round_to<T>(silu_f(g)) * u);
     }
-    const uint4* wr[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) wr[r] = reinterpret_cast<const uint4*>(W + (int64_t)rows[r] * ldw);
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int k = lane; k < kv; k += 64) {
-      uint4 w4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w4[r] = ldg_nt(wr[r] + k);
-      const uint4 xv = xs[k];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xf = vec_get<T>(xv, j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = fmaf(vec_get<T>(w4[r], j), xf, s[r]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off);
-    }
-    if (EPI == DEC_EPI_SWIGLU) {
-      if (lane < 2) {
-        const float g = round_to<T>(lane == 0 ? s[0] : s[2]), u = round_to<T>(lane == 0 ? s[1] : s[3]);
-        out[o0 + lane] = from_f32<T>(round_to<T>(silu_f(g)) * u);
-      }
-    } else if (lane < 4) {
-      const int n = o0 + lane;
-      float v = lane == 0 ? s[0] : lane == 1 ? s[1] : lane == 2 ? s[2] : s[3];
-      if (EPI == DEC_EPI_BIAS) v += to_f32(bias[n]);
-      v = round_to<T>(v);                                   // the linear's own output rounding
-      if (EPI == DEC_EPI_RES) v += to_f32(res[n]);
-      out[n] = from_f32<T>(v);
-    }
+  } else if (tid < 4) {
+    const int n = o0 + tid;
+    float v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    if (EPI == DEC_EPI_BIAS) v += to_f32(bias[n]);
+    v = round_to<T>(v);                                   // the linear's own output rounding
+    if (EPI == DEC_EPI_RES) v += to_f32(res[n]);
+    out[n] = from_f32<T>(v);
   }
 }
 
@@ -191,27 +208,25 @@ extern "C" int v3d_linear_decode(const void* x, const void* norm_weight, float e
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_linear_decode: dtype must be f16 or bf16");
   V3D_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K, "v3d_linear_decode: bad shape N=%d K=%d", N, K);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "v3d_linear_decode: N=%d not supported", N);
-  V3D_REQUIRE((size_t)K * 2 <= 64 * 1024, "v3d_linear_decode: K=%d exceeds the LDS staging row", K);
   V3D_REQUIRE(aligned16(x) && aligned16(W) && (!norm_weight || aligned16(norm_weight)), "v3d_linear_decode: alignment");
   V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "v3d_linear_decode: bias epilogue without bias");
   V3D_REQUIRE(epilogue != DEC_EPI_RES || res, "v3d_linear_decode: residual epilogue without residual");
-  const int n_out = epilogue == DEC_EPI_SWIGLU ? N / 2 : N;
-  const int per_block = (epilogue == DEC_EPI_SWIGLU ? 2 : 4) * 4;
-  int blocks = (n_out + per_block - 1) / per_block;
-  if (blocks > 2048) blocks = 2048;
-  const size_t lds = (size_t)K * 2;
+  V3D_REQUIRE(!norm_weight || K / 8 <= 512, "v3d_linear_decode: fused RMSNorm needs K <= 4096 (got %d)", K);
+  const int blocks = epilogue == DEC_EPI_SWIGLU ? N / 4 : N / 4;     // 4 weight rows per workgroup either way
   hipStream_t st = (hipStream_t)stream;
-#define V3D_LD(TT, EE)                                                                                                      \
-  hipLaunchKernelGGL((linear_decode_kernel<TT, EE>), dim3(blocks), dim3(256), lds, st, (const TT*)x, (const TT*)norm_weight, \
+#define V3D_LD(TT, EE, NN)                                                                                                 \
+  hipLaunchKernelGGL((linear_decode_kernel<TT, EE, NN>), dim3(blocks), dim3(256), 0, st, (const TT*)x, (const TT*)norm_weight, \
                      eps, (const TT*)W, ldw, (const TT*)bias, (const TT*)res, (TT*)out, N, K)
+#define V3D_LD_N(TT, EE) { if (norm_weight) V3D_LD(TT, EE, true); else V3D_LD(TT, EE, false); }
 #define V3D_LD_E(TT)                                                                                  \
   switch (epilogue) {                                                                                 \
-    case DEC_EPI_NONE: V3D_LD(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LD(TT, DEC_EPI_BIAS); break; \
-    case DEC_EPI_RES: V3D_LD(TT, DEC_EPI_RES); break; case DEC_EPI_SWIGLU: V3D_LD(TT, DEC_EPI_SWIGLU); break; \
+    case DEC_EPI_NONE: V3D_LD_N(TT, DEC_EPI_NONE) break; case DEC_EPI_BIAS: V3D_LD_N(TT, DEC_EPI_BIAS) break; \
+    case DEC_EPI_RES: V3D_LD_N(TT, DEC_EPI_RES) break; case DEC_EPI_SWIGLU: V3D_LD_N(TT, DEC_EPI_SWIGLU) break; \
     default: set_error("v3d_linear_decode: unknown epilogue %d", epilogue); return V3D_E_INVALID;     \
   }
   if (dtype == V3D_BF16) { V3D_LD_E(bf16_t) } else { V3D_LD_E(f16_t) }
 #undef V3D_LD_E
+#undef V3D_LD_N
 #undef V3D_LD
   return check_launch("v3d_linear_decode");
 }

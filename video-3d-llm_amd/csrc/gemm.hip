@@ -260,6 +260,8 @@ constexpr int GEMM3_LDS_BYTES = 2 * S3_BYTES;           // 128 KiB
 
 // MT = 16-row accumulator tiles per wave along M: 8 -> BM = 256, 6 -> BM = 192 (picked so that the tile count
 // fills whole rounds of the 256 CUs, e.g. M = 6794, N = 3584: 27 x 14 = 378 tiles (74 %) vs 36 x 14 = 504 (98 %)).
+// Register budget: <= 224 per lane (2 waves/SIMD = 448 of 512) leaves one 64-register slot per SIMD, which is
+// what a linear_decode wave of ANOTHER scene needs to stream weights beside this kernel (bench.py run_pipelined).
 template <typename T, int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,29 +281,31 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * B3N;
 
-  const uint16_t* a_src[APW];
-  const uint16_t* w_src[4];
+  // per-lane source offsets in elements (32 bit: M*lda and N*ldw stay below 2^31 on this path; checked by the host)
+  unsigned a_off[APW], w_off[4];   // BYTE offsets, unsigned: lets the DMA use the SGPR-base + 32-bit VGPR-offset form
 #pragma unroll
   for (int i = 0; i < APW; ++i) {
     const int row = wave * (APW * 8) + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     int gm = m0 + row;
     gm = gm < p.M ? gm : p.M - 1;
-    a_src[i] = (const uint16_t*)p.A + (int64_t)gm * p.lda + chunk * 8;
+    a_off[i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    w_src[i] = (const uint16_t*)p.W + (int64_t)(n0 + row) * p.ldw + chunk * 8;
+    w_off[i] = (unsigned)((n0 + row) * (int)p.ldw + chunk * 8) * 2u;
   }
   auto stage = [&](int buf, int kt) {
     char* ba = smem + buf * S3_BYTES + (wave * APW * 8) * (BK * 2);
     char* bw = smem + buf * S3_BYTES + T3_BYTES + (wave * 32) * (BK * 2);
+    const char* Ak = (const char*)p.A + (size_t)kt * (BK * 2);
+    const char* Wk = (const char*)p.W + (size_t)kt * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < APW; ++i) glds16(a_src[i] + kt * BK, ba + i * 8 * (BK * 2));
+    for (int i = 0; i < APW; ++i) glds16(Ak + a_off[i], ba + i * 8 * (BK * 2));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(w_src[i] + kt * BK, bw + i * 8 * (BK * 2));
+    for (int i = 0; i < 4; ++i) glds16(Wk + w_off[i], bw + i * 8 * (BK * 2));
   };
 
   // all wave row bases are multiples of 16, so ((row>>1)&7) == ((lane>>1)&7)
@@ -395,8 +399,8 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
       for (int ni = 0; ni < 4; ++ni) {
         const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (epi_has_bias(EPI)) {
-#pragma unroll
+        if (epi_has_bias(EPI) || bias != nullptr) {   // (bias is NULL for the bias-free epilogues; keeping the
+#pragma unroll                                          //  load site in every variant keeps hipcc at <= 224 VGPRs)
           for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
         }
 #pragma unroll
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
           pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
           pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
           *reinterpret_cast<uint2*>(smem + ml * C3_ROW + nl * 2) = pk;
+          __builtin_amdgcn_sched_barrier(0);      // keep the packs in order: bounds the live temporaries (<= 224 VGPRs)
         }
       }
     }
@@ -658,8 +663,9 @@ extern "C" int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   V3D_REQUIRE(!need_bias || bias, "v3d_gemm: epilogue %d needs a bias", epilogue);
   V3D_REQUIRE(!need_res || (res && aligned16(res) && ldr % 8 == 0), "v3d_gemm: epilogue %d needs an aligned residual", epilogue);
   V3D_REQUIRE(ldo >= (epilogue == EPI_SWIGLU ? N / 2 : N), "v3d_gemm: ldo too small");
+  V3D_REQUIRE((int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31), "v3d_gemm: operand larger than 2^31 elements (4 GiB)");
   GemmArgs p;
-  p.A = A; p.W = W; p.bias = bias; p.res = res; p.out = out;
+  p.A = A; p.W = W; p.bias = need_bias ? bias : nullptr; p.res = need_res ? res : nullptr; p.out = out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldo = ldo; p.res_mod = res_mod;
   p.tiles_m = (M + BM - 1) / BM; p.tiles_n = N / BN;
   hipStream_t st = (hipStream_t)stream;
