@@ -421,31 +421,39 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, int 
       }
     }
   }
-  // merge the 16 key slots
+  // merge the 16 key slots: partial accumulators -> LDS, 16 x G rescale factors computed ONCE, then 16 FMAs per output
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (cl == 0) { sm_m[slot][g] = m[g]; sm_l[slot][g] = l[g]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sm_o[slot][g][cl * 8 + j] = acc[g][j];
+    float4* dst = reinterpret_cast<float4*>(&sm_o[slot][g][cl * 8]);
+    dst[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    dst[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
   }
   __syncthreads();
-  for (int idx = tid; idx < G * D; idx += 256) {
-    const int g = idx / D, d = idx - g * D;
+  if (tid < G) {
+    const int g = tid;
     float mm = -INFINITY;
 #pragma unroll
     for (int s_ = 0; s_ < 16; ++s_) mm = fmaxf(mm, sm_m[s_][g]);
     const float mu = mm == -INFINITY ? 0.f : mm;
-    float lt = 0.f, ot = 0.f;
+    float lt = 0.f;
 #pragma unroll
     for (int s_ = 0; s_ < 16; ++s_) {
-      const float f = exp2f(sm_m[s_][g] - mu);     // -inf slots contribute 0
+      const float f = __builtin_amdgcn_exp2f(sm_m[s_][g] - mu);      // empty slots (m = -inf) -> 0
       lt += sm_l[s_][g] * f;
-      ot += sm_o[s_][g][d] * f;
+      sm_m[s_][g] = f;                                                 // reuse as the factor table
     }
-    const int head = hk * G + g;
-    float* w = ws + ((size_t)split * p.Hq + head) * (D + 2);
-    w[d] = ot;
-    if (d == 0) { w[D] = mm; w[D + 1] = lt; }
+    float* w = ws + ((size_t)split * p.Hq + hk * G + g) * (D + 2);
+    w[D] = mm;
+    w[D + 1] = lt;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, d = idx - g * D;
+    float ot = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) ot = fmaf(sm_o[s_][g][d], sm_m[s_][g], ot);
+    ws[((size_t)split * p.Hq + hk * G + g) * (D + 2) + d] = ot;
   }
 }
 
