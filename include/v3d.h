@@ -204,8 +204,9 @@ int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const v
 int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
                        const void* sin_table, int n_pos, int pos, void* cache_row, int dtype, void* stream);
 
-/* Greedy token choice: index of the maximum of x[0..n) (lowest index on ties, as torch.argmax). */
-int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* stream);
+/* Greedy token choice: index of the maximum of x[0..n) (lowest index on ties, as torch.argmax).
+ * workspace: 1 KiB of device scratch. */
+int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ grounding (K19, K20) - */
 

@@ -125,3 +125,43 @@ def test_scene_grounding_matches_oracle(dt, tol):
     assert got.shape == (8,)
     # cosine scores in [-1, 1]: absolute tolerance
     assert (got.float().cpu() - want["scores"].float()).abs().max().item() < tol
+
+
+def test_two_scenes_in_flight_equal_serial():
+    """bench.py overlaps the decode of scene i (stream B) with the prefill of scene i+1 (stream A) using two
+    per-scene contexts; results must be identical to running the scenes one after the other."""
+    from v3d.engine import Engine, random_state_dict
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=7, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    g = torch.Generator().manual_seed(8)
+    scenes = []
+    for _ in range(4):
+        images = torch.randn(2, 3, 384, 384, generator=g).cuda()
+        coords = ((torch.rand(2, 384, 384, 3, generator=g) - 0.5) * 20).cuda()
+        t = torch.randint(0, 320, (18,), generator=g)
+        scenes.append((torch.cat([t[:7], torch.tensor([PO.IMAGE_TOKEN_INDEX]), t[7:]]), images, coords))
+    serial = [eng.generate(ids, im, wc, max_new_tokens=6).clone() for ids, im, wc in scenes]
+
+    ctxs = [eng.ctx, eng.new_context()]
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    pre_done, dec_done, out = [], [], []
+    for i, (ids, im, wc) in enumerate(scenes):
+        c = ctxs[i % 2]
+        with torch.cuda.stream(sA):
+            if i >= 2:
+                sA.wait_event(dec_done[i - 2])
+            eng.use(c)
+            feats = eng.encode_images(im)
+            vox = eng.voxel_ids(wc.to(eng.dtype))
+            x = eng.build_inputs_embeds(ids, feats, vox)
+            logits = eng.llm_forward(x, 0)
+            pre_done.append(sA.record_event())
+        with torch.cuda.stream(sB):
+            sB.wait_event(pre_done[i])
+            eng.use(c)
+            out.append(eng.decode_loop(logits, x.shape[0], 6))
+            dec_done.append(sB.record_event())
+    torch.cuda.synchronize()
+    for a, b in zip(serial, out):
+        assert torch.equal(a, b)

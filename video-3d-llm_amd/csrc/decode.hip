@@ -169,32 +169,37 @@ __global__ __launch_bounds__(256) void rope_kv_append_kernel(T* __restrict__ qkv
   }
 }
 
-// argmax over the f32-rounded logits row (greedy decoding: generation_utils' argmax over logits[:, -1]).
-// Ties resolve to the lowest index, as torch.argmax does.
+// argmax over the logits row (greedy decoding: generation_utils' argmax over logits[:, -1]).  Ties resolve to the
+// lowest index, as torch.argmax does.  Two launches: per-block candidates (16-byte loads), then one small block.
+__device__ __forceinline__ void amax_merge(float& bv, int& bi, float ov, int oi) {
+  if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+
 template <typename T>
-__global__ __launch_bounds__(1024) void argmax_kernel(const T* __restrict__ x, int n, int64_t* __restrict__ out) {
-  __shared__ float bv[16];
-  __shared__ int bi[16];
+__global__ __launch_bounds__(256) void argmax_part_kernel(const T* __restrict__ x, int n, float* __restrict__ pv, int* __restrict__ pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = to_f32(x[i]);
-    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) amax_merge(best, idx, to_f32(x[i]), i);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ov = __shfl_xor(best, off);
-    const int oi = __shfl_xor(idx, off);
-    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-  }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { bv[wave] = best; bi[wave] = idx; }
+  for (int off = 32; off > 0; off >>= 1) amax_merge(best, idx, __shfl_xor(best, off), __shfl_xor(idx, off));
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = idx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-    out[0] = idx;
+    for (int w = 1; w < 4; ++w) amax_merge(best, idx, sv[w], si[w]);
+    pv[blockIdx.x] = best;
+    pi[blockIdx.x] = idx;
   }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* __restrict__ out) {
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < nb; i += 64) amax_merge(best, idx, pv[i], pi[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax_merge(best, idx, __shfl_xor(best, off), __shfl_xor(idx, off));
+  if (threadIdx.x == 0) out[0] = idx;
 }
 
 }  // namespace v3d
@@ -248,8 +253,13 @@ extern "C" int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, 
   return check_launch("v3d_rope_kv_append");
 }
 
-extern "C" int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* stream) {
-  V3D_REQUIRE(x && out_index && n > 0, "v3d_argmax: bad arguments");
-  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(argmax_kernel<T>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const T*)x, n, out_index));
+extern "C" int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* workspace, void* stream) {
+  V3D_REQUIRE(x && out_index && workspace && n > 0, "v3d_argmax: bad arguments");
+  constexpr int NB = 128;                                    // workspace: NB floats + NB ints = 1 KiB
+  float* pv = (float*)workspace;
+  int* pi = (int*)(pv + NB);
+  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(argmax_part_kernel<T>, dim3(NB), dim3(256), 0, (hipStream_t)stream, (const T*)x, n, pv, pi));
+  if (int e = check_launch("v3d_argmax (partial)")) return e;
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pv, pi, NB, out_index);
   return check_launch("v3d_argmax");
 }

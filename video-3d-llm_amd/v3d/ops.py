@@ -341,9 +341,17 @@ def rope_kv_append(qkv_row, n_q, n_kv, hd, table, pos, cache_row):
                                    _p(cache_row), _code(qkv_row), _stream()), "v3d_rope_kv_append")
 
 
-def argmax(x, out):
-    """out: int64 device tensor of one element."""
-    check(lib().v3d_argmax(_p(x), x.numel(), _code(x), _p(out), _stream()), "v3d_argmax")
+_argmax_ws = {}
+
+
+def argmax(x, out, workspace=None):
+    """out: int64 device tensor of one element; workspace: >= 1 KiB device scratch (one per stream in flight)."""
+    if workspace is None:
+        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        workspace = _argmax_ws.get(key)
+        if workspace is None:
+            workspace = _argmax_ws[key] = torch.empty(256, dtype=torch.float32, device=x.device)
+    check(lib().v3d_argmax(_p(x), x.numel(), _code(x), _p(out), _p(workspace), _stream()), "v3d_argmax")
     return out
 
 
