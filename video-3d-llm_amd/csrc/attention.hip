@@ -24,6 +24,8 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using i16x4 = __attribute__((ext_vector_type(4))) short;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4i = __attribute__((ext_vector_type(4))) int;
+using v2i = __attribute__((ext_vector_type(2))) int;
 
 template <typename T> struct Mfma32;
 template <> struct Mfma32<bf16_t> {
@@ -107,22 +109,32 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     const int t = last_key / AT_BKV + 1;
     n_tiles = t < n_tiles_all ? t : n_tiles_all;
   }
+  // DMA source addressing: loop-invariant per-lane parts hoisted; per tile 3 VALU per 4-row piece and the
+  // SGPR-base + 32-bit VGPR-offset form of global_load_lds (K and V bases are workgroup-uniform).
   const int srow = lane >> 4;                 // row within the 4-row DMA piece
+  int st_row[4];
+  unsigned st_ch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    st_row[i] = wave * 16 + i * 4 + srow;
+    int chunk = (lane & 15) ^ kv_swz(st_row[i]);
+    chunk = chunk < CH ? chunk : CH - 1;        // D=96: the 4 pad slots are never read
+    st_ch[i] = (unsigned)chunk * 16u;
+  }
+  const unsigned ldk_b = (unsigned)p.ldk * 2u, ldv_b = (unsigned)p.ldv * 2u;
   auto stage = [&](int buf, int t) {
     char* kb = smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW;
     char* vb = kb + AT_TILE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = wave * 16 + i * 4 + srow;
-      int chunk = (lane & 15) ^ kv_swz(row);
-      chunk = chunk < CH ? chunk : CH - 1;      // D=96: the 4 pad slots are never read
-      int key = t * AT_BKV + row;
+      int key = t * AT_BKV + st_row[i];
       key = key < p.Sk ? key : p.Sk - 1;        // tail keys are masked in the scores
-      glds16a(K + (int64_t)key * p.ldk + chunk * 8, kb + i * 4 * AT_ROW);
-      glds16a(V + (int64_t)key * p.ldv + chunk * 8, vb + i * 4 * AT_ROW);
+      glds16a((const char*)K + ((unsigned)key * ldk_b + st_ch[i]), kb + i * 4 * AT_ROW);
+      glds16a((const char*)V + ((unsigned)key * ldv_b + st_ch[i]), vb + i * 4 * AT_ROW);
     }
   };
 
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   // ---- per-lane LDS offsets ----
   // K row read: key row (32kt + ql), logical chunk 2ks + h
   const int k_row_off = ql * AT_ROW;
@@ -134,6 +146,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   // rows: 16*s4 + 4h + qq (+8); (row & 15) = 4h + qq (+8)  -> swizzle independent of s4
   const int v_row0 = 4 * h + qq;
   const int v_sw0 = kv_swz(v_row0), v_sw1 = kv_swz(v_row0 + 8);
+  unsigned kaddr[KS], vaddr[2 * DT];          // fragment read addresses in ring buffer 0 (flipped every tile)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds_base + k_row_off + (((2 * ks + h) ^ k_sw) << 4);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    vaddr[2 * dt] = lds_base + AT_TILE + v_row0 * AT_ROW + v_byte + (((4 * dt + v_chunk_lo) ^ v_sw0) << 4);
+    vaddr[2 * dt + 1] = lds_base + AT_TILE + (v_row0 + 8) * AT_ROW + v_byte + (((4 * dt + v_chunk_lo) ^ v_sw1) << 4);
+  }
 
   f32x16 o[DT];
 #pragma unroll
@@ -153,20 +173,41 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     const int kv0 = t * AT_BKV;
     const bool active = !CAUSAL || kv0 <= wave_last_pos;      // wave-uniform
     if (active) {
-      const char* sK = smem + cur * 2 * AT_TILE;
-      const char* sV = sK + AT_TILE;
       // ---- S^T = K . Q^T ----
+      // K fragments by inline-asm ds_read_b128 in a 2 x 4 register ring with hand-counted lgkmcnt waits (hipcc
+      // serialises read -> wait -> MFMA for compiler-visible LDS reads and drains the next tile's LDS-DMA in front
+      // of them).  Addresses are loop-carried registers (kaddr[ks], current ring buffer); the 32-key half is an
+      // immediate offset, so a read costs no VALU.
       f32x16 s[2];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          Frag16 kf;
-          kf.u = *reinterpret_cast<const uint4*>(sK + kt * 32 * AT_ROW + k_row_off + (((2 * ks + h) ^ k_sw) << 4));
-          s[kt] = M::run(as_frag<T>(kf), as_frag<T>(qf[ks]), s[kt]);
+      {
+        v4i ka[4], kc[4];
+#define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(kaddr[ks]))
+#define V3D_KW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+#define V3D_KM(f, i, kt, ks) s[kt] = M::run(__builtin_bit_cast(typename M::frag, f[i]), as_frag<T>(qf[ks]), s[kt])
+        if constexpr (KS == 8) {
+          V3D_KR(ka[0], 0, 0); V3D_KR(ka[1], 1, 0); V3D_KR(ka[2], 2, 0); V3D_KR(ka[3], 3, 0);
+          V3D_KR(kc[0], 4, 0); V3D_KR(kc[1], 5, 0); V3D_KR(kc[2], 6, 0); V3D_KR(kc[3], 7, 0);
+          V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
+          V3D_KR(ka[0], 0, 8192); V3D_KR(ka[1], 1, 8192); V3D_KR(ka[2], 2, 8192); V3D_KR(ka[3], 3, 8192);
+          V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 0, 6); V3D_KM(kc, 3, 0, 7);
+          V3D_KR(kc[0], 4, 8192); V3D_KR(kc[1], 5, 8192); V3D_KR(kc[2], 6, 8192); V3D_KR(kc[3], 7, 8192);
+          V3D_KW(4, ka); V3D_KM(ka, 0, 1, 0); V3D_KM(ka, 1, 1, 1); V3D_KM(ka, 2, 1, 2); V3D_KM(ka, 3, 1, 3);
+          V3D_KW(0, kc); V3D_KM(kc, 0, 1, 4); V3D_KM(kc, 1, 1, 5); V3D_KM(kc, 2, 1, 6); V3D_KM(kc, 3, 1, 7);
+        } else {   // KS == 6 (head dim 96): 4 + 2 k-steps per key half
+          V3D_KR(ka[0], 0, 0); V3D_KR(ka[1], 1, 0); V3D_KR(ka[2], 2, 0); V3D_KR(ka[3], 3, 0);
+          V3D_KR(kc[0], 4, 0); V3D_KR(kc[1], 5, 0); V3D_KR(kc[2], 0, 8192); V3D_KR(kc[3], 1, 8192);
+          V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
+          V3D_KR(ka[0], 2, 8192); V3D_KR(ka[1], 3, 8192); V3D_KR(ka[2], 4, 8192); V3D_KR(ka[3], 5, 8192);
+          V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 1, 0); V3D_KM(kc, 3, 1, 1);
+          V3D_KW(0, ka); V3D_KM(ka, 0, 1, 2); V3D_KM(ka, 1, 1, 3); V3D_KM(ka, 2, 1, 4); V3D_KM(ka, 3, 1, 5);
         }
+#undef V3D_KR
+#undef V3D_KW
+#undef V3D_KM
       }
       // ---- mask + online softmax (lane = one query; keys of reg r: (r&3) + 8(r>>2) + 4h) ----
       const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > p.q_pos0 + q0 + wave * 32) || (kv0 + AT_BKV > p.Sk);
@@ -212,20 +253,47 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       }
-      // ---- O^T += V^T . P^T ----
+      // ---- O^T += V^T . P^T ----  (V^T fragments by asm ds_read_b64_tr_b16, ring of two d-tiles; the 16-key
+      //                              step is an immediate offset, vaddr[2*dt + half] the loop-carried address)
+      {
+        v2i va[8], vc[8];          // [2*s4 + half]
+#define V3D_VR(f, dt) \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[0]) : "v"(vaddr[2 * (dt)])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[1]) : "v"(vaddr[2 * (dt) + 1])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f[2]) : "v"(vaddr[2 * (dt)])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f[3]) : "v"(vaddr[2 * (dt) + 1])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[4]) : "v"(vaddr[2 * (dt)])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[5]) : "v"(vaddr[2 * (dt) + 1])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[6]) : "v"(vaddr[2 * (dt)])); \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[7]) : "v"(vaddr[2 * (dt) + 1]));
+        auto mmav = [&](const v2i* f, int dt) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const char* vrow = sV + (16 * s4 + v_row0) * AT_ROW + v_byte;
-          Frag16 vf;
-          vf.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(vrow + (((4 * dt + v_chunk_lo) ^ v_sw0) << 4)));
-          vf.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) i16x4*)(vrow + 8 * AT_ROW + (((4 * dt + v_chunk_lo) ^ v_sw1) << 4)));
-          o[dt] = M::run(as_frag<T>(vf), as_frag<T>(pf[s4]), o[dt]);
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const v4i vf = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
+            o[dt] = M::run(__builtin_bit_cast(typename M::frag, vf), as_frag<T>(pf[s4]), o[dt]);
+          }
+        };
+#define V3D_VW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory")
+        V3D_VR(va, 0) V3D_VR(vc, 1)
+        V3D_VW(8, va); mmav(va, 0); V3D_VR(va, 2)
+        if constexpr (DT == 4) {
+          V3D_VW(8, vc); mmav(vc, 1); V3D_VR(vc, 3)
+          V3D_VW(8, va); mmav(va, 2);
+          V3D_VW(0, vc); mmav(vc, 3);
+        } else {
+          V3D_VW(8, vc); mmav(vc, 1);
+          V3D_VW(0, va); mmav(va, 2);
         }
+#undef V3D_VR
+#undef V3D_VW
       }
+    }
+    {   // flip the loop-carried fragment addresses to the other ring buffer (one VALU add each)
+      const int delta = cur ? -2 * AT_TILE : 2 * AT_TILE;
+#pragma unroll
+      for (int i = 0; i < KS; ++i) kaddr[i] += delta;
+#pragma unroll
+      for (int i = 0; i < 2 * DT; ++i) vaddr[i] += delta;
     }
     __syncthreads();   // next tile landed; everyone is done with `cur`
   }
