@@ -24,7 +24,7 @@ def bare_processor(**kw):
 
 def test_surface_names_exist():
     import llava.mm_utils as mm
-    from llava.constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+    from v3d.token_ids import IGNORE_INDEX, IMAGE_TOKEN_INDEX
     from llava.model.language_model.llava_qwen import LlavaQwenForCausalLM  # noqa: F401
     from llava.model.llava_arch import LlavaMetaForCausalLM
     from llava.model.position_encoding import PositionEmbeddingSine3D  # noqa: F401

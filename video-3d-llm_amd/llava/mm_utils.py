@@ -3,7 +3,7 @@ Pure host-side string/id helpers - nothing to accelerate, kept so the drivers' i
 import torch
 from transformers import StoppingCriteria
 
-from llava.constants import IMAGE_TOKEN_INDEX
+from v3d.token_ids import IMAGE_TOKEN_INDEX
 
 
 def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None):
