@@ -57,3 +57,33 @@ def test_arch_mixin_methods(golden):
     avg = m.average_coordinate_in_patch(x16)
     assert np.array_equal(avg.cpu().numpy(), gc["avg_f16"])
     assert np.array_equal(m.discrete_coords(avg).cpu().numpy(), gc["vox_f16"])
+
+
+def test_llava_qwen_generate_and_grounding_call_contract():
+    """The overlay's LlavaQwenForCausalLM keeps the 3-D eval drivers' call shapes
+    (model_scanqa.py:173-185, model_scanrefer.py:165-173) on a tiny random-init model."""
+    from llava.model.language_model.llava_qwen import LlavaQwenForCausalLM
+    from v3d.engine import EngineConfig, LlmConfig, VitConfig, random_state_dict
+    cfg = EngineConfig(vit=VitConfig(hidden=144, inter=272, layers=1, heads=2),
+                       llm=LlmConfig(hidden=256, inter=384, layers=1, heads=2, kv_heads=1, vocab=320, max_pos=1024))
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=9, std=0.05, ground_head=True)
+    model = LlavaQwenForCausalLM(cfg, sd, dtype=torch.float16, device="cuda")
+    g = torch.Generator().manual_seed(10)
+    images = torch.randn(1, 2, 3, 384, 384, generator=g).half().cuda()
+    video_dict = {"world_coords": ((torch.rand(1, 2, 384, 384, 3, generator=g) - 0.5) * 10).half().cuda(),
+                  "objects": torch.cat([torch.zeros(5, 3), torch.ones(5, 3) * 3], 1)[None].half().cuda(),
+                  "box_input": torch.Tensor([])}
+    t = torch.randint(0, 300, (1, 16), generator=g)
+    input_ids = torch.cat([t[:, :6], torch.tensor([[-200]]), t[:, 6:]], 1).cuda()
+    out = model.generate(input_ids, images=images, modalities="video", do_sample=False, num_beams=1, max_new_tokens=5,
+                         use_cache=True, video_dict=video_dict)
+    assert out.shape == (1, 5) and out.dtype == torch.int64 and int(out.max()) < 320
+    # grounding: labels mark the <ground> token position (config.ground_token_ids)
+    model.config.ground_token_ids = [310, 311]
+    labels = torch.full_like(input_ids, -100)
+    labels[0, 12] = 310
+    _, scores = model(input_ids, images=images, modalities="video", video_dict=video_dict, labels=labels,
+                      use_object_proposals=True, box_labels=None)
+    assert scores.shape == (6,) and torch.isfinite(scores.float()).all() and scores.float().abs().max() <= 1.001
+    with pytest.raises(NotImplementedError):
+        model.generate(input_ids, images=images, video_dict=video_dict, do_sample=True)
