@@ -143,6 +143,18 @@ int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void*
              int64_t ldr, int res_mod, void* out, int64_t ldo, int M, int N, int K, int dtype, int epilogue,
              void* stream);
 
+/* FP8 (OCP e4m3) variant of the LLM linears - BASELINE configs[3]; not part of the reference (tolerance is
+ * re-stated in tests/test_gpu_fp8.py).  y[m,n] = sa[m] * sw[n] * sum_k qa[m,k] qw[n,k] with per-row scales.
+ * v3d_quantize_fp8_rows: x [rows, cols] (f16/bf16) -> q [rows, cols] e4m3 bytes (row stride ldq) + scale[rows] f32,
+ *   scale = amax|row| / 448.  Used for activations per call and for weights once at load.
+ * v3d_gemm_fp8: A [M,K] e4m3 (lda bytes), W [N,K] e4m3; N % 256 == 0, K % 128 == 0; epilogues NONE / BIAS / RES /
+ *   SWIGLU (same codes and row interleave as v3d_gemm); output in out_dtype (f16 / bf16). */
+int v3d_quantize_fp8_rows(const void* x, int64_t ldx, int64_t rows, int cols, int dtype, void* q, int64_t ldq,
+                          float* scale, void* stream);
+int v3d_gemm_fp8(const void* A, int64_t lda, const float* scale_a, const void* W, int64_t ldw, const float* scale_w,
+                 const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
+                 int out_dtype, int epilogue, void* stream);
+
 /* ------------------------------------------------------------------ norms / rotary ------ */
 
 /* K13  Qwen2RMSNorm, modeling_qwen2.py:85-90: out = weight * T(x * rsqrt(mean(x^2) + eps)), f32 inside. */

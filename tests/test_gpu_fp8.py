@@ -1,0 +1,115 @@
+"""FP8 (OCP e4m3) LLM linears - BASELINE.json configs[3].  Not a reference code path (the reference runs bf16 only,
+scripts/3d/train/train_multi.sh:57-58), so the tolerance is re-stated here instead of being pinned by a golden:
+
+  * v3d_quantize_fp8_rows is checked BIT-EXACT against torch's float8_e4m3fn cast of x * (1 / scale), scale = amax/448;
+  * v3d_gemm_fp8 is checked against an f64 matmul of the SAME dequantised operands: the only error left is f32
+    accumulation + one rounding to the output type -> |err| <= 2^-8 |ref| + 2^-10 rms(ref)  (bf16 output);
+  * against the bf16 v3d_gemm of the unquantised operands the relative Frobenius error must stay below 6 %
+    (e4m3 carries 3 mantissa bits: <= 2^-4 relative error per operand, ~3.6 % rms for both operands).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from v3d import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def _deq(q, s):
+    return q.view(torch.float8_e4m3fn).to(torch.float64) * s.to(torch.float64)[:, None]
+
+
+def _rand(m, k, dtype, seed, outlier=True):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(m, k, generator=g)
+    if outlier:
+        x[:, 3] *= 20.0          # a heavy channel, as LLM activations have
+    return x.to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols", [(1, 128), (5, 3584), (300, 18944), (6794, 3584)])
+def test_quantize_rows_bit_exact(dtype, rows, cols):
+    x = _rand(rows, cols, dtype, rows * 7 + cols)
+    x[rows // 2] = 0                                           # an all-zero row keeps scale 1
+    q, s = ops.quantize_fp8_rows(x)
+    # IEEE f32 divisions on the host (torch's GPU "tensor / scalar" multiplies by a rounded reciprocal instead)
+    amax = x.float().abs().amax(1).cpu().numpy()
+    s_ref = np.where(amax > 0, amax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    assert np.array_equal(s.cpu().numpy(), s_ref)
+    inv = (np.float32(1.0) / s_ref).astype(np.float32)
+    scaled = torch.from_numpy(x.float().cpu().numpy() * inv[:, None])
+    q_ref = scaled.to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q.cpu(), q_ref)
+    assert int(q[rows // 2].max()) == 0
+
+
+CASES = [
+    # M, N, K, epilogue
+    (256, 256, 128, "none"),
+    (1, 256, 256, "none"),
+    (300, 512, 3584, "bias"),
+    (777, 3584, 3584, "res"),
+    (1000, 1024, 18944, "res"),
+    (513, 2048, 3584, "swiglu"),
+    (6794, 4608, 3584, "bias"),
+]
+
+
+@pytest.mark.parametrize("M,N,K,epi", CASES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_fp8_vs_dequantised_f64(M, N, K, epi, dtype):
+    a = _rand(M, K, dtype, 11 + M)
+    w = (_rand(N, K, dtype, 13 + N, outlier=False).float() * K ** -0.5).to(dtype)
+    qa, sa = ops.quantize_fp8_rows(a)
+    qw, sw = ops.quantize_fp8_rows(w)
+    ref = _deq(qa, sa) @ _deq(qw, sw).T
+    kw = {}
+    if epi == "bias":
+        bias = _rand(1, N, dtype, 5, outlier=False)[0]
+        kw = dict(bias=bias, epilogue=ops.EPI_BIAS)
+        ref = ref + bias.double()
+    elif epi == "res":
+        res = _rand(M, N, dtype, 6, outlier=False)
+        kw = dict(res=res, epilogue=ops.EPI_RES)
+        # the kernel rounds the product to the output type, then adds the residual (as v3d_gemm's RES epilogue)
+        ref = ref.to(dtype).double() + res.double()
+    elif epi == "swiglu":
+        kw = dict(epilogue=ops.EPI_SWIGLU)
+        r = ref.to(dtype).float().view(M, N // 128, 2, 64)
+        g, u = r[:, :, 0], r[:, :, 1]
+        ref = (torch.nn.functional.silu(g).to(dtype).float() * u).reshape(M, N // 2).double()
+    out = ops.gemm_fp8(qa, sa, qw, sw, dtype, **kw)
+    assert out.shape == ref.shape
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # "res"/"swiglu" round an intermediate to the output type first: one more half-ulp of that intermediate
+    slack = 3.0 if epi in ("res", "swiglu") else 1.0
+    rms = ref.pow(2).mean().sqrt()
+    err = (out.double() - ref).abs()
+    bound = slack * eps * ref.abs() + slack * 4 * eps * rms * (1.0 if epi != "none" else 0.25)
+    assert bool((err <= bound).all()), f"max excess {(err - bound).max().item():.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 4608, 3584), (2000, 3584, 18944)])
+def test_gemm_fp8_close_to_bf16(M, N, K):
+    dtype = torch.bfloat16
+    a = _rand(M, K, dtype, 3)
+    w = (_rand(N, K, dtype, 4, outlier=False).float() * K ** -0.5).to(dtype)
+    full = ops.gemm(a, w).float()
+    qa, sa = ops.quantize_fp8_rows(a)
+    qw, sw = ops.quantize_fp8_rows(w)
+    out = ops.gemm_fp8(qa, sa, qw, sw, dtype).float()
+    rel = (out - full).norm() / full.norm()
+    assert rel < 0.06, rel.item()
+
+
+def test_gemm_fp8_rejects_bad_shapes():
+    qa = torch.zeros(4, 128, dtype=torch.uint8, device=DEV)
+    sa = torch.ones(4, device=DEV)
+    qw = torch.zeros(128, 128, dtype=torch.uint8, device=DEV)     # N not a multiple of 256
+    sw = torch.ones(128, device=DEV)
+    with pytest.raises(Exception, match="multiple of 256"):
+        ops.gemm_fp8(qa, sa, qw, sw, torch.bfloat16)

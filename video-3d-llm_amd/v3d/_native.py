@@ -46,6 +46,8 @@ SIGNATURES = {
     "v3d_visual_tokens": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "v3d_embed_gather": (c_i, [c_p, c_l, c_i, c_p, c_l, c_p, c_l, c_i, c_p]),
     "v3d_gemm": (c_i, [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_quantize_fp8_rows": (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_p, c_p]),
+    "v3d_gemm_fp8": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_p]),
     "v3d_rmsnorm": (c_i, [c_p, c_l, c_p, c_p, c_l, c_l, c_i, c_f, c_i, c_p]),
     "v3d_layernorm": (c_i, [c_p, c_l, c_p, c_p, c_p, c_l, c_l, c_i, c_f, c_i, c_p]),
     "v3d_rope_table_build": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p]),

@@ -244,6 +244,34 @@ def interleave_gate_up(wg, wu):
     return torch.stack([wg.view(I // 64, 64, K), wu.view(I // 64, 64, K)], 1).reshape(2 * I, K).contiguous()
 
 
+# ------------------------------------------------------------------------------ fp8 (configs[3])
+
+
+def quantize_fp8_rows(x, q=None, scale=None):
+    """x [rows, cols] f16/bf16 -> (q uint8 e4m3 [rows, cols], scale f32 [rows]); per-row amax/448 scales."""
+    rows, cols = x.shape
+    if q is None:
+        q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib().v3d_quantize_fp8_rows(_p(x), x.stride(0), rows, cols, _code(x), _p(q), q.stride(0), _p(scale), _stream()),
+          "v3d_quantize_fp8_rows")
+    return q, scale
+
+
+def gemm_fp8(qa, sa, qw, sw, out_dtype, bias=None, res=None, epilogue=EPI_NONE, out=None):
+    """out = epilogue( (qa @ qw.T) * sa[:,None] * sw[None,:] ); qa [M,K], qw [N,K] e4m3 bytes."""
+    M, K = qa.shape
+    N = qw.shape[0]
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=out_dtype, device=qa.device)
+    check(lib().v3d_gemm_fp8(_p(qa), qa.stride(0), _p(sa), _p(qw), qw.stride(0), _p(sw), _p(bias), _p(res),
+                             res.stride(0) if res is not None else 0, _p(out), out.stride(0), M, N, K, _DT[out_dtype],
+                             epilogue, _stream()), "v3d_gemm_fp8")
+    return out
+
+
 # ------------------------------------------------------------------------------ norms / rotary
 
 
