@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one scene at a time (no decode/prefill overlap)")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[3]: e4m3 linears in the Qwen2 prefill; the headline line becomes that run")
+    ap.add_argument("--no-fp8-extra", action="store_true", help="skip the extra configs[3] measurement appended to the default N=1 line")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,7 +194,8 @@ def main():
     from v3d.engine import Engine, EngineConfig, random_state_dict
     dtype = torch.bfloat16
     cfg = EngineConfig()
-    eng = Engine(cfg, random_state_dict(cfg, dtype, dev, seed=0), dtype=dtype, device=dev, max_frames=FRAMES)
+    sd = random_state_dict(cfg, dtype, dev, seed=0)
+    eng = Engine(cfg, sd, dtype=dtype, device=dev, max_frames=FRAMES, llm_fp8=a.fp8)
     inp = synth_inputs(dev, dtype, seed=100 + rank)
     ids = inp["input_ids"]
     inp["ids_pre"], inp["ids_post"] = ids[:TEXT_PRE].to(dev), ids[TEXT_PRE + 1:].to(dev)
@@ -206,28 +209,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctxs = [eng.ctx, eng.new_context()]
     streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-    for w in range(a.warmup):
-        eng.use(ctxs[w % 2])
-        scene_step(eng, ops, inp, null)
-    barrier()
-    t0 = time.perf_counter()
-    if a.no_overlap:
-        eng.use(ctxs[0])
-        toks = [scene_step(eng, ops, inp, stamps) for _ in range(a.steps)]
-    else:
-        toks = run_pipelined(eng, ops, inp, stamps, null, a.steps, ctxs, streams)
-    answers = torch.stack(toks)
-    if world > 1:   # eval collation: ONE gather of the generated ids to rank 0 (replaces Ray + file lock)
-        bucket = [torch.empty_like(answers) for _ in range(world)] if rank == 0 else None
-        dist.gather(answers, bucket, dst=0)
-    barrier()
-    dt_s = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_s = tt.item()
+
+    def measure(eng, stamps):
+        """W untimed warm-up scenes, then EXACTLY `steps` scenes between barrier + synchronize; max over ranks."""
+        ctxs = [eng.ctx, eng.new_context()]
+        for w in range(a.warmup):
+            eng.use(ctxs[w % 2])
+            scene_step(eng, ops, inp, null)
+        barrier()
+        t0 = time.perf_counter()
+        if a.no_overlap:
+            eng.use(ctxs[0])
+            toks = [scene_step(eng, ops, inp, stamps) for _ in range(a.steps)]
+        else:
+            toks = run_pipelined(eng, ops, inp, stamps, null, a.steps, ctxs, streams)
+        answers = torch.stack(toks)
+        if world > 1:   # eval collation: ONE gather of the generated ids to rank 0 (replaces Ray + file lock)
+            bucket = [torch.empty_like(answers) for _ in range(world)] if rank == 0 else None
+            dist.gather(answers, bucket, dst=0)
+        barrier()
+        dt_s = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_s = tt.item()
+        return dt_s
+
+    dt_s = measure(eng, stamps)
+    fp8_extra = None
+    if world == 1 and not a.fp8 and not a.no_fp8_extra:
+        del eng
+        eng8 = Engine(cfg, sd, dtype=dtype, device=dev, max_frames=FRAMES, llm_fp8=True)
+        st8 = {"pe": Stamp(), "gemm": Stamp(), "attn": Stamp()}
+        t8 = measure(eng8, st8)
+        g8 = st8["gemm"].mean_us()
+        fp8_extra = {"what": "BASELINE configs[3]: same scene step with e4m3 (per-row scaled) linears in the Qwen2 prefill; "
+                             "ViT, attention, norms, residual stream and decode stay bf16",
+                     "value": a.steps / t8, "unit": "scenes/s", "ms_per_step": t8 / a.steps * 1e3,
+                     "gate_up_gemm_us": g8, "gate_up_gemm_tflops": 2.0 * (TEXT_PRE + FRAMES * 210 + TEXT_POST) * 37888 * 3584 / g8 / 1e6,
+                     "mfma_peak_tflops": 5000.0}
+        del eng8
 
     if rank == 0:
         S = TEXT_PRE + FRAMES * 210 + TEXT_POST
@@ -235,6 +257,7 @@ def main():
         pe_bytes = FRAMES * 729 * 3584 * 2 + FRAMES * 210 * 3584 * 2          # feat read + token rows written (SURVEY 8d, K7+K5-K6+K8)
         gemm_us = stamps["gemm"].mean_us()
         gemm_flops = 2.0 * S * 37888 * 3584                                   # the gate/up GEMM stamped in llm_forward
+        gemm_peak = 5000.0 if a.fp8 else 2500.0
         attn_us = stamps["attn"].mean_us()
         attn_flops = 2.0 * S * S * 128 * 28                                   # causal: half of 4*S^2*d*H
         traffic = None
@@ -244,22 +267,24 @@ def main():
         line = {
             "metric": "scenes/sec ScanQA @32 frames", "value": world * a.steps / dt_s, "unit": "scenes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_s / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ScanQA val, uniform 32 frames, bf16, 1xMI355X per rank: 32x(480x640 u16 depth + 384x384 RGB) -> "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": "ScanQA val, uniform 32 frames, %s, 1xMI355X per rank: 32x(480x640 u16 depth + 384x384 RGB) -> "
                                    "SigLIP-so400m(26L) + mlp2x_gelu + 3D-PE fusion -> Qwen2-7B prefill S=%d + %d greedy decode steps; "
-                                   "random-init weights at true widths" % (S, DECODE_STEPS),
+                                   "random-init weights at true widths" % ("fp8 LLM prefill linears (configs[3])" if a.fp8 else "bf16", S, DECODE_STEPS),
                        "frames": FRAMES, "seq_len": S, "decode_steps": DECODE_STEPS, "parallelism": "scene-dp%d" % world,
                        "scenes_in_flight_per_gpu": 1 if a.no_overlap else 2},
             "roofline": {"kernel": "visual_tokens_kernel (bilinear pool + 3D-PE add + newline, K5-K8)", "bound": "hbm",
                          "achieved": pe_bytes / pe_us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": pe_bytes / pe_us / 1e3 / 8000.0,
                          "traffic": traffic, "us_per_launch": pe_us, "algorithmic_bytes": pe_bytes},
             "roofline_dominant": {"kernel": "gemm_kernel (Qwen2 gate/up + SwiGLU, M=%d N=37888 K=3584)" % S, "bound": "mfma",
-                                  "achieved": gemm_flops / gemm_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
-                                  "frac": gemm_flops / gemm_us / 1e6 / 2500.0, "traffic": None, "us_per_launch": gemm_us},
+                                  "achieved": gemm_flops / gemm_us / 1e6, "peak": gemm_peak, "unit": "TFLOP/s",
+                                  "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": None, "us_per_launch": gemm_us},
             "roofline_attention": {"kernel": "attn_prefill_kernel (causal GQA, S=%d, 28q/4kv, hd128)" % S, "bound": "mfma",
                                    "achieved": attn_flops / attn_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
                                    "frac": attn_flops / attn_us / 1e6 / 2500.0, "traffic": None, "us_per_launch": attn_us},
         }
+        if fp8_extra is not None:
+            line["fp8_config3"] = fp8_extra
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(line))

@@ -137,8 +137,11 @@ class SceneContext:
 class Engine:
     VIT_DP = 96      # SigLIP head dim 72, zero padded to the attention kernel's 96
 
-    def __init__(self, cfg: EngineConfig, state_dict, dtype=torch.bfloat16, device="cuda", max_frames=32):
-        self.cfg, self.dtype, self.device = cfg, dtype, device
+    def __init__(self, cfg: EngineConfig, state_dict, dtype=torch.bfloat16, device="cuda", max_frames=32, llm_fp8=False):
+        """llm_fp8: run the four decoder linears of the PREFILL in OCP e4m3 (weights quantised once per output row,
+        activations per token row per call; BASELINE configs[3]).  The ViT, attention, norms, the residual stream and
+        the single-token decode stay in `dtype`."""
+        self.cfg, self.dtype, self.device, self.llm_fp8 = cfg, dtype, device, bool(llm_fp8)
         v, l = cfg.vit, cfg.llm
         self.hd = l.hidden // l.heads
         if self.hd != 128:
@@ -148,6 +151,8 @@ class Engine:
             raise V3DError("the SigLIP path needs head_dim 72")
         if l.hidden % 128 or l.inter % 64:
             raise V3DError("LLM hidden must be a multiple of 128 and intermediate of 64")
+        if self.llm_fp8 and (l.hidden % 256 or l.inter % 128):
+            raise V3DError("llm_fp8 needs LLM hidden to be a multiple of 256 and intermediate of 128")
         sd = {k: t.to(device=device, dtype=dtype) for k, t in state_dict.items()}
         self._prep_vit(sd)
         self._prep_llm(sd)
@@ -207,13 +212,17 @@ class Engine:
                               sd[p + "self_attn.v_proj.weight"]], 0)
             bqkv = torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"],
                               sd[p + "self_attn.v_proj.bias"]], 0)
-            nq = _up(wqkv.shape[0], 128)
+            nq = _up(wqkv.shape[0], 256 if self.llm_fp8 else 128)
             self.l_layers.append(dict(
                 ln1=sd[p + "input_layernorm.weight"].contiguous(), ln2=sd[p + "post_attention_layernorm.weight"].contiguous(),
                 wqkv=_pad2(wqkv, nq, l.hidden), bqkv=_pad1(bqkv, nq),
                 wo=sd[p + "self_attn.o_proj.weight"].contiguous(),
                 wgu=ops.interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]),
                 wd=sd[p + "mlp.down_proj.weight"].contiguous()))
+            if self.llm_fp8:
+                L = self.l_layers[-1]
+                for k in ("wqkv", "wo", "wgu", "wd"):
+                    L[k + "8"] = ops.quantize_fp8_rows(L[k])
         self.l_nqkv = self.l_layers[0]["wqkv"].shape[0] if self.l_layers else 0
         self.l_norm = sd["model.norm.weight"].contiguous()
         self.l_head = _pad2(sd["lm_head.weight"], _up(l.vocab, 128), l.hidden)
@@ -231,6 +240,9 @@ class Engine:
         S = l.max_pos
         self.l_h = z(S, l.hidden)                      # prefill scratch (one prefill runs at a time)
         self.l_qkv, self.l_att, self.l_act = z(S, self.l_nqkv), z(S, l.hidden), z(S, l.inter)
+        if self.llm_fp8:                               # e4m3 image + row scales of the current GEMM's activations
+            self.l_q8 = torch.zeros((S, max(l.hidden, l.inter)), dtype=torch.uint8, device=dev)
+            self.l_s8 = torch.zeros(S, dtype=torch.float32, device=dev)
         self.ctx = self.new_context()                  # per-scene state (sequence buffer, KV cache, decode rows)
 
     def new_context(self):
@@ -343,9 +355,20 @@ class Engine:
         h, qkv, att, act = self.l_h[:S], self.l_qkv[:S], self.l_att[:S], self.l_act[:S]
         kvw = nkv * hd
         scale = 1.0 / math.sqrt(hd)
+        if self.llm_fp8 and S > 8:
+            s8 = self.l_s8[:S]
+
+            def lin(a, L, key, out, **kw):           # quantise the activation rows, then the e4m3 GEMM
+                q8 = self.l_q8[:S, : a.shape[1]]
+                ops.quantize_fp8_rows(a, q8, s8)
+                qw, sw = L[key + "8"]
+                return ops.gemm_fp8(q8, s8, qw, sw, self.dtype, out=out, **kw)
+        else:
+            def lin(a, L, key, out, **kw):
+                return ops.gemm(a, L[key], out=out, **kw)
         for i, L in enumerate(self.l_layers):
             ops.rmsnorm(x, L["ln1"], l.eps, out=h)
-            ops.gemm(h, L["wqkv"], bias=L["bqkv"], epilogue=ops.EPI_BIAS, out=qkv)
+            lin(h, L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.EPI_BIAS)
             ops.rope_apply(qkv, nh + nkv, hd, self.rope, pos0=pos0)
             cache = self.kv[i]
             ops.copy_rows(qkv[:, nh * hd:], cache[pos0: pos0 + S], cols=2 * kvw)
@@ -357,14 +380,14 @@ class Engine:
                 stamps["attn"](attn)      # bench: HIP events around one layer's launch
             else:
                 attn()
-            ops.gemm(att, L["wo"], res=x, epilogue=ops.EPI_RES, out=x)
+            lin(att, L, "wo", x, res=x, epilogue=ops.EPI_RES)
             ops.rmsnorm(x, L["ln2"], l.eps, out=h)
-            gu = lambda: ops.gemm(h, L["wgu"], epilogue=ops.EPI_SWIGLU, out=act)
+            gu = lambda: lin(h, L, "wgu", act, epilogue=ops.EPI_SWIGLU)
             if stamps is not None and i == 1:
                 stamps["gemm"](gu)
             else:
                 gu()
-            ops.gemm(act, L["wd"], res=x, epilogue=ops.EPI_RES, out=x)
+            lin(act, L, "wd", x, res=x, epilogue=ops.EPI_RES)
         self.kv_len = pos0 + S
         return self._head(x[S - 1:])
 
