@@ -46,6 +46,7 @@ union Frag16 {   // 16 bytes viewed as MFMA fragment / raw words
   bf16x8 b;
   f16x8 h;
   i16x4 s[2];
+  v4i i4;
 };
 template <typename T> __device__ __forceinline__ typename Mfma32<T>::frag as_frag(const Frag16& f);
 template <> __device__ __forceinline__ bf16x8 as_frag<bf16_t>(const Frag16& f) { return f.b; }
@@ -66,6 +67,11 @@ struct AttnArgs {
   float scale_log2;                  // softmax scale * log2(e)
 };
 
+#ifdef V3D_ATTN_PROF   // tools/probes/attn_prof.hip only: per-wave cycle split of the tile loop (never in the product build)
+__device__ unsigned long long g_attn_prof[8 * 64];
+__device__ unsigned long long g_attn_blocks[4 * 4096];   // per workgroup: realtime start, end, shader-clock delta, HW_ID
+#endif
+
 __device__ __forceinline__ int kv_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
@@ -73,9 +79,18 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+template <int N> struct IntC { static constexpr int value = N; };
+
+// Softmax bookkeeping is in the log2 domain on PRE-SCALED scores: Q is multiplied by scale*log2(e) once when it is
+// loaded, and the S^T accumulators START at -m_run (the lane's running maximum), so a score leaves the MFMA chain as
+// s' = q.k*c - m_run and p = exp2(s') needs no subtract.  The maximum is only RAISED when some s' exceeds
+// AT_RAISE (p <= 2^AT_RAISE stays far inside f32 / 16-bit range) - after the first tiles that is rare, so the common
+// tile costs one max3 chain, 32 v_exp, 32 adds and 16 packs per lane and no cross-lane traffic at all.
+constexpr float AT_RAISE = 8.0f;
+
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 1 KiB: fragment addresses are formed by XOR
   using M = Mfma32<T>;
   constexpr int KS = D / 16;       // k-steps of QK^T
   constexpr int DT = D / 32;       // 32-wide d tiles of O^T
@@ -84,8 +99,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, h = lane >> 5;
-  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;   // heaviest (last) query tiles first
-  const int head = blockIdx.y, b = blockIdx.z;
+  // Grid = (head, query tile, batch): workgroups are dispatched x-fastest, so ALL heads' heaviest (last, causal)
+  // query tiles start first and the lightest ones fill the tail (longest-processing-time order; with the query
+  // tile fastest the last heads' 107-tile workgroups started late and left 40 % of the launch half empty).
+  const int qt = (int)gridDim.y - 1 - (int)blockIdx.y;
+  const int head = blockIdx.x, b = blockIdx.z;
   const int hk = head / p.group;
   const int q0 = qt * AT_BQ;
 
@@ -93,210 +111,284 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   const uint16_t* K = (const uint16_t*)p.k + b * p.bsk + (int64_t)hk * p.hsk;
   const uint16_t* V = (const uint16_t*)p.v + b * p.bsk + (int64_t)hk * p.hsk;
 
-  // ---- Q fragments: B operand, lane (q, h) holds Q[q][16ks + 8h .. +8) ----
-  int qi = q0 + wave * 32 + ql;
+  // ---- Q fragments: B operand, lane (q, h) holds c * Q[q][16ks + 8h .. +8) ----
+  const int qi = q0 + wave * 32 + ql;
   const int qi_ld = qi < p.Sq ? qi : p.Sq - 1;
   Frag16 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-    qf[ks].u = *reinterpret_cast<const uint4*>(Q + (int64_t)qi_ld * p.ldq + ks * 16 + h * 8);
-
-  // ---- KV staging: one DMA = 4 rows x 256 B; wave w stages rows [16w, 16w+16) of K and of V ----
-  const int n_tiles_all = (p.Sk + AT_BKV - 1) / AT_BKV;
-  int n_tiles = n_tiles_all;
-  if (CAUSAL) {
-    const int last_key = p.q_pos0 + (q0 + AT_BQ - 1 < p.Sq ? q0 + AT_BQ - 1 : p.Sq - 1);
-    const int t = last_key / AT_BKV + 1;
-    n_tiles = t < n_tiles_all ? t : n_tiles_all;
-  }
-  // DMA source addressing: loop-invariant per-lane parts hoisted; per tile 3 VALU per 4-row piece and the
-  // SGPR-base + 32-bit VGPR-offset form of global_load_lds (K and V bases are workgroup-uniform).
-  const int srow = lane >> 4;                 // row within the 4-row DMA piece
-  int st_row[4];
-  unsigned st_ch[4];
+  for (int ks = 0; ks < KS; ++ks) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(Q + (int64_t)qi_ld * p.ldq + ks * 16 + h * 8);
+    float f[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    st_row[i] = wave * 16 + i * 4 + srow;
-    int chunk = (lane & 15) ^ kv_swz(st_row[i]);
-    chunk = chunk < CH ? chunk : CH - 1;        // D=96: the 4 pad slots are never read
-    st_ch[i] = (unsigned)chunk * 16u;
+    for (int j = 0; j < 8; ++j) f[j] = vec_get<T>(raw, j) * p.scale_log2;
+    qf[ks].u = vec_pack<T>(f);
   }
+
+  // ---- tile counts ----
+  const int n_tiles_all = (p.Sk + AT_BKV - 1) / AT_BKV;
+  int n_tiles = n_tiles_all;           // tiles the workgroup stages
+  int n_wave = n_tiles_all;            // tiles THIS wave computes (a causal wave stops at its last query's tile)
+  if (CAUSAL) {
+    const int last_q = q0 + AT_BQ - 1 < p.Sq ? q0 + AT_BQ - 1 : p.Sq - 1;
+    const int t = (p.q_pos0 + last_q) / AT_BKV + 1;
+    n_tiles = t < n_tiles_all ? t : n_tiles_all;
+    const int tw = (p.q_pos0 + q0 + wave * 32 + 31) / AT_BKV + 1;
+    n_wave = tw < n_tiles ? tw : n_tiles;
+  }
+
+  // ---- KV staging by LDS-DMA: one instruction = 4 rows x 256 B; wave w stages rows [16w, 16w+16) of a tile.
+  //      LDS: buffer j&1 of tile j = { K image 16 KiB, V image 16 KiB }.
+  //      Row (16w + 4i + srow) of piece i has swizzle kv_swz = (srow << 2) | i, so its source chunk is chunk0 ^ i:
+  //      two registers describe all four pieces.
+  const int srow = lane >> 4;                 // row within the 4-row DMA piece
+  const int st_row0 = wave * 16 + srow;
+  const int st_chunk0 = (lane & 15) ^ (srow << 2);
   const unsigned ldk_b = (unsigned)p.ldk * 2u, ldv_b = (unsigned)p.ldv * 2u;
-  auto stage = [&](int buf, int t) {
-    char* kb = smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW;
-    char* vb = kb + AT_TILE;
+  auto stage = [&](const uint16_t* src, unsigned ld_b, char* dst, int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int key = t * AT_BKV + st_row[i];
+      int key = t * AT_BKV + st_row0 + 4 * i;
       key = key < p.Sk ? key : p.Sk - 1;        // tail keys are masked in the scores
-      glds16a((const char*)K + ((unsigned)key * ldk_b + st_ch[i]), kb + i * 4 * AT_ROW);
-      glds16a((const char*)V + ((unsigned)key * ldv_b + st_ch[i]), vb + i * 4 * AT_ROW);
+      int chunk = st_chunk0 ^ i;
+      if (CH < 16) chunk = chunk < CH ? chunk : CH - 1;        // D=96: the 4 pad slots are never read
+      glds16a((const char*)src + ((unsigned)key * ld_b + (unsigned)chunk * 16u), dst + i * 4 * AT_ROW);
     }
   };
+  auto stage_k = [&](int buf, int t) { stage(K, ldk_b, smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW, t); };
+  auto stage_v = [&](int buf, int t) { stage(V, ldv_b, smem + buf * 2 * AT_TILE + AT_TILE + (wave * 16) * AT_ROW, t); };
 
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  // ---- per-lane LDS offsets ----
+  // ---- per-lane LDS read addresses (buffer 0; buffer 1 and the key sub-blocks are immediate offsets) ----
   // K row read: key row (32kt + ql), logical chunk 2ks + h
-  const int k_row_off = ql * AT_ROW;
   const int k_sw = kv_swz(ql);                 // kv_swz(32kt + ql) == kv_swz(ql)
   // V transposed read: lane = 16g + 4qq + pp supplies row (base + qq), 4 columns at d = 32dt + 16(g&1) + 4pp
   const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
   const int v_chunk_lo = 2 * (g & 1) + (pp >> 1);          // + 4dt
   const int v_byte = 8 * (pp & 1);
-  // rows: 16*s4 + 4h + qq (+8); (row & 15) = 4h + qq (+8)  -> swizzle independent of s4
-  const int v_row0 = 4 * h + qq;
+  const int v_row0 = 4 * h + qq;               // rows 16*s4 + 4h + qq (+8): the swizzle does not depend on s4
   const int v_sw0 = kv_swz(v_row0), v_sw1 = kv_swz(v_row0 + 8);
-  unsigned kaddr[KS], vaddr[2 * DT];          // fragment read addresses in ring buffer 0 (flipped every tile)
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kaddr[ks] = lds_base + k_row_off + (((2 * ks + h) ^ k_sw) << 4);
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-    vaddr[2 * dt] = lds_base + AT_TILE + v_row0 * AT_ROW + v_byte + (((4 * dt + v_chunk_lo) ^ v_sw0) << 4);
-    vaddr[2 * dt + 1] = lds_base + AT_TILE + (v_row0 + 8) * AT_ROW + v_byte + (((4 * dt + v_chunk_lo) ^ v_sw1) << 4);
-  }
+  // chunk (2ks + h) ^ k_sw = ((h ^ k_sw) ^ 2ks): the k-step toggles address bits 5..7, the d tile bits 6..7 of V's
+  const unsigned kaddr0_ = lds_base + ql * AT_ROW + ((h ^ k_sw) << 4);
+  const unsigned vaddr0_ = lds_base + AT_TILE + v_row0 * AT_ROW + v_byte + ((v_chunk_lo ^ v_sw0) << 4);
+  const unsigned vaddr1_ = lds_base + AT_TILE + (v_row0 + 8) * AT_ROW + v_byte + ((v_chunk_lo ^ v_sw1) << 4);
 
   f32x16 o[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  const float sc = p.scale_log2;
+  float m_run = 0.f, l_run = 0.f;              // m_run in scaled log2 units; fixed by the first tile
   const int q_pos = p.q_pos0 + qi;
-  const int wave_last_pos = p.q_pos0 + q0 + wave * 32 + 31;
+  const int wave_first_pos = p.q_pos0 + q0 + wave * 32;
 
-  stage(0, 0);
-  __syncthreads();
-  for (int t = 0; t < n_tiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < n_tiles) stage(cur ^ 1, t + 1);
-    const int kv0 = t * AT_BKV;
-    const bool active = !CAUSAL || kv0 <= wave_last_pos;      // wave-uniform
-    if (active) {
-      // ---- S^T = K . Q^T ----
-      // K fragments by inline-asm ds_read_b128 in a 2 x 4 register ring with hand-counted lgkmcnt waits (hipcc
-      // serialises read -> wait -> MFMA for compiler-visible LDS reads and drains the next tile's LDS-DMA in front
-      // of them).  Addresses are loop-carried registers (kaddr[ks], current ring buffer); the 32-key half is an
-      // immediate offset, so a read costs no VALU.
-      f32x16 s[2];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      {
-        v4i ka[4], kc[4];
-#define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(kaddr[ks]))
+#define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(kaddr0 ^ ((ks) << 5)), "i"(imm))
 #define V3D_KW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
 #define V3D_KM(f, i, kt, ks) s[kt] = M::run(__builtin_bit_cast(typename M::frag, f[i]), as_frag<T>(qf[ks]), s[kt])
-        if constexpr (KS == 8) {
-          V3D_KR(ka[0], 0, 0); V3D_KR(ka[1], 1, 0); V3D_KR(ka[2], 2, 0); V3D_KR(ka[3], 3, 0);
-          V3D_KR(kc[0], 4, 0); V3D_KR(kc[1], 5, 0); V3D_KR(kc[2], 6, 0); V3D_KR(kc[3], 7, 0);
-          V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
-          V3D_KR(ka[0], 0, 8192); V3D_KR(ka[1], 1, 8192); V3D_KR(ka[2], 2, 8192); V3D_KR(ka[3], 3, 8192);
-          V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 0, 6); V3D_KM(kc, 3, 0, 7);
-          V3D_KR(kc[0], 4, 8192); V3D_KR(kc[1], 5, 8192); V3D_KR(kc[2], 6, 8192); V3D_KR(kc[3], 7, 8192);
-          V3D_KW(4, ka); V3D_KM(ka, 0, 1, 0); V3D_KM(ka, 1, 1, 1); V3D_KM(ka, 2, 1, 2); V3D_KM(ka, 3, 1, 3);
-          V3D_KW(0, kc); V3D_KM(kc, 0, 1, 4); V3D_KM(kc, 1, 1, 5); V3D_KM(kc, 2, 1, 6); V3D_KM(kc, 3, 1, 7);
-        } else {   // KS == 6 (head dim 96): 4 + 2 k-steps per key half
-          V3D_KR(ka[0], 0, 0); V3D_KR(ka[1], 1, 0); V3D_KR(ka[2], 2, 0); V3D_KR(ka[3], 3, 0);
-          V3D_KR(kc[0], 4, 0); V3D_KR(kc[1], 5, 0); V3D_KR(kc[2], 0, 8192); V3D_KR(kc[3], 1, 8192);
-          V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
-          V3D_KR(ka[0], 2, 8192); V3D_KR(ka[1], 3, 8192); V3D_KR(ka[2], 4, 8192); V3D_KR(ka[3], 5, 8192);
-          V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 1, 0); V3D_KM(kc, 3, 1, 1);
-          V3D_KW(0, ka); V3D_KM(ka, 0, 1, 2); V3D_KM(ka, 1, 1, 3); V3D_KM(ka, 2, 1, 4); V3D_KM(ka, 3, 1, 5);
-        }
-#undef V3D_KR
-#undef V3D_KW
-#undef V3D_KM
-      }
-      // ---- mask + online softmax (lane = one query; keys of reg r: (r&3) + 8(r>>2) + 4h) ----
-      const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > p.q_pos0 + q0 + wave * 32) || (kv0 + AT_BKV > p.Sk);
-      if (need_mask) {   // wave-uniform; only diagonal / tail tiles pay for it (compare + select per score)
-        int last = p.Sk - 1;
-        if (CAUSAL) last = q_pos < last ? q_pos : last;
-        const int limit = last - kv0 - 4 * h;            // visible iff tile-local key offset <= limit
+  // S'^T = K . (cQ)^T - m_run for the tile in ring buffer KB: K fragments by inline-asm ds_read_b128 in a 2 x 4 register
+  // ring with hand-counted lgkmcnt waits (hipcc serialises read -> wait -> MFMA for compiler-visible LDS reads and drains
+  // the LDS-DMA in front of them).  `fill` issues the first ring-full; the caller puts independent work behind it.
+  v4i ka_[4], kc_[4];
+  // (asm operands inside a generic lambda do not trigger implicit capture: each lambda first binds plain references)
+  auto qk_fill = [&](auto kb_c) {
+    constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+    auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+    if constexpr (KS == 8) {
+      V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
+      V3D_KR(kc[0], 4, KB); V3D_KR(kc[1], 5, KB); V3D_KR(kc[2], 6, KB); V3D_KR(kc[3], 7, KB);
+    } else {
+      V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
+      V3D_KR(kc[0], 4, KB); V3D_KR(kc[1], 5, KB); V3D_KR(kc[2], 0, KB + 8192); V3D_KR(kc[3], 1, KB + 8192);
+    }
+  };
+  auto qk_run = [&](auto kb_c, f32x16 (&s)[2]) {
+    constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+    auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+    const float init = -m_run;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            s[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : s[kt][r];
-      }
-      float mx = -INFINITY;
+      for (int r = 0; r < 16; ++r) s[kt][r] = init;
+    if constexpr (KS == 8) {
+      V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
+      V3D_KR(ka[0], 0, KB + 8192); V3D_KR(ka[1], 1, KB + 8192); V3D_KR(ka[2], 2, KB + 8192); V3D_KR(ka[3], 3, KB + 8192);
+      V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 0, 6); V3D_KM(kc, 3, 0, 7);
+      V3D_KR(kc[0], 4, KB + 8192); V3D_KR(kc[1], 5, KB + 8192); V3D_KR(kc[2], 6, KB + 8192); V3D_KR(kc[3], 7, KB + 8192);
+      V3D_KW(4, ka); V3D_KM(ka, 0, 1, 0); V3D_KM(ka, 1, 1, 1); V3D_KM(ka, 2, 1, 2); V3D_KM(ka, 3, 1, 3);
+      V3D_KW(0, kc); V3D_KM(kc, 0, 1, 4); V3D_KM(kc, 1, 1, 5); V3D_KM(kc, 2, 1, 6); V3D_KM(kc, 3, 1, 7);
+    } else {   // KS == 6 (head dim 96): 4 + 2 k-steps per key half
+      V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
+      V3D_KR(ka[0], 2, KB + 8192); V3D_KR(ka[1], 3, KB + 8192); V3D_KR(ka[2], 4, KB + 8192); V3D_KR(ka[3], 5, KB + 8192);
+      V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 1, 0); V3D_KM(kc, 3, 1, 1);
+      V3D_KW(0, ka); V3D_KM(ka, 0, 1, 2); V3D_KM(ka, 1, 1, 3); V3D_KM(ka, 2, 1, 4); V3D_KM(ka, 3, 1, 5);
+    }
+  };
+
+  // Softmax part 1 for tile t (lane = one query; keys of register r: (r&3) + 8(r>>2) + 4h + 32kt): mask, max,
+  // and the (rare) raise of the running maximum.  Returns the factor O and l must be multiplied by (1 = untouched).
+  auto softmax_prep = [&](f32x16 (&s)[2], int t) -> float {
+    const int kv0 = t * AT_BKV;
+    const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > wave_first_pos) || (kv0 + AT_BKV > p.Sk);
+    if (need_mask) {   // wave-uniform; only diagonal / tail tiles pay for it (compare + select per score)
+      int last = p.Sk - 1;
+      if (CAUSAL) last = q_pos < last ? q_pos : last;
+      const int limit = last - kv0 - 4 * h;            // visible iff tile-local key offset <= limit
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * sc);   // v_exp_f32; m_run = -inf -> 0
-      const float mb = m_use * sc;
-      float ls = 0.f;
-      Frag16 pf[4];
+        for (int r = 0; r < 16; ++r)
+          s[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : s[kt][r];
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+    float alpha = 1.0f;
+    if (t == 0 || __any(mx > AT_RAISE)) {              // wave-uniform
+      const float mp = fmaxf(mx, __shfl_xor(mx, 32));    // both key halves of the query
+      float d = t == 0 ? mp : fmaxf(mp, 0.f);            // the first tile FIXES the maximum, later ones only raise it
+      d = mp == -INFINITY ? 0.f : d;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          float e[8];
+        for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+      m_run += d;
+      alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);     // nothing accumulated yet at t = 0
+    }
+    return alpha;
+  };
+  // Softmax part 2, one quarter: 8 scores -> exp2 -> one P^T fragment (k order of the V^T fragments) + row-sum share.
+  auto softmax_quarter = [&](const f32x16 (&s)[2], int i, Frag16& pf, float& ls0, float& ls1) {
+    float e[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            e[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][8 * s2 + j], sc, -mb));
-            ls += e[j];
-          }
-          pf[2 * kt + s2].u = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
-        }
-      l_run = l_run * alpha + ls;
-      m_run = m_new;
-      if (__any(alpha != 1.0f)) {     // wave-uniform: once the running max has settled the rescale is skipped
+    for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(s[i >> 1][8 * (i & 1) + j]);
+    ls0 += (e[0] + e[1]) + (e[2] + e[3]);
+    ls1 += (e[4] + e[5]) + (e[6] + e[7]);
+    pf.u = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
+  };
+
+#define V3D_VR(f, dt, VB) { \
+  const unsigned a0 = vaddr0 ^ ((dt) << 6), a1 = vaddr1 ^ ((dt) << 6); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[0]) : "v"(a0), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[1]) : "v"(a1), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[2]) : "v"(a0), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[3]) : "v"(a1), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[4]) : "v"(a0), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[5]) : "v"(a1), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[6]) : "v"(a0), "i"(VB + 12288)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[7]) : "v"(a1), "i"(VB + 12288)); }
+#define V3D_VW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory")
+
+  // One pipeline step: S' of tile t+1 (MFMA only), then O^T += V^T . P^T of tile t with the softmax of tile t+1
+  // slotted between its MFMAs (v_exp / adds / packs issue in the shadow of the 32-cycle MFMAs of the same wave).
+  //   PAR = t & 1: V of tile t is in ring buffer PAR, K of tile t+1 in buffer 1-PAR.
+  //   FULL = 1: steady state (tiles t+1 and t+2 exist, this wave computes both halves) - one straight-line block, so
+  //   the scheduler can weave the VALU between the MFMAs; FULL = 0: the guarded form for the last two steps.
+  auto step = [&](auto par_c, auto full_c, int t, Frag16 (&pc)[4], Frag16 (&pn)[4]) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool FULL = decltype(full_c)::value != 0;
+    constexpr int VB = PAR * 2 * AT_TILE;
+    const unsigned vaddr0 = vaddr0_, vaddr1 = vaddr1_;
+    const bool do_qk = FULL || t + 1 < n_wave, do_pv = FULL || t < n_wave;          // wave-uniform
+    f32x16 s[2];
+    if (do_qk) qk_fill(IntC<1 - PAR>{});
+    if (FULL || t + 2 < n_tiles) stage_k(PAR, t + 2);          // K[PAR] (tile t) was consumed one step ago
+    if (FULL || t + 1 < n_tiles) stage_v(1 - PAR, t + 1);      // V[1-PAR] (tile t-1) was consumed one step ago
+    if (do_qk) qk_run(IntC<1 - PAR>{}, s);
+    v2i va[8], vc[8];          // V^T fragments [2*s4 + half], ring of two d-tiles
+    if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    float alpha = 1.0f, ls0 = 0.f, ls1 = 0.f;
+    if (do_qk) alpha = softmax_prep(s, t + 1);
+    auto mmav = [&](const v2i* f, int dt, int quarter) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const v4i vf = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
+        o[dt] = M::run(__builtin_bit_cast(typename M::frag, vf), as_frag<T>(pc[s4]), o[dt]);
+      }
+      if (quarter >= 0 && do_qk) {
+        softmax_quarter(s, quarter, pn[quarter], ls0, ls1);
+        // keep this quarter's VALU here, between the MFMAs (the fragment is only consumed one step later and the
+        // compiler would otherwise sink the whole softmax out of the MFMA shadow)
+        asm volatile("" : "+v"(pn[quarter].i4), "+v"(ls0), "+v"(ls1));
+      }
+    };
+    if (do_pv) {
+      V3D_VW(8, va); mmav(va, 0, 0); V3D_VR(va, 2, VB)
+      if constexpr (DT == 4) {
+        V3D_VW(8, vc); mmav(vc, 1, 1); V3D_VR(vc, 3, VB)
+        V3D_VW(8, va); mmav(va, 2, 2);
+        V3D_VW(0, vc); mmav(vc, 3, 3);
+      } else {
+        V3D_VW(8, vc); mmav(vc, 1, 1);
+        V3D_VW(0, va); mmav(va, 2, 2);
+        if (do_qk) softmax_quarter(s, 3, pn[3], ls0, ls1);
+      }
+    }
+    if (do_qk) {
+      if (__any(alpha != 1.0f)) {     // wave-uniform, rare: the maximum moved, bring O and l to the new reference
 #pragma unroll
         for (int i = 0; i < DT; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run *= alpha;
       }
-      // ---- O^T += V^T . P^T ----  (V^T fragments by asm ds_read_b64_tr_b16, ring of two d-tiles; the 16-key
-      //                              step is an immediate offset, vaddr[2*dt + half] the loop-carried address)
-      {
-        v2i va[8], vc[8];          // [2*s4 + half]
-#define V3D_VR(f, dt) \
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[0]) : "v"(vaddr[2 * (dt)])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[1]) : "v"(vaddr[2 * (dt) + 1])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f[2]) : "v"(vaddr[2 * (dt)])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f[3]) : "v"(vaddr[2 * (dt) + 1])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[4]) : "v"(vaddr[2 * (dt)])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[5]) : "v"(vaddr[2 * (dt) + 1])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[6]) : "v"(vaddr[2 * (dt)])); \
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[7]) : "v"(vaddr[2 * (dt) + 1]));
-        auto mmav = [&](const v2i* f, int dt) {
+      l_run += ls0 + ls1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // tiles t+1 (V) / t+2 (K) landed and visible; everyone is done with tile t
+  };
+
+#ifdef V3D_ATTN_PROF
+  const unsigned long long blk_rt0 = __builtin_amdgcn_s_memrealtime(), blk_c0 = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- prologue: tiles 0 (K, V) and 1 (K) in flight, S' and P of tile 0 ----
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (n_tiles > 1) stage_k(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Frag16 pa[4], pb[4];
+  {
+    f32x16 s[2];
+    float ls0 = 0.f, ls1 = 0.f;
+    qk_fill(IntC<0>{});
+    qk_run(IntC<0>{}, s);
+    softmax_prep(s, 0);
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const v4i vf = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
-            o[dt] = M::run(__builtin_bit_cast(typename M::frag, vf), as_frag<T>(pf[s4]), o[dt]);
-          }
-        };
-#define V3D_VW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory")
-        V3D_VR(va, 0) V3D_VR(vc, 1)
-        V3D_VW(8, va); mmav(va, 0); V3D_VR(va, 2)
-        if constexpr (DT == 4) {
-          V3D_VW(8, vc); mmav(vc, 1); V3D_VR(vc, 3)
-          V3D_VW(8, va); mmav(va, 2);
-          V3D_VW(0, vc); mmav(vc, 3);
-        } else {
-          V3D_VW(8, vc); mmav(vc, 1);
-          V3D_VW(0, va); mmav(va, 2);
-        }
+    for (int i = 0; i < 4; ++i) softmax_quarter(s, i, pa[i], ls0, ls1);
+    l_run = ls0 + ls1;
+  }
+  {
+    const int n_full = (n_tiles - 2 < n_wave - 1 ? n_tiles - 2 : n_wave - 1) & ~1;     // steady-state steps, in pairs
+    int t = 0;
+    for (; t < n_full; t += 2) {
+      step(IntC<0>{}, IntC<1>{}, t, pa, pb);
+      step(IntC<1>{}, IntC<1>{}, t + 1, pb, pa);
+    }
+    for (; t < n_tiles; t += 2) {
+      step(IntC<0>{}, IntC<0>{}, t, pa, pb);
+      if (t + 1 < n_tiles) step(IntC<1>{}, IntC<0>{}, t + 1, pb, pa);
+    }
+  }
+  __syncthreads();
+#undef V3D_KR
+#undef V3D_KW
+#undef V3D_KM
 #undef V3D_VR
 #undef V3D_VW
-      }
+#ifdef V3D_ATTN_PROF
+  if (tid == 0) {
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (bid < 4096) {
+      unsigned hwid, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      g_attn_blocks[4 * bid + 0] = blk_rt0;
+      g_attn_blocks[4 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+      g_attn_blocks[4 * bid + 2] = __builtin_amdgcn_s_memtime() - blk_c0;
+      g_attn_blocks[4 * bid + 3] = ((unsigned long long)xcc << 32) | hwid;
+      g_attn_blocks[4 * 4095 + (bid & 3)] = (unsigned long long)n_tiles;
     }
-    {   // flip the loop-carried fragment addresses to the other ring buffer (one VALU add each)
-      const int delta = cur ? -2 * AT_TILE : 2 * AT_TILE;
-#pragma unroll
-      for (int i = 0; i < KS; ++i) kaddr[i] += delta;
-#pragma unroll
-      for (int i = 0; i < 2 * DT; ++i) vaddr[i] += delta;
-    }
-    __syncthreads();   // next tile landed; everyone is done with `cur`
   }
+#endif
 
   // ---- normalise, transpose through LDS, store whole rows ----
   float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -566,7 +658,7 @@ __global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, int 
 
 template <typename T>
 static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t st) {
-  const dim3 grid((p.Sq + AT_BQ - 1) / AT_BQ, p.Hq, B), block(256);
+  const dim3 grid(p.Hq, (p.Sq + AT_BQ - 1) / AT_BQ, B), block(256);
 #define V3D_ATTN(DD, CC)                                                                                          \
   {                                                                                                               \
     auto k = attn_prefill_kernel<T, DD, CC>;                                                                      \
