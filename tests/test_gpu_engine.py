@@ -165,3 +165,78 @@ def test_two_scenes_in_flight_equal_serial():
     torch.cuda.synchronize()
     for a, b in zip(serial, out):
         assert torch.equal(a, b)
+
+
+def _prefill(eng, ctx, ids, im, wc):
+    eng.use(ctx)
+    feats = eng.encode_images(im)
+    vox = eng.voxel_ids(wc.to(eng.dtype))
+    x = eng.build_inputs_embeds(ids, feats, vox)
+    eng.llm_forward(x, 0)
+    return x.shape[0]
+
+
+@pytest.mark.parametrize("M", [2, 3, 4])
+def test_decode_group_tokens_identical_to_single_scene(M):
+    """M prefilled scenes decode together in one pass over the weights (bench.py's decode groups): every scene's tokens
+    must be exactly the tokens it generates alone (same arithmetic per row; same prompt lengths -> same split count)."""
+    from v3d.engine import Engine, random_state_dict
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=9, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    g = torch.Generator().manual_seed(10 + M)
+    scenes = []
+    for _ in range(M):
+        images = torch.randn(2, 3, 384, 384, generator=g).cuda()
+        coords = ((torch.rand(2, 384, 384, 3, generator=g) - 0.5) * 20).cuda()
+        t = torch.randint(0, 320, (18,), generator=g)
+        scenes.append((torch.cat([t[:7], torch.tensor([PO.IMAGE_TOKEN_INDEX]), t[7:]]), images, coords))
+    main = eng.ctx
+    eng.use(main)
+    alone = [eng.generate(ids, im, wc, max_new_tokens=7).clone() for ids, im, wc in scenes]
+    ctxs = [eng.new_context() for _ in range(M)]
+    lens = [_prefill(eng, c, *sc) for c, sc in zip(ctxs, scenes)]
+    grp = eng.new_group(M)
+    toks = eng.decode_group(grp, ctxs, lens, 7)
+    torch.cuda.synchronize()
+    assert toks.shape == (M, 7)
+    for m in range(M):
+        assert torch.equal(toks[m], alone[m]), (m, toks[m].tolist(), alone[m].tolist())
+        assert ctxs[m].kv_len == lens[m] + 6
+
+
+def test_decode_group_ragged_lengths_close_to_single_scene():
+    """Scenes of different prompt lengths in one group: the split count follows the longest scene, so the split merge
+    adds in another order - logits agree to bf16 rounding noise (relative L2 < 1e-2), not bit for bit."""
+    from v3d.engine import Engine, random_state_dict
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=11, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    g = torch.Generator().manual_seed(12)
+    scenes = []
+    for n_text in (12, 40):
+        images = torch.randn(2, 3, 384, 384, generator=g).cuda()
+        coords = ((torch.rand(2, 384, 384, 3, generator=g) - 0.5) * 20).cuda()
+        t = torch.randint(0, 320, (n_text,), generator=g)
+        scenes.append((torch.cat([t[:5], torch.tensor([PO.IMAGE_TOKEN_INDEX]), t[5:]]), images, coords))
+    tok = torch.tensor([5], device="cuda")
+    single = []
+    for ids, im, wc in scenes:                       # one decode step alone, token 5 appended
+        c = eng.new_context()
+        S = _prefill(eng, c, ids, im, wc)
+        xe = ops_embed(eng, tok, c, S)
+        single.append(eng.decode_forward(xe, S).float().clone())
+    ctxs = [eng.new_context() for _ in scenes]
+    lens = [_prefill(eng, c, *sc) for c, sc in zip(ctxs, scenes)]
+    assert lens[0] != lens[1]
+    grp = eng.new_group(2)
+    from v3d import ops
+    ops.embed_gather(eng.embed, torch.tensor([5, 5], device="cuda"), out=grp.x[:2])
+    logits = eng.decode_forward_rows(grp, ctxs, lens).float()
+    for m in range(2):
+        assert rel_err(logits[m], single[m].cpu()) < 1e-2
+
+
+def ops_embed(eng, tok, ctx, S):
+    from v3d import ops
+    return ops.embed_gather(eng.embed, tok, out=ctx.l_x[S: S + 1])

@@ -233,6 +233,35 @@ def test_linear_decode_fused_variants(ops, kind):
     close(act, want, kind, ulps=3.0, floor=0.3)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("K,N", [(512, 384), (3584, 512), (4736, 256)])
+def test_linear_decode_rows_bit_identical_to_single_rows(ops, M, K, N):
+    """Scenes decoding together share one pass over the weights; a row's result must not depend on its batch."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(100 + M)
+    x = torch.randn(M, K, generator=g).to(dt).cuda()
+    lnw = (1 + 0.1 * torch.randn(K, generator=g)).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    r = torch.randn(M, N, generator=g).to(dt).cuda()
+    cases = [dict(), dict(bias=b, epilogue=ops.DEC_BIAS), dict(res=r, epilogue=ops.DEC_RES), dict(epilogue=ops.DEC_SWIGLU)]
+    if K <= 4096:
+        cases += [dict(norm_weight=lnw, eps=1e-6, bias=b, epilogue=ops.DEC_BIAS), dict(norm_weight=lnw, eps=1e-6, epilogue=ops.DEC_SWIGLU)]
+    for kw in cases:
+        n_out = N // 2 if kw.get("epilogue") == ops.DEC_SWIGLU else N
+        if kw.get("epilogue") == ops.DEC_SWIGLU and N % 128:
+            continue
+        got = torch.full((M, n_out), 7.0, dtype=dt, device="cuda")
+        ops.linear_decode_rows(x, w, got, **kw)
+        for m in range(M):
+            one = torch.empty(n_out, dtype=dt, device="cuda")
+            kw1 = dict(kw)
+            if "res" in kw1:
+                kw1["res"] = r[m]
+            ops.linear_decode(x[m], w, one, **kw1)
+            assert torch.equal(got[m], one), (kw.get("epilogue"), m)
+
+
 def test_rope_kv_append_and_argmax(ops):
     dt = torch.bfloat16
     H, KV, D = 4, 2, 128

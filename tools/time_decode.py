@@ -23,6 +23,29 @@ t("o_proj", 3584, 3584, 2)
 t("gate_up", 37888, 3584, 3, norm=True)
 t("down", 3584, 18944, 2)
 t("lm_head", 152064, 3584, 0, norm=False, iters=12)
+def tm(name, N, K, epi, M, iters=40, norm=False):
+    x = torch.randn(M, K, device="cuda", dtype=dt)
+    ws = [torch.randn(N, K, device="cuda", dtype=dt) * 0.02 for _ in range(4)]
+    nw = torch.ones(K, device="cuda", dtype=dt) if norm else None
+    b = torch.zeros(N, device="cuda", dtype=dt); r = torch.zeros(M, N, device="cuda", dtype=dt)
+    out = torch.empty(M, N // 2 if epi == 3 else N, device="cuda", dtype=dt)
+    f = lambda w: ops.linear_decode_rows(x, w, out, norm_weight=nw, bias=b if epi == 1 else None, res=r if epi == 2 else None, epilogue=epi)
+    for w in ws: f(w)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters): f(ws[i % 4])
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"{name:10s} M={M} N={N:6d} K={K:6d} {us:8.1f} us  {N*K*2/us/1e6:6.2f} TB/s")
+for M in (2, 4):
+    tm("qkv", 4608, 3584, 1, M, norm=True)
+    tm("o_proj", 3584, 3584, 2, M)
+    tm("gate_up", 37888, 3584, 3, M, norm=True)
+    tm("down", 3584, 18944, 2, M)
+    tm("lm_head", 152064, 3584, 0, M, iters=12)
+    tm("qkv-nonorm", 4608, 3584, 1, M)
+    tm("gu-nonorm", 37888, 3584, 3, M)
 # decode attention
 H, KV, D, Sk = 28, 4, 128, 6800
 q = torch.randn(H * D, device="cuda", dtype=dt)

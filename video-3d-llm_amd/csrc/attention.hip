@@ -513,10 +513,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 // the workspace; a second tiny kernel merges the splits.  HBM-bound: cache bytes read once.
 // ------------------------------------------------------------------------------------------
 constexpr int DEC_MAXG = 8;
+constexpr int DEC_MAXROWS = 4;
+
+// Scenes decoding together (blockIdx.z = scene): each has its own cache, length, query row and workspace slice.
+struct DecRows {
+  const void* k[DEC_MAXROWS];
+  const void* v[DEC_MAXROWS];
+  int sk[DEC_MAXROWS];
+  int64_t q_stride, o_stride;       // elements between the scenes' query / output rows
+  int64_t ws_stride;                // floats between the scenes' workspace slices
+};
 
 template <typename T, int G>
-__global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, int n_split, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecRows rw, int n_split, float* __restrict__ ws) {
   constexpr int D = 128;
+  {
+    const int sc = blockIdx.z;
+    p.k = rw.k[sc]; p.v = rw.v[sc]; p.Sk = rw.sk[sc]; p.q_pos0 = rw.sk[sc] - 1;
+    p.q = (const uint16_t*)p.q + sc * rw.q_stride;
+    ws += sc * rw.ws_stride;
+  }
   __shared__ float sm_m[16][G], sm_l[16][G];
   __shared__ float sm_o[16][G][D + 4];
   const int tid = threadIdx.x;
@@ -618,8 +634,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, int 
 }
 
 template <typename T>
-__global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, int n_split, const float* __restrict__ ws) {
+__global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, DecRows rw, int n_split, const float* __restrict__ ws) {
   constexpr int D = 128;
+  p.o = (uint16_t*)p.o + blockIdx.z * rw.o_stride;
+  ws += blockIdx.z * rw.ws_stride;
   __shared__ float sm_f[1024], sm_lsum;
   const int head = blockIdx.x, d = threadIdx.x;
   // per-split (max, sum) pairs -> LDS once, then every thread reuses the rescale factors
@@ -716,41 +734,66 @@ extern "C" int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits) 
   return (int64_t)max_splits * Hq * (128 + 2) * (int64_t)sizeof(float);
 }
 
-extern "C" int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int Sk,
-                                    int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
-                                    void* workspace, int64_t workspace_bytes, void* stream) {
-  V3D_REQUIRE(q && k_cache && v_cache && o && workspace, "v3d_attention_decode: null pointer");
-  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_attention_decode: dtype must be f16 or bf16");
-  V3D_REQUIRE(Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DEC_MAXG, "v3d_attention_decode: bad head counts");
-  V3D_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0 && hsq % 8 == 0 && hsk % 8 == 0 && aligned16(q) && aligned16(k_cache) && aligned16(v_cache),
-              "v3d_attention_decode: alignment");
+static int attention_decode_rows(const void* q, int64_t q_stride, int M, const void* const* k_caches, const void* const* v_caches,
+                                 const int* Sk, void* o, int64_t o_stride, int dtype, int Hq, int Hkv, int64_t ldk, int64_t ldv,
+                                 int hsq, int hsk, int hso, float scale, void* workspace, int64_t workspace_bytes, void* stream,
+                                 const char* who) {
+  V3D_REQUIRE(q && k_caches && v_caches && Sk && o && workspace, "%s: null pointer", who);
+  V3D_REQUIRE(M >= 1 && M <= DEC_MAXROWS, "%s: 1 to %d scenes (got %d)", who, DEC_MAXROWS, M);
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
+  V3D_REQUIRE(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DEC_MAXG, "%s: bad head counts", who);
+  V3D_REQUIRE(ldk % 8 == 0 && ldv % 8 == 0 && hsq % 8 == 0 && hsk % 8 == 0 && q_stride % 8 == 0 && aligned16(q), "%s: alignment", who);
+  DecRows rw{};
+  int sk_max = 0;
+  for (int m = 0; m < M; ++m) {
+    V3D_REQUIRE(k_caches[m] && v_caches[m] && aligned16(k_caches[m]) && aligned16(v_caches[m]) && Sk[m] > 0, "%s: scene %d cache", who, m);
+    rw.k[m] = k_caches[m]; rw.v[m] = v_caches[m]; rw.sk[m] = Sk[m];
+    sk_max = Sk[m] > sk_max ? Sk[m] : sk_max;
+  }
   static int kps = 0;
   if (!kps) { const char* e = getenv("V3D_DEC_KEYS_PER_SPLIT"); kps = e ? atoi(e) : 64; }
-  int n_split = (Sk + kps - 1) / kps;                // >= 64 keys per split: 4 x 107 workgroups at S = 6.8k
-  const int cap = 1024 / Hkv;                        // ~4 workgroups per CU
+  int n_split = (sk_max + kps - 1) / kps;            // >= 64 keys per split: 4 x 107 workgroups at S = 6.8k
+  const int cap = 1024 / Hkv;                        // ~4 workgroups per CU and scene
   if (n_split > cap) n_split = cap;
   if (n_split < 1) n_split = 1;
-  V3D_REQUIRE(workspace_bytes >= v3d_attention_decode_workspace_bytes(Hq, n_split), "v3d_attention_decode: workspace too small for %d splits", n_split);
+  const int64_t ws_one = v3d_attention_decode_workspace_bytes(Hq, n_split);
+  V3D_REQUIRE(workspace_bytes >= ws_one * M, "%s: workspace too small for %d scenes x %d splits", who, M, n_split);
+  rw.q_stride = q_stride; rw.o_stride = o_stride; rw.ws_stride = ws_one / (int64_t)sizeof(float);
   AttnArgs p{};
-  p.q = q; p.k = k_cache; p.v = v_cache; p.o = o;
+  p.q = q; p.o = o;
   p.ldk = ldk; p.ldv = ldv; p.hsq = hsq; p.hsk = hsk; p.hso = hso;
-  p.Sq = 1; p.Sk = Sk; p.Hq = Hq; p.group = Hq / Hkv; p.d_out = 128; p.q_pos0 = Sk - 1;
+  p.Sq = 1; p.Hq = Hq; p.group = Hq / Hkv; p.d_out = 128;
   p.scale_log2 = scale * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const int G = Hq / Hkv;
-#define V3D_DEC(TT, GG) hipLaunchKernelGGL((attn_decode_split_kernel<TT, GG>), dim3(Hkv, n_split), dim3(256), 0, st, p, n_split, ws)
+#define V3D_DEC(TT, GG) hipLaunchKernelGGL((attn_decode_split_kernel<TT, GG>), dim3(Hkv, n_split, M), dim3(256), 0, st, p, rw, n_split, ws)
 #define V3D_DEC_G(TT)                                                                          \
   switch (G) {                                                                                 \
     case 1: V3D_DEC(TT, 1); break; case 2: V3D_DEC(TT, 2); break; case 4: V3D_DEC(TT, 4); break; \
     case 7: V3D_DEC(TT, 7); break; case 8: V3D_DEC(TT, 8); break;                              \
-    default: set_error("v3d_attention_decode: group size %d unsupported (1,2,4,7,8)", G); return V3D_E_UNSUPPORTED; \
+    default: set_error("%s: group size %d unsupported (1,2,4,7,8)", who, G); return V3D_E_UNSUPPORTED; \
   }
   if (dtype == V3D_BF16) { V3D_DEC_G(bf16_t) } else { V3D_DEC_G(f16_t) }
 #undef V3D_DEC_G
 #undef V3D_DEC
-  if (int e = check_launch("v3d_attention_decode (split)")) return e;
-  if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_merge_kernel<bf16_t>), dim3(Hq), dim3(128), 0, st, p, n_split, ws);
-  else hipLaunchKernelGGL((attn_decode_merge_kernel<f16_t>), dim3(Hq), dim3(128), 0, st, p, n_split, ws);
-  return check_launch("v3d_attention_decode (merge)");
+  if (int e = check_launch(who)) return e;
+  if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_merge_kernel<bf16_t>), dim3(Hq, 1, M), dim3(128), 0, st, p, rw, n_split, ws);
+  else hipLaunchKernelGGL((attn_decode_merge_kernel<f16_t>), dim3(Hq, 1, M), dim3(128), 0, st, p, rw, n_split, ws);
+  return check_launch(who);
+}
+
+extern "C" int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int Sk,
+                                    int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  return attention_decode_rows(q, 0, 1, &k_cache, &v_cache, &Sk, o, 0, dtype, Hq, Hkv, ldk, ldv, hsq, hsk, hso, scale, workspace,
+                               workspace_bytes, stream, "v3d_attention_decode");
+}
+
+extern "C" int v3d_attention_decode_rows(const void* q, int64_t q_stride, int M, const void* const* k_caches,
+                                         const void* const* v_caches, const int* Sk, void* o, int64_t o_stride, int dtype, int Hq,
+                                         int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale, void* workspace,
+                                         int64_t workspace_bytes, void* stream) {
+  return attention_decode_rows(q, q_stride, M, k_caches, v_caches, Sk, o, o_stride, dtype, Hq, Hkv, ldk, ldv, hsq, hsk, hso, scale,
+                               workspace, workspace_bytes, stream, "v3d_attention_decode_rows");
 }

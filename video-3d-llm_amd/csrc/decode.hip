@@ -27,15 +27,16 @@ __device__ __forceinline__ uint4 ldg_nt(const uint4* p) {
 // Workgroup = 4 waves = FOUR weight rows; the K range is split over the 256 threads (chunk k = tid + 256 i), so
 // every row is streamed by all four waves at once: N/4 workgroups (1152 for the QKV linear) keep the whole chip
 // loading even for the small linears, and each thread has 8 independent 16-byte loads in flight.
-// <= 64 VGPRs on purpose: one wave of this kernel then fits on every SIMD beside two resident 224-register GEMM
-// waves, so the decode step of one scene streams weights while another scene's prefill owns the matrix cores.
+// M activation rows (M scenes decoding together, 1 <= M <= 4) share ONE pass over the weights: the step is
+// HBM-bound on the 15 GB of weights, so M scenes cost about what one does.  Each row's arithmetic is exactly the
+// M = 1 arithmetic (same chunk order, same reductions), so batching scenes never changes a result bit.
 // NORM (fused Qwen2RMSNorm, modeling_qwen2.py:85-90) needs K <= 4096: the thread keeps its 2 chunks of x in
 // registers between the sum-of-squares pass and the multiply pass.
-template <typename T, int EPI, bool NORM>
-__global__ __launch_bounds__(256, 8) void linear_decode_kernel(const T* __restrict__ x, const T* __restrict__ norm_w, float eps,
-                                                               const T* __restrict__ W, int64_t ldw, const T* __restrict__ bias,
-                                                               const T* __restrict__ res, T* __restrict__ out, int N, int K) {
-  __shared__ float red[4][4];
+template <typename T, int EPI, bool NORM, int M>
+__global__ __launch_bounds__(256, M == 1 ? 8 : 4) void linear_decode_kernel(
+    const T* __restrict__ x, int64_t ldx, const T* __restrict__ norm_w, float eps, const T* __restrict__ W, int64_t ldw,
+    const T* __restrict__ bias, const T* __restrict__ res, int64_t ldr, T* __restrict__ out, int64_t ldo, int N, int K) {
+  __shared__ float red[M][4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kv = K / 8;
   int rows[4];
@@ -49,92 +50,129 @@ __global__ __launch_bounds__(256, 8) void linear_decode_kernel(const T* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) rows[r] = o0 + r;
   }
-  const uint4* xr = reinterpret_cast<const uint4*>(x);
-  uint4 xn[2];
+  uint4 xn[M][2];
   if (NORM) {                                              // kv <= 512: chunks tid and tid + 256
-    float ss = 0.f;
+    float ss[M];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = tid + 256 * i;
-      xn[i] = k < kv ? xr[k] : make_uint4(0, 0, 0, 0);
+    for (int m = 0; m < M; ++m) {
+      const uint4* xr = reinterpret_cast<const uint4*>(x + m * ldx);
+      ss[m] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(xn[i], j); ss = fmaf(f, f, ss); }
+      for (int i = 0; i < 2; ++i) {
+        const int k = tid + 256 * i;
+        xn[m][i] = k < kv ? xr[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(xn[m][i], j); ss[m] = fmaf(f, f, ss[m]); }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss[m] += __shfl_xor(ss[m], off);
+      if (lane == 0) red[m][0][wave] = ss[m];
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) red[0][wave] = ss;
     __syncthreads();
-    const float r = 1.0f / sqrtf((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)K + eps);
+    float rstd[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      rstd[m] = 1.0f / sqrtf((red[m][0][0] + red[m][0][1] + red[m][0][2] + red[m][0][3]) / (float)K + eps);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int k = tid + 256 * i;
       if (k < kv) {
         const uint4 w = reinterpret_cast<const uint4*>(norm_w)[k];
-        float y[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(w, j) * round_to<T>(vec_get<T>(xn[i], j) * r);
-        xn[i] = vec_pack<T>(y);
+        for (int m = 0; m < M; ++m) {
+          float y[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(w, j) * round_to<T>(vec_get<T>(xn[m][i], j) * rstd[m]);
+          xn[m][i] = vec_pack<T>(y);
+        }
       }
     }
   }
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  float s[M][4];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[m][r] = 0.f;
   const uint4* w0 = reinterpret_cast<const uint4*>(W + (int64_t)rows[0] * ldw);
   const uint4* w1 = reinterpret_cast<const uint4*>(W + (int64_t)rows[1] * ldw);
   const uint4* w2 = reinterpret_cast<const uint4*>(W + (int64_t)rows[2] * ldw);
   const uint4* w3 = reinterpret_cast<const uint4*>(W + (int64_t)rows[3] * ldw);
-  auto fma8 = [&](const uint4& xv, const uint4& a, const uint4& b, const uint4& c, const uint4& d) {
+  auto fma8 = [&](int m, const uint4& xv, const uint4& a, const uint4& b, const uint4& c, const uint4& d) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float xf = vec_get<T>(xv, j);
-      s[0] = fmaf(vec_get<T>(a, j), xf, s[0]);
-      s[1] = fmaf(vec_get<T>(b, j), xf, s[1]);
-      s[2] = fmaf(vec_get<T>(c, j), xf, s[2]);
-      s[3] = fmaf(vec_get<T>(d, j), xf, s[3]);
+      s[m][0] = fmaf(vec_get<T>(a, j), xf, s[m][0]);
+      s[m][1] = fmaf(vec_get<T>(b, j), xf, s[m][1]);
+      s[m][2] = fmaf(vec_get<T>(c, j), xf, s[m][2]);
+      s[m][3] = fmaf(vec_get<T>(d, j), xf, s[m][3]);
     }
   };
   if (NORM) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int k = tid + 256 * i;
-      if (k < kv) fma8(xn[i], ldg_nt(w0 + k), ldg_nt(w1 + k), ldg_nt(w2 + k), ldg_nt(w3 + k));
+      if (k < kv) {
+        const uint4 a = ldg_nt(w0 + k), b = ldg_nt(w1 + k), c = ldg_nt(w2 + k), d = ldg_nt(w3 + k);
+#pragma unroll
+        for (int m = 0; m < M; ++m) fma8(m, xn[m][i], a, b, c, d);
+      }
     }
   } else {
 #pragma unroll 2
-    for (int k = tid; k < kv; k += 256) fma8(xr[k], ldg_nt(w0 + k), ldg_nt(w1 + k), ldg_nt(w2 + k), ldg_nt(w3 + k));
+    for (int k = tid; k < kv; k += 256) {
+      const uint4 a = ldg_nt(w0 + k), b = ldg_nt(w1 + k), c = ldg_nt(w2 + k), d = ldg_nt(w3 + k);
+#pragma unroll
+      for (int m = 0; m < M; ++m) fma8(m, reinterpret_cast<const uint4*>(x + m * ldx)[k], a, b, c, d);
+    }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int m = 0; m < M; ++m)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s[r] += __shfl_xor(s[r], off);
-  }
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[m][r] += __shfl_xor(s[m][r], off);
+    }
   if (lane == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[r][wave] = s[r];
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[m][r][wave] = s[m][r];
   }
   __syncthreads();
   if (EPI == DEC_EPI_SWIGLU) {
-    if (tid < 2) {
-      const float g = round_to<T>(red[2 * tid][0] + red[2 * tid][1] + red[2 * tid][2] + red[2 * tid][3]);
-      const float u = round_to<T>(red[2 * tid + 1][0] + red[2 * tid + 1][1] + red[2 * tid + 1][2] + red[2 * tid + 1][3]);
-      out[o0 + tid] = from_f32<T>(round_to<T>(silu_f(g)) * u);
+    if (tid < 2 * M) {
+      const int m = tid >> 1, t2 = tid & 1;
+      const float g = round_to<T>(red[m][2 * t2][0] + red[m][2 * t2][1] + red[m][2 * t2][2] + red[m][2 * t2][3]);
+      const float u = round_to<T>(red[m][2 * t2 + 1][0] + red[m][2 * t2 + 1][1] + red[m][2 * t2 + 1][2] + red[m][2 * t2 + 1][3]);
+      out[m * ldo + o0 + t2] = from_f32<T>(round_to<T>(silu_f(g)) * u);
     }
-  } else if (tid < 4) {
-    const int n = o0 + tid;
-    float v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+  } else if (tid < 4 * M) {
+    const int m = tid >> 2, r = tid & 3;
+    const int n = o0 + r;
+    float v = red[m][r][0] + red[m][r][1] + red[m][r][2] + red[m][r][3];
     if (EPI == DEC_EPI_BIAS) v += to_f32(bias[n]);
     v = round_to<T>(v);                                   // the linear's own output rounding
-    if (EPI == DEC_EPI_RES) v += to_f32(res[n]);
-    out[n] = from_f32<T>(v);
+    if (EPI == DEC_EPI_RES) v += to_f32(res[m * ldr + n]);
+    out[m * ldo + n] = from_f32<T>(v);
   }
 }
 
 // rotary (apply_rotary_pos_emb, modeling_qwen2.py:141-173) on the new token's q and k heads, in place in the
 // QKV row, and append of k (rotated) and v to cache row `pos`:  cache_row = [k heads | v heads].
+struct RopeRows {        // scenes decoding together (blockIdx.y = scene): own position and cache row
+  int pos[4];
+  void* cache_row[4];
+  int64_t qkv_stride;
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_append_kernel(T* __restrict__ qkv, int n_q, int n_kv, int hd,
                                                              const T* __restrict__ cos_t, const T* __restrict__ sin_t,
-                                                             int pos, T* __restrict__ cache_row) {
+                                                             RopeRows rw) {
+  const int pos = rw.pos[blockIdx.y];
+  T* __restrict__ cache_row = (T*)rw.cache_row[blockIdx.y];
+  qkv += blockIdx.y * rw.qkv_stride;
   const int half = hd / 2, vper = half / 8;
   const int n_rot = (n_q + n_kv) * vper;            // rotation work items (pairs of 16-byte vectors)
   const int n_v = n_kv * hd / 8;                    // v copy items
@@ -176,9 +214,12 @@ __device__ __forceinline__ void amax_merge(float& bv, int& bi, float ov, int oi)
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void argmax_part_kernel(const T* __restrict__ x, int n, float* __restrict__ pv, int* __restrict__ pi) {
+__global__ __launch_bounds__(256) void argmax_part_kernel(const T* __restrict__ x, int64_t ldx, int n, float* __restrict__ pv, int* __restrict__ pi) {
   __shared__ float sv[4];
   __shared__ int si[4];
+  x += blockIdx.y * ldx;                     // blockIdx.y = row; its candidates live in workspace slice y (256 words)
+  pv += blockIdx.y * 256;
+  pi += blockIdx.y * 256;
   float best = -INFINITY;
   int idx = 0x7fffffff;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) amax_merge(best, idx, to_f32(x[i]), i);
@@ -194,6 +235,9 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const T* __restrict__ 
 }
 
 __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int nb, int64_t* __restrict__ out) {
+  pv += blockIdx.x * 256;
+  pi += blockIdx.x * 256;
+  out += blockIdx.x;
   float best = -INFINITY;
   int idx = 0x7fffffff;
   for (int i = threadIdx.x; i < nb; i += 64) amax_merge(best, idx, pv[i], pi[i]);
@@ -206,60 +250,107 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
 
 using namespace v3d;
 
-extern "C" int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const void* W, int64_t ldw,
-                                 const void* bias, const void* res, void* out, int N, int K, int dtype, int epilogue,
-                                 void* stream) {
-  V3D_REQUIRE(x && W && out, "v3d_linear_decode: null pointer");
-  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_linear_decode: dtype must be f16 or bf16");
-  V3D_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K, "v3d_linear_decode: bad shape N=%d K=%d", N, K);
-  V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "v3d_linear_decode: N=%d not supported", N);
-  V3D_REQUIRE(aligned16(x) && aligned16(W) && (!norm_weight || aligned16(norm_weight)), "v3d_linear_decode: alignment");
-  V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "v3d_linear_decode: bias epilogue without bias");
-  V3D_REQUIRE(epilogue != DEC_EPI_RES || res, "v3d_linear_decode: residual epilogue without residual");
-  V3D_REQUIRE(!norm_weight || K / 8 <= 512, "v3d_linear_decode: fused RMSNorm needs K <= 4096 (got %d)", K);
-  const int blocks = epilogue == DEC_EPI_SWIGLU ? N / 4 : N / 4;     // 4 weight rows per workgroup either way
+static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W, int64_t ldw,
+                              const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K, int dtype,
+                              int epilogue, void* stream, const char* who) {
+  V3D_REQUIRE(x && W && out, "%s: null pointer", who);
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
+  V3D_REQUIRE(M >= 1 && M <= 4, "%s: 1 to 4 activation rows (got %d)", who, M);
+  V3D_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K, "%s: bad shape N=%d K=%d", who, N, K);
+  V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
+  V3D_REQUIRE(aligned16(x) && aligned16(W) && (!norm_weight || aligned16(norm_weight)), "%s: alignment", who);
+  V3D_REQUIRE(M == 1 || (ldx % 8 == 0 && ldx >= K), "%s: activation row stride %lld", who, (long long)ldx);
+  V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "%s: bias epilogue without bias", who);
+  V3D_REQUIRE(epilogue != DEC_EPI_RES || res, "%s: residual epilogue without residual", who);
+  V3D_REQUIRE(!norm_weight || K / 8 <= 512, "%s: fused RMSNorm needs K <= 4096 (got %d)", who, K);
+  const int blocks = N / 4;                                   // 4 weight rows per workgroup (SWIGLU: 2 gate/up pairs)
   hipStream_t st = (hipStream_t)stream;
-#define V3D_LD(TT, EE, NN)                                                                                                 \
-  hipLaunchKernelGGL((linear_decode_kernel<TT, EE, NN>), dim3(blocks), dim3(256), 0, st, (const TT*)x, (const TT*)norm_weight, \
-                     eps, (const TT*)W, ldw, (const TT*)bias, (const TT*)res, (TT*)out, N, K)
-#define V3D_LD_N(TT, EE) { if (norm_weight) V3D_LD(TT, EE, true); else V3D_LD(TT, EE, false); }
+#define V3D_LD(TT, EE, NN, MM)                                                                                                \
+  hipLaunchKernelGGL((linear_decode_kernel<TT, EE, NN, MM>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, (const TT*)norm_weight, \
+                     eps, (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LD_M(TT, EE, NN)                                                                          \
+  switch (M) { case 1: V3D_LD(TT, EE, NN, 1); break; case 2: V3D_LD(TT, EE, NN, 2); break;            \
+               case 3: V3D_LD(TT, EE, NN, 3); break; default: V3D_LD(TT, EE, NN, 4); break; }
+#define V3D_LD_N(TT, EE) { if (norm_weight) { V3D_LD_M(TT, EE, true) } else { V3D_LD_M(TT, EE, false) } }
 #define V3D_LD_E(TT)                                                                                  \
   switch (epilogue) {                                                                                 \
     case DEC_EPI_NONE: V3D_LD_N(TT, DEC_EPI_NONE) break; case DEC_EPI_BIAS: V3D_LD_N(TT, DEC_EPI_BIAS) break; \
     case DEC_EPI_RES: V3D_LD_N(TT, DEC_EPI_RES) break; case DEC_EPI_SWIGLU: V3D_LD_N(TT, DEC_EPI_SWIGLU) break; \
-    default: set_error("v3d_linear_decode: unknown epilogue %d", epilogue); return V3D_E_INVALID;     \
+    default: set_error("%s: unknown epilogue %d", who, epilogue); return V3D_E_INVALID;               \
   }
   if (dtype == V3D_BF16) { V3D_LD_E(bf16_t) } else { V3D_LD_E(f16_t) }
 #undef V3D_LD_E
 #undef V3D_LD_N
+#undef V3D_LD_M
 #undef V3D_LD
-  return check_launch("v3d_linear_decode");
+  return check_launch(who);
+}
+
+extern "C" int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const void* W, int64_t ldw,
+                                 const void* bias, const void* res, void* out, int N, int K, int dtype, int epilogue,
+                                 void* stream) {
+  return linear_decode_rows(x, 0, 1, norm_weight, eps, W, ldw, bias, res, 0, out, 0, N, K, dtype, epilogue, stream, "v3d_linear_decode");
+}
+
+extern "C" int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W,
+                                      int64_t ldw, const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N,
+                                      int K, int dtype, int epilogue, void* stream) {
+  return linear_decode_rows(x, ldx, M, norm_weight, eps, W, ldw, bias, res, ldr, out, ldo, N, K, dtype, epilogue, stream,
+                            "v3d_linear_decode_rows");
+}
+
+static int rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
+                               const void* sin_table, int n_pos, const int* pos, void* const* cache_rows, int dtype, void* stream,
+                               const char* who) {
+  V3D_REQUIRE(qkv && cos_table && sin_table && pos && cache_rows, "%s: null pointer", who);
+  V3D_REQUIRE(M >= 1 && M <= 4 && head_dim % 16 == 0 && aligned16(qkv) && qkv_stride % 8 == 0, "%s: bad arguments", who);
+  RopeRows rw{};
+  for (int m = 0; m < M; ++m) {
+    V3D_REQUIRE(pos[m] >= 0 && pos[m] < n_pos, "%s: pos %d outside the table (%d)", who, pos[m], n_pos);
+    V3D_REQUIRE(cache_rows[m] && aligned16(cache_rows[m]), "%s: cache row %d", who, m);
+    rw.pos[m] = pos[m]; rw.cache_row[m] = cache_rows[m];
+  }
+  rw.qkv_stride = qkv_stride;
+  const int items = (n_q_heads + n_kv_heads) * (head_dim / 16) + n_kv_heads * head_dim / 8;
+  const dim3 grid((items + 255) / 256, M);
+  if (dtype == V3D_BF16)
+    hipLaunchKernelGGL(rope_kv_append_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv,
+                       n_q_heads, n_kv_heads, head_dim, (const bf16_t*)cos_table, (const bf16_t*)sin_table, rw);
+  else if (dtype == V3D_F16)
+    hipLaunchKernelGGL(rope_kv_append_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, (f16_t*)qkv,
+                       n_q_heads, n_kv_heads, head_dim, (const f16_t*)cos_table, (const f16_t*)sin_table, rw);
+  else { set_error("%s: dtype must be f16 or bf16", who); return V3D_E_INVALID; }
+  return check_launch(who);
 }
 
 extern "C" int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
                                   const void* sin_table, int n_pos, int pos, void* cache_row, int dtype, void* stream) {
-  V3D_REQUIRE(qkv_row && cos_table && sin_table && cache_row, "v3d_rope_kv_append: null pointer");
-  V3D_REQUIRE(head_dim % 16 == 0 && pos >= 0 && pos < n_pos, "v3d_rope_kv_append: pos %d outside the table (%d)", pos, n_pos);
-  V3D_REQUIRE(aligned16(qkv_row) && aligned16(cache_row), "v3d_rope_kv_append: alignment");
-  const int items = (n_q_heads + n_kv_heads) * (head_dim / 16) + n_kv_heads * head_dim / 8;
-  const int blocks = (items + 255) / 256;
-  if (dtype == V3D_BF16)
-    hipLaunchKernelGGL(rope_kv_append_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)qkv_row,
-                       n_q_heads, n_kv_heads, head_dim, (const bf16_t*)cos_table, (const bf16_t*)sin_table, pos, (bf16_t*)cache_row);
-  else if (dtype == V3D_F16)
-    hipLaunchKernelGGL(rope_kv_append_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (f16_t*)qkv_row,
-                       n_q_heads, n_kv_heads, head_dim, (const f16_t*)cos_table, (const f16_t*)sin_table, pos, (f16_t*)cache_row);
-  else { set_error("v3d_rope_kv_append: dtype must be f16 or bf16"); return V3D_E_INVALID; }
-  return check_launch("v3d_rope_kv_append");
+  return rope_kv_append_rows(qkv_row, 0, 1, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, n_pos, &pos, &cache_row, dtype,
+                             stream, "v3d_rope_kv_append");
+}
+
+extern "C" int v3d_rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_heads, int n_kv_heads, int head_dim,
+                                       const void* cos_table, const void* sin_table, int n_pos, const int* pos,
+                                       void* const* cache_rows, int dtype, void* stream) {
+  return rope_kv_append_rows(qkv, qkv_stride, M, n_q_heads, n_kv_heads, head_dim, cos_table, sin_table, n_pos, pos, cache_rows,
+                             dtype, stream, "v3d_rope_kv_append_rows");
+}
+
+static int argmax_rows(const void* x, int64_t ldx, int M, int n, int dtype, int64_t* out_index, void* workspace, void* stream, const char* who) {
+  V3D_REQUIRE(x && out_index && workspace && n > 0 && M >= 1 && M <= 64, "%s: bad arguments", who);
+  constexpr int NB = 128;                                    // workspace per row: NB floats + NB ints = 1 KiB
+  float* pv = (float*)workspace;
+  int* pi = (int*)(pv + NB);
+  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(argmax_part_kernel<T>, dim3(NB, M), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, n, pv, pi));
+  if (int e = check_launch(who)) return e;
+  hipLaunchKernelGGL(argmax_final_kernel, dim3(M), dim3(64), 0, (hipStream_t)stream, pv, pi, NB, out_index);
+  return check_launch(who);
 }
 
 extern "C" int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* workspace, void* stream) {
-  V3D_REQUIRE(x && out_index && workspace && n > 0, "v3d_argmax: bad arguments");
-  constexpr int NB = 128;                                    // workspace: NB floats + NB ints = 1 KiB
-  float* pv = (float*)workspace;
-  int* pi = (int*)(pv + NB);
-  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(argmax_part_kernel<T>, dim3(NB), dim3(256), 0, (hipStream_t)stream, (const T*)x, n, pv, pi));
-  if (int e = check_launch("v3d_argmax (partial)")) return e;
-  hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pv, pi, NB, out_index);
-  return check_launch("v3d_argmax");
+  return argmax_rows(x, 0, 1, n, dtype, out_index, workspace, stream, "v3d_argmax");
+}
+
+extern "C" int v3d_argmax_rows(const void* x, int64_t ldx, int M, int n, int dtype, int64_t* out_index, void* workspace, void* stream) {
+  return argmax_rows(x, ldx, M, n, dtype, out_index, workspace, stream, "v3d_argmax_rows");
 }

@@ -191,12 +191,54 @@ using namespace v3d;
     default: v3d::set_error("dtype must be f16 or bf16 (got %d)", (int)(dtype)); return V3D_E_INVALID; \
   }
 
+// RMSNorm of a few rows in the SUMMATION ORDER of v3d_linear_decode's fused norm (thread t sums chunks t and
+// t + 256, wave shuffle, four wave sums in order): scenes decoding together normalise once here and then use the
+// unfused linear, and get the bits the fused single-scene path produces.  One workgroup per row, cols <= 4096.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_decode_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ out,
+                                                             int cols, int64_t ldx, int64_t ldo, float eps) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kv = cols / 8;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + blockIdx.x * ldx);
+  uint4 xn[2];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = tid + 256 * i;
+    xn[i] = k < kv ? xr[k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(xn[i], j); ss = fmaf(f, f, ss); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float r = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)cols + eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = tid + 256 * i;
+    if (k < kv) {
+      const uint4 wv = reinterpret_cast<const uint4*>(w)[k];
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(wv, j) * round_to<T>(vec_get<T>(xn[i], j) * r);
+      reinterpret_cast<uint4*>(out + blockIdx.x * ldo)[k] = vec_pack<T>(y);
+    }
+  }
+}
+
 extern "C" int v3d_rmsnorm(const void* x, int64_t ldx, const void* weight, void* out, int64_t ldo, int64_t rows, int cols,
                            float eps, int dtype, void* stream) {
   V3D_REQUIRE(x && weight && out, "v3d_rmsnorm: null pointer");
   V3D_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= NORM_MAXV * 512, "v3d_rmsnorm: cols=%d unsupported", cols);
   V3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && aligned16(x) && aligned16(out) && aligned16(weight), "v3d_rmsnorm: alignment");
   if (rows == 0) return V3D_OK;
+  if (rows <= 4 && cols <= 4096) {     // decode rows: the fused decode linear's summation order (see the kernel)
+    V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(rmsnorm_decode_kernel<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                                              (const T*)x, (const T*)weight, (T*)out, cols, ldx, ldo, eps));
+    return check_launch("v3d_rmsnorm");
+  }
   V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                                             (hipStream_t)stream, (const T*)x, (const T*)weight, (T*)out, rows, cols, ldx, ldo, eps));
   return check_launch("v3d_rmsnorm");

@@ -465,6 +465,70 @@ class Engine:
         logits = self.llm_forward(x, 0)
         return self.decode_loop(logits, S, max_new_tokens, eos_token_id)
 
+    # ------------------------------------------------------------------ scenes decoding together
+    def new_group(self, n_scenes):
+        """Row buffers for up to 4 scenes whose decode steps run as ONE pass over the weights (the decode step is
+        HBM-bound on the 15 GB of weights: M scenes cost about what one does; every row's arithmetic is the
+        single-scene arithmetic, so grouping never changes a token)."""
+        if not 1 <= n_scenes <= 4:
+            raise V3DError("a decode group holds 1 to 4 scenes")
+        l = self.cfg.llm
+        z = lambda *s: torch.zeros(s, dtype=self.dtype, device=self.device)
+        g = SceneContext()
+        g.n = n_scenes
+        g.x, g.h, g.att = z(n_scenes, l.hidden), z(n_scenes, l.hidden), z(n_scenes, l.hidden)
+        g.qkv, g.act = z(n_scenes, self.l_nqkv), z(n_scenes, l.inter)
+        g.last, g.logits = z(n_scenes, l.hidden), z(n_scenes, self.l_head.shape[0])
+        one = ops.decode_workspace(l.heads, l.kv_heads, self.device)
+        g.ws = torch.empty(one.numel() * n_scenes, dtype=torch.float32, device=self.device)
+        g.amax_ws = torch.empty(256 * n_scenes, dtype=torch.float32, device=self.device)
+        return g
+
+    def decode_forward_rows(self, g, ctxs, positions):
+        """One new token for each of the M scenes (rows of g.x, in place) at its own position: per layer 4 weight-streaming
+        linears over all rows + one rotary/append and one split-KV attention launch pair covering all scenes."""
+        l = self.cfg.llm
+        M = len(ctxs)
+        hd, nh, nkv = self.hd, l.heads, l.kv_heads
+        kvw = nkv * hd
+        scale = 1.0 / math.sqrt(hd)
+        x, h, qkv, att, act = g.x[:M], g.h[:M], g.qkv[:M], g.att[:M], g.act[:M]
+        sk = [p + 1 for p in positions]
+        for i, L in enumerate(self.l_layers):
+            caches = [c.kv[i] for c in ctxs]
+            ops.rmsnorm(x, L["ln1"], l.eps, out=h)
+            ops.linear_decode_rows(h, L["wqkv"], qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
+            ops.rope_kv_append_rows(qkv, nh, nkv, hd, self.rope, positions, [c[p] for c, p in zip(caches, positions)])
+            ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws)
+            ops.linear_decode_rows(att, L["wo"], x, res=x, epilogue=ops.DEC_RES)
+            ops.rmsnorm(x, L["ln2"], l.eps, out=h)
+            ops.linear_decode_rows(h, L["wgu"], act, epilogue=ops.DEC_SWIGLU)
+            ops.linear_decode_rows(act, L["wd"], x, res=x, epilogue=ops.DEC_RES)
+        for c, p in zip(ctxs, positions):
+            c.kv_len = p + 1
+        ops.rmsnorm(x, self.l_norm, l.eps, out=g.last[:M])
+        ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
+        return g.logits[:M, : l.vocab]
+
+    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens):
+        """Greedy decoding of M prefilled scenes together (their prefill logits are in ctx.logits[0]); returns the token
+        ids [M, max_new_tokens] (device).  No EOS stop: callers trim per scene."""
+        l = self.cfg.llm
+        M = len(ctxs)
+        if M > g.n:
+            raise V3DError("decode group too small")
+        toks = torch.empty((max_new_tokens, M), dtype=torch.int64, device=self.device)
+        for m, c in enumerate(ctxs):
+            g.logits[m].copy_(c.logits[0])
+        logits = g.logits[:M, : l.vocab]
+        for step in range(max_new_tokens):
+            ops.argmax_rows(logits, toks[step], g.amax_ws)
+            if step + 1 == max_new_tokens:
+                break
+            ops.embed_gather(self.embed, toks[step], out=g.x[:M])
+            logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens])
+        return toks.t()
+
     def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None):
         """Greedy loop; token ids stay on the device (argmax kernel -> embedding gather), the host only
         synchronises per step when an EOS id has to be checked."""

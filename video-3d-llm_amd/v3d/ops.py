@@ -364,9 +364,52 @@ def linear_decode(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=None, ep
     return out
 
 
+def linear_decode_rows(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=None, epilogue=DEC_NONE):
+    """M = 1..4 activation rows x [M, K] against w [N, K] in ONE pass over the weights (scenes decoding together);
+    row m of out [M, N'] is bit-identical to linear_decode(x[m], ...)."""
+    N, K = w.shape
+    M = x.shape[0]
+    check(lib().v3d_linear_decode_rows(_p(x), x.stride(0), M, _p(norm_weight), eps, _p(w), w.stride(0), _p(bias), _p(res),
+                                       res.stride(0) if res is not None else 0, _p(out), out.stride(0), N, K, _code(x),
+                                       epilogue, _stream()), "v3d_linear_decode_rows")
+    return out
+
+
 def rope_kv_append(qkv_row, n_q, n_kv, hd, table, pos, cache_row):
     check(lib().v3d_rope_kv_append(_p(qkv_row), n_q, n_kv, hd, _p(table.cos), _p(table.sin), table.n_pos, pos,
                                    _p(cache_row), _code(qkv_row), _stream()), "v3d_rope_kv_append")
+
+
+def _host_ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _host_ints(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def rope_kv_append_rows(qkv, n_q, n_kv, hd, table, positions, cache_rows):
+    """qkv [M, n] rows of M scenes decoding together; positions / cache_rows: one per scene."""
+    check(lib().v3d_rope_kv_append_rows(_p(qkv), qkv.stride(0), qkv.shape[0], n_q, n_kv, hd, _p(table.cos), _p(table.sin),
+                                        table.n_pos, _host_ints(positions), _host_ptrs(cache_rows), _code(qkv), _stream()),
+          "v3d_rope_kv_append_rows")
+
+
+def attention_decode_rows(q, k_caches, v_caches, out, sk, n_heads, n_kv_heads, scale, workspace):
+    """q / out [M, Hq*128]; k_caches / v_caches: per-scene cache views [>=Sk, ...] sharing strides; sk: lengths."""
+    k0 = k_caches[0]
+    check(lib().v3d_attention_decode_rows(_p(q), q.stride(0), q.shape[0], _host_ptrs(k_caches), _host_ptrs(v_caches), _host_ints(sk),
+                                          _p(out), out.stride(0), _code(q), n_heads, n_kv_heads, k0.stride(0), v_caches[0].stride(0),
+                                          128, 128, 128, float(scale), _p(workspace), workspace.numel() * workspace.element_size(),
+                                          _stream()), "v3d_attention_decode_rows")
+    return out
+
+
+def argmax_rows(x, out, workspace):
+    """x [M, n] -> out int64 [M]; workspace >= M KiB."""
+    check(lib().v3d_argmax_rows(_p(x), x.stride(0), x.shape[0], x.shape[1], _code(x), _p(out), _p(workspace), _stream()),
+          "v3d_argmax_rows")
+    return out
 
 
 _argmax_ws = {}
