@@ -44,11 +44,10 @@ def synth_inputs(dev, dtype, seed):
     P[:, 0, 0], P[:, 0, 1], P[:, 1, 0], P[:, 1, 1] = torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)
     P[:, 2, 2] = P[:, 3, 3] = 1.0
     P[:, :3, 3] = torch.randn(F_, 3, generator=g, device=dev) * 1.5
-    rgb = torch.randint(0, 256, (F_, 3, 384, 384), generator=g, device=dev, dtype=torch.int32)
-    images = ((rgb.float() / 255.0 - 0.5) / 0.5).to(dtype)          # SigLipImageProcessor rescale+normalise
+    frames = torch.randint(0, 256, (F_, 384, 384, 3), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)   # RGB crops
     text = torch.randint(0, 151000, (TEXT_PRE + TEXT_POST,), generator=g, device=dev)
     input_ids = torch.cat([text[:TEXT_PRE], torch.tensor([IMAGE_TOKEN_INDEX], device=dev), text[TEXT_PRE:]]).cpu()
-    return dict(depth=depth, K=K, P=P, images=images, input_ids=input_ids)
+    return dict(depth=depth, K=K, P=P, frames=frames, input_ids=input_ids)
 
 
 class Stamp:
@@ -74,7 +73,8 @@ def prefill_phase(eng, ops, inp, stamps):
     dt = eng.dtype
     coords = ops.unproject_sampled(inp["depth"], inp["K"], inp["P"], 384, dt)           # K1+K2
     ids = eng.voxel_ids(coords)                                                         # K3+K4
-    feats = eng.encode_images(inp["images"])                                            # K10-K12
+    images = ops.preprocess_rgb(inp["frames"], dt)                                      # a7: rescale + normalise + CHW
+    feats = eng.encode_images(images)                                                   # K10-K12
     n_vis = FRAMES * 14 * 15
     S = TEXT_PRE + n_vis + TEXT_POST
     x = eng.l_x[:S]

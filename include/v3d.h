@@ -264,6 +264,12 @@ int v3d_ground_scores(const void* obj, int64_t ldo, int n_rows, const void* quer
 int v3d_copy_rows(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int dtype,
                   void* stream);
 
+/* a7: SigLipImageProcessor.preprocess, siglip_encoder.py:47-67, for frames that already have the tower's size (the
+ * 384 x 384 crops of VideoProcessor.preprocess, video_utils.py:292-308, for which its bicubic resize is the identity):
+ * frames [F,H,W,3] u8 (device) -> out [F,3,H,W];  v = f32(f64(u8) * rescale);  out = T((v - mean[c]) / std[c]) in f32. */
+int v3d_preprocess_rgb_u8(const uint8_t* frames, int F, int H, int W, const float* mean_host, const float* std_host,
+                          double rescale, void* out, int dtype, void* stream);
+
 /* K10 input: SigLipVisionEmbeddings' Conv2d(kernel = stride = patch), siglip_encoder.py:156-172, as a
  * GEMM: gathers images [B,3,S,S] into rows [B*(S/patch)^2, kpad], columns (c, ky, kx) zero padded. */
 int v3d_patchify(const void* images, void* out, int B, int S, int patch, int kpad, int dtype, void* stream);

@@ -472,6 +472,23 @@ def g_objects():
          query=q.numpy(), scores=scores.numpy(), dim_t=(10000 ** (2 * (d // 2) / (C // 3))).numpy(), **hw, **out)
 
 
+def g_imgproc():
+    """a7: SigLipImageProcessor.preprocess (siglip_encoder.py:47-67) on 384x384 RGB frames, the size VideoProcessor
+    hands over (video_utils.py:292-308), so the bicubic resize is the identity; plus one 40x56 frame that really resizes."""
+    from PIL import Image
+    from llava.model.multimodal_encoder import siglip_encoder as se
+    rng = np.random.default_rng(61)
+    frames = rng.integers(0, 256, size=(2, 384, 384, 3), dtype=np.uint8)
+    frames[0, :4, :4] = [[[0, 255, 128]]]
+    proc = se.SigLipImageProcessor()
+    pv = proc.preprocess([Image.fromarray(f) for f in frames], return_tensors="pt")["pixel_values"]
+    small = rng.integers(0, 256, size=(40, 56, 3), dtype=np.uint8)
+    pv_small = proc.preprocess([Image.fromarray(small)], return_tensors="pt")["pixel_values"]
+    assert pv.dtype == torch.float32 and tuple(pv.shape) == (2, 3, 384, 384)
+    save("imgproc", frames=frames[:, :96, :96].copy(), pixel_values=pv[:, :, :96, :96].numpy().copy(),
+         full_sum=np.array(pv.double().sum().item()), small=small, small_pixel_values=pv_small[0, :, ::16, ::16].numpy().copy())
+
+
 GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}
 
 

@@ -176,6 +176,15 @@ def sin3d_pe(xyz, embedding_size, out_kind="f32", dim_t=None, temperature=10000.
 # ----------------------------------------------------------------------------- K7  bilinear 2x pool
 
 
+def image_preprocess(frames_u8, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), rescale=1 / 255):
+    """a7, SigLipImageProcessor.preprocess (siglip_encoder.py:47-67) for frames already at the tower size (the bicubic
+    resize is then the identity): rescale in f64 -> f32 (transformers.image_transforms.rescale), (x - mean) / std in
+    f32 (normalize), HWC -> CHW.  frames_u8 [F,H,W,3] -> [F,3,H,W] f32."""
+    x = (frames_u8.astype(np.float64) * rescale).astype(np.float32)
+    x = (x - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
 def bilinear_taps(n_in=27, n_out=14):
     """Source taps of F.interpolate(mode='bilinear', align_corners=False) (ATen
     area_pixel_compute_source_index): src = scale*(o+0.5)-0.5 clamped at 0, scale = n_in/n_out in f32.

@@ -87,3 +87,18 @@ def test_llava_qwen_generate_and_grounding_call_contract():
     assert scores.shape == (6,) and torch.isfinite(scores.float()).all() and scores.float().abs().max() <= 1.001
     with pytest.raises(NotImplementedError):
         model.generate(input_ids, images=images, video_dict=video_dict, do_sample=True)
+
+
+def test_siglip_image_processor_mirror(golden):
+    """a7 through the reference's class name: PIL frames in, pixel_values out, equal to the reference's own output."""
+    from PIL import Image
+    from llava.model.multimodal_encoder.siglip_encoder import SigLipImageProcessor
+    g = golden("imgproc")
+    proc = SigLipImageProcessor(size=(96, 96), crop_size={"height": 96, "width": 96})
+    out = proc.preprocess([Image.fromarray(f) for f in g["frames"]], return_tensors="pt")["pixel_values"]
+    assert out.dtype == torch.float32 and tuple(out.shape) == (2, 3, 96, 96)
+    assert np.array_equal(out.cpu().numpy(), g["pixel_values"])
+    # a frame of another size goes through the same PIL bicubic call as the reference's transform chain
+    full = SigLipImageProcessor()
+    pv = full.preprocess(Image.fromarray(g["small"]))["pixel_values"]
+    assert np.array_equal(pv[0, :, ::16, ::16].cpu().numpy(), g["small_pixel_values"])

@@ -310,3 +310,21 @@ def test_bad_shapes_raise(ops):
         ops.visual_tokens(torch.zeros((1, 100, 64), device="cuda", dtype=torch.float16))
     with pytest.raises(V3DError):
         ops.coord_pool_voxel(torch.zeros((1, 384, 300, 3), device="cuda"))
+
+
+def test_preprocess_rgb_bit_exact(golden):
+    """a7 on the device vs the reference's own output (golden) and vs the oracle at the full 32 x 384 x 384 shape."""
+    import torch
+    from v3d import ops
+    from oracle import v3d_oracle as O
+    g = golden("imgproc")
+    got = ops.preprocess_rgb(torch.from_numpy(g["frames"]).cuda())
+    assert np.array_equal(got.cpu().numpy(), g["pixel_values"])
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, size=(32, 384, 384, 3), dtype=np.uint8)
+    want = O.image_preprocess(frames)
+    got = ops.preprocess_rgb(torch.from_numpy(frames).cuda())
+    assert np.array_equal(got.cpu().numpy(), want)
+    for dt in (torch.bfloat16, torch.float16):            # 16-bit output = one rounding of the f32 value
+        got16 = ops.preprocess_rgb(torch.from_numpy(frames[:2]).cuda(), dtype=dt)
+        assert torch.equal(got16.cpu(), torch.from_numpy(want[:2]).to(dt))

@@ -140,6 +140,13 @@ def test_fused_small(golden, kind):
         assert (seq != ref32).mean() < 2e-3
 
 
+def test_image_preprocess(golden):
+    """a7 against SigLipImageProcessor.preprocess itself (96 x 96 windows of two 384 x 384 frames): bit-exact."""
+    g = golden("imgproc")
+    got = O.image_preprocess(g["frames"])
+    assert got.dtype == np.float32 and np.array_equal(got, g["pixel_values"])
+
+
 def test_frame_sampling():
     with open(os.path.join(GOLDEN, "frame_sampling.json")) as f:
         g = json.load(f)

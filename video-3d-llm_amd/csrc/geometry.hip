@@ -243,6 +243,34 @@ extern "C" int v3d_unproject_f32(const float* depth_mm, const float* intrinsics,
   return check_launch("v3d_unproject_f32");
 }
 
+// a7: SigLipImageProcessor.preprocess (siglip_encoder.py:47-67) once the frame is 384 x 384 (VideoProcessor's crop,
+// video_utils.py:292-308): rescale = f32(f64(u8) * (1/255)), normalize = (v - mean) / std in f32, HWC -> CHW.
+// One thread = 4 pixels of one row (12 input bytes, three 4-element output runs).
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_rgb_kernel(const uint8_t* __restrict__ in, T* __restrict__ out, int64_t n_quads,
+                                                             int HW, float m0, float m1, float m2, float s0, float s1, float s2,
+                                                             double rescale) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n_quads) return;
+  const int64_t px = q * 4;                       // first pixel (HW % 4 == 0: the quad stays inside one frame)
+  const int64_t f = px / HW, rem = px - f * HW;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(in + px * 3);
+  const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+  uint8_t b[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { b[i] = (w0 >> (8 * i)) & 0xff; b[4 + i] = (w1 >> (8 * i)) & 0xff; b[8 + i] = (w2 >> (8 * i)) & 0xff; }
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    T* dst = out + (f * 3 + c) * (int64_t)HW + rem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v = (float)((double)b[3 * i + c] * rescale);
+      dst[i] = from_f32<T>((v - mean[c]) / sd[c]);
+    }
+  }
+}
+
 extern "C" int v3d_unproject_sampled_u16(const uint16_t* depth, const float* intrinsics, const float* poses,
                                          void* out, int out_dtype, int V, int H, int W, int crop, void* stream) {
   V3D_REQUIRE(depth && intrinsics && poses && out, "v3d_unproject_sampled_u16: null pointer");
@@ -312,4 +340,17 @@ extern "C" int v3d_coord_pool_voxel(const void* coords, int dtype, int V, int S,
     hipLaunchKernelGGL(k, dim3(n, V), dim3(256), lds, st, (const T*)coords, S, patch, n, rg, (T*)avg, (T*)vox, ids, vec_ok);
   });
   return check_launch("v3d_coord_pool_voxel");
+}
+
+extern "C" int v3d_preprocess_rgb_u8(const uint8_t* frames, int F, int H, int W, const float* mean_host, const float* std_host,
+                                     double rescale, void* out, int dtype, void* stream) {
+  V3D_REQUIRE(frames && mean_host && std_host && out, "v3d_preprocess_rgb_u8: null pointer");
+  V3D_REQUIRE(F > 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0, "v3d_preprocess_rgb_u8: H*W must be a multiple of 4");
+  V3D_REQUIRE((reinterpret_cast<uintptr_t>(frames) & 3) == 0, "v3d_preprocess_rgb_u8: frames must be 4-byte aligned");
+  const int64_t n_quads = (int64_t)F * H * W / 4;
+  const unsigned blocks = (unsigned)((n_quads + 255) / 256);
+  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(preprocess_rgb_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, frames,
+                                               (T*)out, n_quads, H * W, mean_host[0], mean_host[1], mean_host[2], std_host[0],
+                                               std_host[1], std_host[2], rescale));
+  return check_launch("v3d_preprocess_rgb_u8");
 }

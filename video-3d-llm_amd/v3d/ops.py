@@ -469,6 +469,20 @@ def copy_rows(src, dst, cols=None):
     return dst
 
 
+def preprocess_rgb(frames, dtype=torch.float32, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), rescale=1 / 255):
+    """frames [F,H,W,3] uint8 (device) -> pixel_values [F,3,H,W] (SigLipImageProcessor's rescale + normalize + CHW)."""
+    fr = _dev(frames, "frames")
+    if fr.dtype != torch.uint8 or fr.dim() != 4 or fr.shape[-1] != 3:
+        raise V3DError("preprocess_rgb wants [F,H,W,3] uint8 frames")
+    fr = fr.contiguous()
+    F_, H, W, _ = fr.shape
+    out = torch.empty((F_, 3, H, W), dtype=dtype, device=fr.device)
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    check(lib().v3d_preprocess_rgb_u8(_p(fr), F_, H, W, m, sd, float(rescale), _p(out), _DT[dtype], _stream()), "v3d_preprocess_rgb_u8")
+    return out
+
+
 def patchify(images, patch=14, kpad=640):
     B, C, S, _ = images.shape
     g = S // patch
