@@ -288,6 +288,23 @@ int v3d_greedy_cover_host(const int32_t* keys_host, int n_frames, int64_t pts_pe
                           const int32_t* scene_host, int64_t m, int max_frames, int32_t* sel_host,
                           int64_t* gain_host, int64_t* num_all_host, int64_t* num_sel_host);
 
+/* ------------------------------------------------------------------ a3 on the device ---- */
+
+/* scripts/3d/preprocessing/max_coverage_sampling.py:44-45: keys = round(xyz / voxel_size) as int32 (f32 division,
+ * round half to even).  xyz / keys: n_values scalars (3 per point), device. */
+int v3d_voxel_keys_f32(const float* xyz, int64_t n_values, float voxel_size, int32_t* keys, void* stream);
+
+/* The greedy max-coverage loop of max_coverage_sampling.py:46-94 on the device, same contract and tie rule as
+ * v3d_greedy_cover_host.  keys [n_frames, pts_per_frame, 3] and scene [m,3] int32 in HBM; outputs in HBM:
+ * sel[max_frames] (frame positions), gain[max_frames] (voxel_nums), totals[2] = {num_all_voxels, num_select_voxels},
+ * n_sel[1] = number of picks.  Stream-ordered, no host synchronisation.  Coordinates must lie in [-2^20, 2^20): a
+ * scene key outside sets the int at workspace byte offset (workspace_bytes_needed - 256) to 1 (the wrapper raises);
+ * frame keys outside can never match a scene voxel and are ignored. */
+int64_t v3d_greedy_cover_workspace_bytes(int n_frames, int64_t m);
+int v3d_greedy_cover(const int32_t* keys, int n_frames, int64_t pts_per_frame, const int32_t* scene, int64_t m,
+                     int max_frames, int32_t* sel, int64_t* gain, int64_t* totals, int32_t* n_sel, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,6 +195,41 @@ def uniform_frame_indices(total_frames, n):
     return list(out)
 
 
+def voxel_keys(xyz, voxel_size=0.1):
+    """round(xyz / voxel_size) as int32 (max_coverage_sampling.py:44-45) for an f32 device tensor [..., 3]."""
+    x = _dev(xyz, "xyz")
+    if x.dtype != torch.float32:
+        raise V3DError("voxel_keys wants f32 coordinates")
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    check(lib().v3d_voxel_keys_f32(_p(x), x.numel(), float(voxel_size), _p(out), _stream()), "v3d_voxel_keys_f32")
+    return out
+
+
+def greedy_cover_device(keys, scene_voxels, max_frames=32):
+    """a3 on the device: keys [n_frames, pts, 3] int32, scene_voxels [m, 3] int32 (both in HBM).
+    Returns (sel, gains, num_all_voxels, num_select_voxels) like greedy_cover (host); synchronises to read them."""
+    k = _dev(keys, "keys")
+    sc = _dev(scene_voxels, "scene_voxels")
+    if k.dtype != torch.int32 or sc.dtype != torch.int32 or k.dim() != 3 or k.shape[-1] != 3:
+        raise V3DError("greedy_cover_device wants int32 keys [n_frames, pts, 3] and scene [m, 3]")
+    k, sc = k.contiguous(), sc.contiguous().reshape(-1, 3)
+    n_frames, pts, m = k.shape[0], k.shape[1], sc.shape[0]
+    need = lib().v3d_greedy_cover_workspace_bytes(n_frames, m)
+    ws = torch.empty(need, dtype=torch.uint8, device=k.device)
+    sel = torch.zeros(max_frames, dtype=torch.int32, device=k.device)
+    gain = torch.zeros(max_frames, dtype=torch.int64, device=k.device)
+    totals = torch.zeros(2, dtype=torch.int64, device=k.device)
+    n_sel = torch.zeros(1, dtype=torch.int32, device=k.device)
+    check(lib().v3d_greedy_cover(_p(k), n_frames, pts, _p(sc) if m else None, m, max_frames, _p(sel), _p(gain), _p(totals), _p(n_sel),
+                                 _p(ws), need, _stream()), "v3d_greedy_cover")
+    if int(ws[need - 256: need - 252].view(torch.int32)[0]):
+        raise V3DError("v3d_greedy_cover: scene voxel coordinate outside [-2^20, 2^20)")
+    n = int(n_sel[0])
+    t = totals.tolist()
+    return sel[:n].cpu().numpy(), gain[:n].cpu().numpy(), t[0], t[1]
+
+
 def greedy_cover(keys, scene_voxels, max_frames=32):
     """a3.  keys [n_frames, pts, 3] int32 (numpy), scene_voxels [m,3] int32 ->
     (sel, gains, num_all_voxels, num_select_voxels)."""
