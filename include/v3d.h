@@ -225,6 +225,12 @@ int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const v
 int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W,
                            int64_t ldw, const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N,
                            int K, int dtype, int epilogue, void* stream);
+/* The decode linear over OCP e4m3 weights (BASELINE configs[3]; W8A16): W8 [N,K] bytes (row stride ldw) with one
+ * f32 scale per output row as v3d_quantize_fp8_rows writes them; y[m,n] = scale_w[n] * sum_k W8[n,k] x[m,k], then
+ * the epilogue of v3d_linear_decode.  K % 16 == 0.  Not a reference code path (tolerance: tests/test_gpu_fp8.py). */
+int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8, int64_t ldw, const float* scale_w,
+                               const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K,
+                               int dtype, int epilogue, void* stream);
 
 /* Decode-step K14 + cache append in one launch: rotary at position `pos` on the n_q + n_kv heads at the start
  * of the QKV row (in place), rotated k and v copied to cache_row = [k heads | v heads]. */

@@ -138,3 +138,44 @@ def test_engine_prefill_fp8_close_to_bf16():
     tok[0] = x[5]
     lb2 = b.decode_forward(tok, 300)
     assert torch.isfinite(lb2).all()
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("K,N", [(3584, 512), (18944, 256), (256, 384)])
+def test_linear_decode_fp8_rows(M, K, N):
+    """W8A16 decode linear: e4m3 weights (per-row scales) x 16-bit activations, against an f64 product of the SAME
+    dequantised weights: only f32 accumulation and the output rounding remain (|err| <= 2^-8 |ref| + 2^-9 rms)."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(7 * M + K)
+    x = torch.randn(M, K, generator=g).to(dt).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
+    qw, sw = ops.quantize_fp8_rows(w)
+    wd = _deq(qw, sw)                                            # [N, K] f64
+    ref = x.double() @ wd.T
+    b = torch.randn(N, generator=g).to(dt).to(DEV)
+    r = torch.randn(M, N, generator=g).to(dt).to(DEV)
+
+    def check(out, want, slack=1.0):
+        rms = want.pow(2).mean().sqrt()
+        err = (out.double() - want).abs()
+        bound = slack * (2.0 ** -8 * want.abs() + 2.0 ** -9 * rms)
+        assert bool((err <= bound).all()), (err - bound).max().item()
+
+    out = torch.empty(M, N, dtype=dt, device=DEV)
+    ops.linear_decode_fp8_rows(x, qw, sw, out)
+    check(out, ref)
+    ops.linear_decode_fp8_rows(x, qw, sw, out, bias=b, epilogue=ops.DEC_BIAS)
+    check(out, ref + b.double())
+    ops.linear_decode_fp8_rows(x, qw, sw, out, res=r, epilogue=ops.DEC_RES)
+    check(out, ref.to(dt).double() + r.double(), slack=3.0)
+    if N % 128 == 0:
+        act = torch.empty(M, N // 2, dtype=dt, device=DEV)
+        ops.linear_decode_fp8_rows(x, qw, sw, act, epilogue=ops.DEC_SWIGLU)
+        rr = ref.to(dt).float().view(M, N // 128, 2, 64)
+        want = (torch.nn.functional.silu(rr[:, :, 0]).to(dt).float() * rr[:, :, 1]).reshape(M, N // 2).double()
+        check(act, want, slack=4.0)
+    # a row's result does not depend on the other rows of the batch
+    one = torch.empty(1, N, dtype=dt, device=DEV)
+    ops.linear_decode_fp8_rows(x[M - 1: M], qw, sw, one)
+    ops.linear_decode_fp8_rows(x, qw, sw, out)
+    assert torch.equal(out[M - 1], one[0])

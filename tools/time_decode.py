@@ -46,6 +46,26 @@ for M in (2, 4):
     tm("lm_head", 152064, 3584, 0, M, iters=12)
     tm("qkv-nonorm", 4608, 3584, 1, M)
     tm("gu-nonorm", 37888, 3584, 3, M)
+def tm8(name, N, K, epi, M, iters=40):
+    x = torch.randn(M, K, device="cuda", dtype=dt)
+    ws = [ops.quantize_fp8_rows(torch.randn(N, K, device="cuda", dtype=dt) * 0.02) for _ in range(4)]
+    r = torch.zeros(M, N, device="cuda", dtype=dt)
+    out = torch.empty(M, N // 2 if epi == 3 else N, device="cuda", dtype=dt)
+    f = lambda w: ops.linear_decode_fp8_rows(x, w[0], w[1], out, res=r if epi == 2 else None, epilogue=epi)
+    for w in ws: f(w)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters): f(ws[i % 4])
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"fp8 {name:8s} M={M} N={N:6d} K={K:6d} {us:8.1f} us  {N*K/us/1e6:6.2f} TB/s")
+for M in (1, 4):
+    tm8("qkv", 4608, 3584, 0, M)
+    tm8("o_proj", 3584, 3584, 2, M)
+    tm8("gate_up", 37888, 3584, 3, M)
+    tm8("down", 3584, 18944, 2, M)
+    tm8("lm_head", 152064, 3584, 0, M, iters=12)
 # decode attention
 H, KV, D, Sk = 28, 4, 128, 6800
 q = torch.randn(H * D, device="cuda", dtype=dt)

@@ -158,6 +158,98 @@ __global__ __launch_bounds__(256, M == 1 ? 8 : 4) void linear_decode_kernel(
   }
 }
 
+// The same weight-streaming linear over OCP e4m3 weights (BASELINE configs[3]): W8 [N, K] bytes with one f32 scale per
+// output row (v3d_quantize_fp8_rows), activations stay 16-bit (W8A16): y[n] = sw[n] * sum_k q[n,k] x[k].  Half the
+// bytes of the 16-bit kernel per step; a 16-byte chunk is 16 weights (two x vectors).  No fused norm (callers
+// normalise with v3d_rmsnorm first).
+template <typename T, int EPI, int M>
+__global__ __launch_bounds__(256, 4) void linear_decode_fp8_kernel(
+    const T* __restrict__ x, int64_t ldx, const uint8_t* __restrict__ W, int64_t ldw, const float* __restrict__ sw,
+    const T* __restrict__ bias, const T* __restrict__ res, int64_t ldr, T* __restrict__ out, int64_t ldo, int N, int K) {
+  __shared__ float red[M][4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kv = K / 16;
+  int rows[4];
+  int o0;
+  if (EPI == DEC_EPI_SWIGLU) {
+    o0 = blockIdx.x * 2;
+    rows[0] = (o0 >> 6) * 128 + (o0 & 63); rows[1] = rows[0] + 64;
+    rows[2] = ((o0 + 1) >> 6) * 128 + ((o0 + 1) & 63); rows[3] = rows[2] + 64;
+  } else {
+    o0 = blockIdx.x * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows[r] = o0 + r;
+  }
+  float s[M][4];
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[m][r] = 0.f;
+  const uint4* wr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) wr[r] = reinterpret_cast<const uint4*>(W + (int64_t)rows[r] * ldw);
+#pragma unroll 2
+  for (int k = tid; k < kv; k += 256) {
+    uint4 w4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w4[r] = ldg_nt(wr[r] + k);
+    float xf[M][16];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const uint4* xr = reinterpret_cast<const uint4*>(x + m * ldx) + 2 * k;
+      const uint4 x0 = xr[0], x1 = xr[1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xf[m][j] = vec_get<T>(x0, j); xf[m][8 + j] = vec_get<T>(x1, j); }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t ww[4] = {w4[r].x, w4[r].y, w4[r].z, w4[r].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)ww[q], false);     // bytes 0,1
+        const auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)ww[q], true);      // bytes 2,3
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          s[m][r] = fmaf(lo[0], xf[m][4 * q + 0], s[m][r]);
+          s[m][r] = fmaf(lo[1], xf[m][4 * q + 1], s[m][r]);
+          s[m][r] = fmaf(hi[0], xf[m][4 * q + 2], s[m][r]);
+          s[m][r] = fmaf(hi[1], xf[m][4 * q + 3], s[m][r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[m][r] += __shfl_xor(s[m][r], off);
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[m][r][wave] = s[m][r];
+  }
+  __syncthreads();
+  if (EPI == DEC_EPI_SWIGLU) {
+    if (tid < 2 * M) {
+      const int m = tid >> 1, t2 = tid & 1;
+      const float g = round_to<T>((red[m][2 * t2][0] + red[m][2 * t2][1] + red[m][2 * t2][2] + red[m][2 * t2][3]) * sw[rows[2 * t2]]);
+      const float u = round_to<T>((red[m][2 * t2 + 1][0] + red[m][2 * t2 + 1][1] + red[m][2 * t2 + 1][2] + red[m][2 * t2 + 1][3]) * sw[rows[2 * t2 + 1]]);
+      out[m * ldo + o0 + t2] = from_f32<T>(round_to<T>(silu_f(g)) * u);
+    }
+  } else if (tid < 4 * M) {
+    const int m = tid >> 2, r = tid & 3;
+    const int n = o0 + r;
+    float v = (red[m][r][0] + red[m][r][1] + red[m][r][2] + red[m][r][3]) * sw[n];
+    if (EPI == DEC_EPI_BIAS) v += to_f32(bias[n]);
+    v = round_to<T>(v);
+    if (EPI == DEC_EPI_RES) v += to_f32(res[m * ldr + n]);
+    out[m * ldo + n] = from_f32<T>(v);
+  }
+}
+
 // rotary (apply_rotary_pos_emb, modeling_qwen2.py:141-173) on the new token's q and k heads, in place in the
 // QKV row, and append of k (rotated) and v to cache row `pos`:  cache_row = [k heads | v heads].
 struct RopeRows {        // scenes decoding together (blockIdx.y = scene): own position and cache row
@@ -297,6 +389,39 @@ extern "C" int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const v
                                       int K, int dtype, int epilogue, void* stream) {
   return linear_decode_rows(x, ldx, M, norm_weight, eps, W, ldw, bias, res, ldr, out, ldo, N, K, dtype, epilogue, stream,
                             "v3d_linear_decode_rows");
+}
+
+extern "C" int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8, int64_t ldw, const float* scale_w,
+                                          const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K,
+                                          int dtype, int epilogue, void* stream) {
+  const char* who = "v3d_linear_decode_fp8_rows";
+  V3D_REQUIRE(x && W8 && scale_w && out, "%s: null pointer", who);
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
+  V3D_REQUIRE(M >= 1 && M <= 4, "%s: 1 to 4 activation rows (got %d)", who, M);
+  V3D_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldw % 16 == 0 && ldw >= K, "%s: bad shape N=%d K=%d", who, N, K);
+  V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
+  V3D_REQUIRE(aligned16(x) && aligned16(W8) && (M == 1 || (ldx % 8 == 0 && ldx >= K)), "%s: alignment", who);
+  V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "%s: bias epilogue without bias", who);
+  V3D_REQUIRE(epilogue != DEC_EPI_RES || res, "%s: residual epilogue without residual", who);
+  const int blocks = N / 4;
+  hipStream_t st = (hipStream_t)stream;
+#define V3D_LD8(TT, EE, MM)                                                                                                   \
+  hipLaunchKernelGGL((linear_decode_fp8_kernel<TT, EE, MM>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, (const uint8_t*)W8, ldw, \
+                     scale_w, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LD8_M(TT, EE)                                                                             \
+  switch (M) { case 1: V3D_LD8(TT, EE, 1); break; case 2: V3D_LD8(TT, EE, 2); break;                  \
+               case 3: V3D_LD8(TT, EE, 3); break; default: V3D_LD8(TT, EE, 4); break; }
+#define V3D_LD8_E(TT)                                                                                 \
+  switch (epilogue) {                                                                                 \
+    case DEC_EPI_NONE: V3D_LD8_M(TT, DEC_EPI_NONE) break; case DEC_EPI_BIAS: V3D_LD8_M(TT, DEC_EPI_BIAS) break; \
+    case DEC_EPI_RES: V3D_LD8_M(TT, DEC_EPI_RES) break; case DEC_EPI_SWIGLU: V3D_LD8_M(TT, DEC_EPI_SWIGLU) break; \
+    default: set_error("%s: unknown epilogue %d", who, epilogue); return V3D_E_INVALID;               \
+  }
+  if (dtype == V3D_BF16) { V3D_LD8_E(bf16_t) } else { V3D_LD8_E(f16_t) }
+#undef V3D_LD8_E
+#undef V3D_LD8_M
+#undef V3D_LD8
+  return check_launch(who);
 }
 
 static int rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,

@@ -138,9 +138,9 @@ class Engine:
     VIT_DP = 96      # SigLIP head dim 72, zero padded to the attention kernel's 96
 
     def __init__(self, cfg: EngineConfig, state_dict, dtype=torch.bfloat16, device="cuda", max_frames=32, llm_fp8=False):
-        """llm_fp8: run the four decoder linears of the PREFILL in OCP e4m3 (weights quantised once per output row,
-        activations per token row per call; BASELINE configs[3]).  The ViT, attention, norms, the residual stream and
-        the single-token decode stay in `dtype`."""
+        """llm_fp8 (BASELINE configs[3]): the decoder linears and the LM head use OCP e4m3 weights, quantised once per
+        output row; the prefill also quantises the activations per token row (W8A8, MFMA), the decode step keeps them
+        16-bit (W8A16, weight streaming).  The ViT, attention, norms and the residual stream stay in `dtype`."""
         self.cfg, self.dtype, self.device, self.llm_fp8 = cfg, dtype, device, bool(llm_fp8)
         v, l = cfg.vit, cfg.llm
         self.hd = l.hidden // l.heads
@@ -226,6 +226,8 @@ class Engine:
         self.l_nqkv = self.l_layers[0]["wqkv"].shape[0] if self.l_layers else 0
         self.l_norm = sd["model.norm.weight"].contiguous()
         self.l_head = _pad2(sd["lm_head.weight"], _up(l.vocab, 128), l.hidden)
+        if self.llm_fp8:
+            self.l_head8 = ops.quantize_fp8_rows(self.l_head)
 
     # ------------------------------------------------------------------ workspaces
     def _alloc(self, max_frames):
@@ -395,13 +397,25 @@ class Engine:
         """final RMSNorm + LM head on ONE row (K18: only the last position feeds generation)."""
         l = self.cfg.llm
         ops.rmsnorm(x_row, self.l_norm, l.eps, out=self.l_last[:1])
-        ops.linear_decode(self.l_last[0], self.l_head, self.logits[0])
+        if self.llm_fp8:
+            ops.linear_decode_fp8_rows(self.l_last[:1], *self.l_head8, self.logits[:1])
+        else:
+            ops.linear_decode(self.l_last[0], self.l_head, self.logits[0])
         return self.logits[0, : l.vocab]
 
     def decode_forward(self, x_row, pos):
         """One new token (x_row [1, hidden], in place) at position `pos`: 7 launches per layer, no host sync.
         RMSNorms are fused into the QKV / gate-up linears, rotary + cache append into one kernel."""
         l = self.cfg.llm
+        if self.llm_fp8:                  # e4m3 weights: the row goes through the (unfused-norm) rows path as a group of one
+            g = getattr(self.ctx, "g1", None)
+            if g is None:
+                g = self.ctx.g1 = self.new_group(1)
+            g.x[:1].copy_(x_row)
+            logits = self.decode_forward_rows(g, [self.ctx], [pos])[0]
+            x_row.copy_(g.x[:1])
+            self.l_last[:1].copy_(g.last[:1])
+            return logits
         hd, nh, nkv = self.hd, l.heads, l.kv_heads
         kvw = nkv * hd
         scale = 1.0 / math.sqrt(hd)
@@ -494,20 +508,29 @@ class Engine:
         scale = 1.0 / math.sqrt(hd)
         x, h, qkv, att, act = g.x[:M], g.h[:M], g.qkv[:M], g.att[:M], g.act[:M]
         sk = [p + 1 for p in positions]
+        if self.llm_fp8:                  # configs[3]: e4m3 weights, 16-bit activations (W8A16) - half the bytes per step
+            def lin(a, L, key, out, **kw):
+                return ops.linear_decode_fp8_rows(a, *L[key + "8"], out, **kw)
+        else:
+            def lin(a, L, key, out, **kw):
+                return ops.linear_decode_rows(a, L[key], out, **kw)
         for i, L in enumerate(self.l_layers):
             caches = [c.kv[i] for c in ctxs]
             ops.rmsnorm(x, L["ln1"], l.eps, out=h)
-            ops.linear_decode_rows(h, L["wqkv"], qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
+            lin(h, L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
             ops.rope_kv_append_rows(qkv, nh, nkv, hd, self.rope, positions, [c[p] for c, p in zip(caches, positions)])
             ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws)
-            ops.linear_decode_rows(att, L["wo"], x, res=x, epilogue=ops.DEC_RES)
+            lin(att, L, "wo", x, res=x, epilogue=ops.DEC_RES)
             ops.rmsnorm(x, L["ln2"], l.eps, out=h)
-            ops.linear_decode_rows(h, L["wgu"], act, epilogue=ops.DEC_SWIGLU)
-            ops.linear_decode_rows(act, L["wd"], x, res=x, epilogue=ops.DEC_RES)
+            lin(h, L, "wgu", act, epilogue=ops.DEC_SWIGLU)
+            lin(act, L, "wd", x, res=x, epilogue=ops.DEC_RES)
         for c, p in zip(ctxs, positions):
             c.kv_len = p + 1
         ops.rmsnorm(x, self.l_norm, l.eps, out=g.last[:M])
-        ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
+        if self.llm_fp8:
+            ops.linear_decode_fp8_rows(g.last[:M], *self.l_head8, g.logits[:M])
+        else:
+            ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
         return g.logits[:M, : l.vocab]
 
     def decode_group(self, g, ctxs, prompt_lens, max_new_tokens):

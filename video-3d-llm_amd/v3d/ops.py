@@ -410,6 +410,16 @@ def linear_decode_rows(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=Non
     return out
 
 
+def linear_decode_fp8_rows(x, qw, sw, out, bias=None, res=None, epilogue=DEC_NONE):
+    """x [M, K] 16-bit rows against e4m3 weights qw [N, K] (uint8) with row scales sw [N] (W8A16 decode, configs[3])."""
+    N, K = qw.shape
+    M = x.shape[0]
+    check(lib().v3d_linear_decode_fp8_rows(_p(x), x.stride(0), M, _p(qw), qw.stride(0), _p(sw), _p(bias), _p(res),
+                                           res.stride(0) if res is not None else 0, _p(out), out.stride(0), N, K, _code(x),
+                                           epilogue, _stream()), "v3d_linear_decode_fp8_rows")
+    return out
+
+
 def rope_kv_append(qkv_row, n_q, n_kv, hd, table, pos, cache_row):
     check(lib().v3d_rope_kv_append(_p(qkv_row), n_q, n_kv, hd, _p(table.cos), _p(table.sin), table.n_pos, pos,
                                    _p(cache_row), _code(qkv_row), _stream()), "v3d_rope_kv_append")
