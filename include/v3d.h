@@ -201,7 +201,7 @@ int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits);
 int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int Sk,
                          int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
                          void* workspace, int64_t workspace_bytes, void* stream);
-/* The same for M = 1..4 scenes decoding together in ONE launch pair (the single-scene kernels are latency-bound, not
+/* The same for M = 1..16 scenes decoding together in ONE launch pair (the single-scene kernels are latency-bound, not
  * bandwidth-bound): query rows q + m*q_stride, outputs o + m*o_stride (elements), per-scene cache pointers and lengths
  * in HOST arrays of M entries; workspace >= M * v3d_attention_decode_workspace_bytes(Hq, 1024/Hkv).  Scene m's output
  * is bit-identical to v3d_attention_decode on it alone when all scenes have the same length; with different lengths
@@ -219,9 +219,12 @@ enum { V3D_DEC_NONE = 0, V3D_DEC_BIAS = 1, V3D_DEC_RES = 2, V3D_DEC_SWIGLU = 3 }
 int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const void* W, int64_t ldw,
                       const void* bias, const void* res, void* out, int N, int K, int dtype, int epilogue,
                       void* stream);
-/* The same linear for M = 1..4 activation rows at once (M scenes decoding together share one pass over the
- * weights; the step is HBM-bound on them).  x [M, K] row stride ldx, res [M, N] row stride ldr, out [M, N'] row
- * stride ldo.  Row m's result is bit-identical to v3d_linear_decode on that row alone. */
+/* The same linear for M activation rows at once (M scenes decoding together share one pass over the weights; the
+ * step is HBM-bound on them).  x [M, K] row stride ldx, res [M, N] row stride ldr, out [M, N'] row stride ldo.
+ * M = 1..4: row m's result is bit-identical to v3d_linear_decode on that row alone.  M = 5..16 (no fused norm,
+ * K % 64 == 0, N % 16 == 0): the weights feed the matrix cores straight from HBM (v_mfma_f32_16x16x32, activation rows
+ * as the B operand), so the cost does not grow with M; same values up to the f32 summation order, and a row's result
+ * still does not depend on the other rows. */
 int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W,
                            int64_t ldw, const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N,
                            int K, int dtype, int epilogue, void* stream);
@@ -236,7 +239,7 @@ int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8
  * of the QKV row (in place), rotated k and v copied to cache_row = [k heads | v heads]. */
 int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
                        const void* sin_table, int n_pos, int pos, void* cache_row, int dtype, void* stream);
-/* M = 1..4 scenes in one launch: QKV rows qkv + m*qkv_stride, positions pos[m] and cache rows cache_rows[m] (HOST arrays). */
+/* M = 1..16 scenes in one launch: QKV rows qkv + m*qkv_stride, positions pos[m] and cache rows cache_rows[m] (HOST arrays). */
 int v3d_rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_heads, int n_kv_heads, int head_dim,
                             const void* cos_table, const void* sin_table, int n_pos, const int* pos,
                             void* const* cache_rows, int dtype, void* stream);

@@ -240,3 +240,49 @@ def test_decode_group_ragged_lengths_close_to_single_scene():
 def ops_embed(eng, tok, ctx, S):
     from v3d import ops
     return ops.embed_gather(eng.embed, tok, out=ctx.l_x[S: S + 1])
+
+
+def test_decode_group_of_six_matrix_core_form():
+    """Groups above four scenes use the matrix-core decode linear (other f32 summation order): tokens equal the
+    single-scene tokens unless the single-scene top-2 logit margin at that step is inside the rounding noise."""
+    from v3d.engine import Engine, random_state_dict
+    from v3d import ops
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=13, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    g = torch.Generator().manual_seed(14)
+    M, steps = 6, 6
+    scenes = []
+    for _ in range(M):
+        images = torch.randn(2, 3, 384, 384, generator=g).cuda()
+        coords = ((torch.rand(2, 384, 384, 3, generator=g) - 0.5) * 20).cuda()
+        t = torch.randint(0, 320, (18,), generator=g)
+        scenes.append((torch.cat([t[:7], torch.tensor([PO.IMAGE_TOKEN_INDEX]), t[7:]]), images, coords))
+    alone, margins = [], []
+    for ids, im, wc in scenes:                      # single-scene greedy loop, keeping every step's logits
+        c = eng.new_context()
+        S = _prefill(eng, c, ids, im, wc)
+        logits = c.logits[0, : cfg.llm.vocab]
+        toks, mg = [], []
+        for st in range(steps):
+            top2 = torch.topk(logits.float(), 2).values
+            mg.append(((top2[0] - top2[1]) / logits.float().abs().max()).item())
+            tok = torch.zeros(1, dtype=torch.int64, device="cuda")
+            ops.argmax(logits, tok)
+            toks.append(int(tok))
+            if st + 1 < steps:
+                xe = ops.embed_gather(eng.embed, tok, out=c.l_x[S + st: S + st + 1])
+                logits = eng.decode_forward(xe, S + st)
+        alone.append(toks)
+        margins.append(mg)
+    ctxs = [eng.new_context() for _ in range(M)]
+    lens = [_prefill(eng, c, *sc) for c, sc in zip(ctxs, scenes)]
+    toks = eng.decode_group(eng.new_group(M), ctxs, lens, steps).tolist()
+    same = 0
+    for m in range(M):
+        for st in range(steps):
+            if toks[m][st] != alone[m][st]:
+                assert margins[m][st] < 0.02, (m, st, toks[m], alone[m], margins[m][st])
+                break
+            same += 1
+    assert same >= M * steps // 2

@@ -233,10 +233,12 @@ def test_linear_decode_fused_variants(ops, kind):
     close(act, want, kind, ulps=3.0, floor=0.3)
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4])
-@pytest.mark.parametrize("K,N", [(512, 384), (3584, 512), (4736, 256)])
-def test_linear_decode_rows_bit_identical_to_single_rows(ops, M, K, N):
-    """Scenes decoding together share one pass over the weights; a row's result must not depend on its batch."""
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 16])
+@pytest.mark.parametrize("K,N", [(512, 384), (3584, 512), (4736, 256), (18944, 128), (520, 36)])
+def test_linear_decode_rows(ops, M, K, N):
+    """Scenes decoding together share one pass over the weights.  1..4 rows (VALU form): bit-identical to the single-row
+    kernel.  5..16 rows (matrix-core form): a row's result does not depend on the other rows (bit for bit), and equals the
+    single-row result up to the f32 summation order (checked against an f64 reference: 2^-7 |ref| + 2^-8 rms)."""
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(100 + M)
     x = torch.randn(M, K, generator=g).to(dt).cuda()
@@ -245,21 +247,48 @@ def test_linear_decode_rows_bit_identical_to_single_rows(ops, M, K, N):
     b = torch.randn(N, generator=g).to(dt).cuda()
     r = torch.randn(M, N, generator=g).to(dt).cuda()
     cases = [dict(), dict(bias=b, epilogue=ops.DEC_BIAS), dict(res=r, epilogue=ops.DEC_RES), dict(epilogue=ops.DEC_SWIGLU)]
-    if K <= 4096:
+    mfma_shape = K % 64 == 0 and N % 16 == 0
+    if M > 4 and not mfma_shape:
+        with pytest.raises(Exception, match="activation rows"):
+            ops.linear_decode_rows(x, w, torch.empty((M, N), dtype=dt, device="cuda"))
+        return
+    if K <= 4096 and M <= 4:
         cases += [dict(norm_weight=lnw, eps=1e-6, bias=b, epilogue=ops.DEC_BIAS), dict(norm_weight=lnw, eps=1e-6, epilogue=ops.DEC_SWIGLU)]
     for kw in cases:
-        n_out = N // 2 if kw.get("epilogue") == ops.DEC_SWIGLU else N
-        if kw.get("epilogue") == ops.DEC_SWIGLU and N % 128:
+        swiglu = kw.get("epilogue") == ops.DEC_SWIGLU
+        n_out = N // 2 if swiglu else N
+        if swiglu and N % 128:
             continue
         got = torch.full((M, n_out), 7.0, dtype=dt, device="cuda")
         ops.linear_decode_rows(x, w, got, **kw)
-        for m in range(M):
-            one = torch.empty(n_out, dtype=dt, device="cuda")
-            kw1 = dict(kw)
-            if "res" in kw1:
-                kw1["res"] = r[m]
-            ops.linear_decode(x[m], w, one, **kw1)
-            assert torch.equal(got[m], one), (kw.get("epilogue"), m)
+        if M <= 4:
+            for m in range(M):
+                one = torch.empty(n_out, dtype=dt, device="cuda")
+                kw1 = dict(kw)
+                if "res" in kw1:
+                    kw1["res"] = r[m]
+                ops.linear_decode(x[m], w, one, **kw1)
+                assert torch.equal(got[m], one), (kw.get("epilogue"), m)
+        else:       # independence of the other rows: the same rows inside another batch (first 5 of them, shuffled partners)
+            sub = torch.empty((5, n_out), dtype=dt, device="cuda")
+            kw5 = dict(kw)
+            if "res" in kw5:
+                kw5["res"] = r[M - 5:]
+            ops.linear_decode_rows(x[M - 5:], w, sub, **kw5)
+            assert torch.equal(sub, got[M - 5:])
+        if "norm_weight" not in kw and not swiglu:       # and the values are right (f64 reference)
+            ref = x.double() @ w.double().t()
+            if "bias" in kw:
+                ref = ref + b.double()
+            if "res" in kw:
+                ref = ref.to(dt).double() + r.double()
+            err = (got.double() - ref).abs()
+            assert bool((err <= 2.0 ** -7 * ref.abs() + 2.0 ** -8 * ref.pow(2).mean().sqrt()).all())
+        if swiglu and "norm_weight" not in kw:
+            rr = (x.double() @ w.double().t()).to(dt).float().view(M, N // 128, 2, 64)
+            want = (F.silu(rr[:, :, 0]).to(dt).float() * rr[:, :, 1]).reshape(M, N // 2).double()
+            err = (got.double() - want).abs()
+            assert bool((err <= 2.0 ** -6 * want.abs() + 2.0 ** -6 * want.pow(2).mean().sqrt()).all())
 
 
 def test_rope_kv_append_and_argmax(ops):

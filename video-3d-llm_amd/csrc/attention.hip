@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 // the workspace; a second tiny kernel merges the splits.  HBM-bound: cache bytes read once.
 // ------------------------------------------------------------------------------------------
 constexpr int DEC_MAXG = 8;
-constexpr int DEC_MAXROWS = 4;
+constexpr int DEC_MAXROWS = 16;
 
 // Scenes decoding together (blockIdx.z = scene): each has its own cache, length, query row and workspace slice.
 struct DecRows {

@@ -158,6 +158,99 @@ __global__ __launch_bounds__(256, M == 1 ? 8 : 4) void linear_decode_kernel(
   }
 }
 
+// Matrix-core form of the decode linear for up to 16 activation rows (scenes decoding together): the weights are the
+// MFMA A operand straight from HBM - lane (r, g) of v_mfma_f32_16x16x32 holds W[row0 + r][k0 + 8g .. +8), one 16-byte
+// non-temporal load, no LDS - and the activation rows are the B operand (x[m][k0 + 8g .. +8) for column m < M, zero
+// beyond), so 1..16 scenes cost the same VALU-free pass over the weights.  A workgroup owns 16 output rows (SWIGLU:
+// 16 gate + 16 up rows sharing the B fragments) and its 8 waves split K in interleaved 32-element steps (a row's eight
+// waves read 512 contiguous bytes per round); partial 16 x 16 tiles meet in LDS.  Column m of the result depends on
+// row m of x only, so a scene's numbers do not depend on its group.
+using dec_f32x4 = __attribute__((ext_vector_type(4))) float;
+using dec_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using dec_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ dec_f32x4 dec_mfma(bf16_t, const uint4& a, const uint4& b, dec_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dec_bf16x8, a), __builtin_bit_cast(dec_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ dec_f32x4 dec_mfma(f16_t, const uint4& a, const uint4& b, dec_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dec_f16x8, a), __builtin_bit_cast(dec_f16x8, b), c, 0, 0, 0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void linear_decode_mfma_kernel(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W,
+                                                                 int64_t ldw, const T* __restrict__ bias, const T* __restrict__ res,
+                                                                 int64_t ldr, T* __restrict__ out, int64_t ldo, int N, int K) {
+  constexpr int RG = EPI == DEC_EPI_SWIGLU ? 2 : 1;        // 16-row groups per workgroup
+  constexpr int UN = 4;                                     // 64-element K steps in flight per wave (8 x 16 B of weights per lane)
+  __shared__ float part[8][RG][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int o0 = blockIdx.x * 16;                           // first output of this workgroup
+  const T* wrow[RG];
+  if (EPI == DEC_EPI_SWIGLU) {
+    const int gate = (o0 >> 6) * 128 + (o0 & 63) + r;       // tile-interleaved rows: 64 gate rows, then their 64 up rows
+    wrow[0] = W + (int64_t)gate * ldw + 8 * g;
+    wrow[RG - 1] = W + (int64_t)(gate + 64) * ldw + 8 * g;
+  } else {
+    wrow[0] = W + (int64_t)(o0 + r) * ldw + 8 * g;
+  }
+  const bool col_ok = r < M;
+  const T* xrow = x + (int64_t)(col_ok ? r : 0) * ldx + 8 * g;
+  dec_f32x4 acc[RG];
+#pragma unroll
+  for (int q = 0; q < RG; ++q) acc[q] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = K / 64;                                  // a step = 64 elements: each row's two loads fill one 128-byte line
+  for (int s0 = wave; s0 < steps; s0 += 8 * UN) {
+    uint4 a[UN][2][RG], b[UN][2];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int s = s0 + 8 * u;
+      const bool ok = s < steps;
+      const int k0 = 64 * (ok ? s : s0);                    // past the end: re-read a valid step, its x is zeroed
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q) a[u][hf][q] = ldg_nt(reinterpret_cast<const uint4*>(wrow[q] + k0 + 32 * hf));
+        b[u][hf] = make_uint4(0u, 0u, 0u, 0u);
+        if (col_ok && ok) b[u][hf] = *reinterpret_cast<const uint4*>(xrow + k0 + 32 * hf);     // lanes of absent scenes load nothing
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int q = 0; q < RG; ++q) acc[q] = dec_mfma(T{}, a[u][hf][q], b[u][hf], acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < RG; ++q)
+    *reinterpret_cast<float4*>(&part[wave][q][lane * 4]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+  __syncthreads();
+  if (tid < 256) {                                          // element (row 4 (l >> 4) + i, column l & 15), l = tid >> 2, i = tid & 3
+    const int l = tid >> 2, i = tid & 3;
+    const int row = 4 * (l >> 4) + i, m = l & 15;
+    float v[RG];
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      v[q] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v[q] += part[w][q][tid];
+    }
+    if (m < M) {
+      const int n = o0 + row;
+      if (EPI == DEC_EPI_SWIGLU) {
+        const float gt = round_to<T>(v[0]), up = round_to<T>(v[RG - 1]);
+        out[m * ldo + n] = from_f32<T>(round_to<T>(silu_f(gt)) * up);
+      } else {
+        float y = v[0];
+        if (EPI == DEC_EPI_BIAS) y += to_f32(bias[n]);
+        y = round_to<T>(y);                                 // the linear's own output rounding
+        if (EPI == DEC_EPI_RES) y += to_f32(res[m * ldr + n]);
+        out[m * ldo + n] = from_f32<T>(y);
+      }
+    }
+  }
+}
+
 // The same weight-streaming linear over OCP e4m3 weights (BASELINE configs[3]): W8 [N, K] bytes with one f32 scale per
 // output row (v3d_quantize_fp8_rows), activations stay 16-bit (W8A16): y[n] = sw[n] * sum_k q[n,k] x[k].  Half the
 // bytes of the 16-bit kernel per step; a 16-byte chunk is 16 weights (two x vectors).  No fused norm (callers
@@ -253,8 +346,8 @@ __global__ __launch_bounds__(256, 4) void linear_decode_fp8_kernel(
 // rotary (apply_rotary_pos_emb, modeling_qwen2.py:141-173) on the new token's q and k heads, in place in the
 // QKV row, and append of k (rotated) and v to cache row `pos`:  cache_row = [k heads | v heads].
 struct RopeRows {        // scenes decoding together (blockIdx.y = scene): own position and cache row
-  int pos[4];
-  void* cache_row[4];
+  int pos[16];
+  void* cache_row[16];
   int64_t qkv_stride;
 };
 
@@ -347,16 +440,36 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
                               int epilogue, void* stream, const char* who) {
   V3D_REQUIRE(x && W && out, "%s: null pointer", who);
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
-  V3D_REQUIRE(M >= 1 && M <= 4, "%s: 1 to 4 activation rows (got %d)", who, M);
   V3D_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K, "%s: bad shape N=%d K=%d", who, N, K);
+  // 1..4 rows: the VALU form (bit-identical to the single-row kernel, and the faster one at these sizes); 5..16 rows: the
+  // matrix-core form, whose cost does not grow with M (same values up to the f32 summation order)
+  const bool mfma_ok = !norm_weight && K % 64 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
+  const bool mfma = mfma_ok && M > 4;
+  V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? 16 : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? 16 : 4, M);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
   V3D_REQUIRE(aligned16(x) && aligned16(W) && (!norm_weight || aligned16(norm_weight)), "%s: alignment", who);
   V3D_REQUIRE(M == 1 || (ldx % 8 == 0 && ldx >= K), "%s: activation row stride %lld", who, (long long)ldx);
   V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "%s: bias epilogue without bias", who);
   V3D_REQUIRE(epilogue != DEC_EPI_RES || res, "%s: residual epilogue without residual", who);
   V3D_REQUIRE(!norm_weight || K / 8 <= 512, "%s: fused RMSNorm needs K <= 4096 (got %d)", who, K);
-  const int blocks = N / 4;                                   // 4 weight rows per workgroup (SWIGLU: 2 gate/up pairs)
   hipStream_t st = (hipStream_t)stream;
+  if (mfma) {
+    V3D_REQUIRE(aligned16(W) && (M == 1 || ldx % 8 == 0), "%s: alignment", who);
+    const int mblocks = (epilogue == DEC_EPI_SWIGLU ? N / 2 : N) / 16;
+#define V3D_LDM(TT, EE) hipLaunchKernelGGL((linear_decode_mfma_kernel<TT, EE>), dim3(mblocks), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                           (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LDM_E(TT)                                                                                 \
+  switch (epilogue) {                                                                                 \
+    case DEC_EPI_NONE: V3D_LDM(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LDM(TT, DEC_EPI_BIAS); break; \
+    case DEC_EPI_RES: V3D_LDM(TT, DEC_EPI_RES); break; case DEC_EPI_SWIGLU: V3D_LDM(TT, DEC_EPI_SWIGLU); break; \
+    default: set_error("%s: unknown epilogue %d", who, epilogue); return V3D_E_INVALID;               \
+  }
+    if (dtype == V3D_BF16) { V3D_LDM_E(bf16_t) } else { V3D_LDM_E(f16_t) }
+#undef V3D_LDM_E
+#undef V3D_LDM
+    return check_launch(who);
+  }
+  const int blocks = N / 4;                                   // 4 weight rows per workgroup (SWIGLU: 2 gate/up pairs)
 #define V3D_LD(TT, EE, NN, MM)                                                                                                \
   hipLaunchKernelGGL((linear_decode_kernel<TT, EE, NN, MM>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, (const TT*)norm_weight, \
                      eps, (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
@@ -428,7 +541,7 @@ static int rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_hea
                                const void* sin_table, int n_pos, const int* pos, void* const* cache_rows, int dtype, void* stream,
                                const char* who) {
   V3D_REQUIRE(qkv && cos_table && sin_table && pos && cache_rows, "%s: null pointer", who);
-  V3D_REQUIRE(M >= 1 && M <= 4 && head_dim % 16 == 0 && aligned16(qkv) && qkv_stride % 8 == 0, "%s: bad arguments", who);
+  V3D_REQUIRE(M >= 1 && M <= 16 && head_dim % 16 == 0 && aligned16(qkv) && qkv_stride % 8 == 0, "%s: bad arguments", who);
   RopeRows rw{};
   for (int m = 0; m < M; ++m) {
     V3D_REQUIRE(pos[m] >= 0 && pos[m] < n_pos, "%s: pos %d outside the table (%d)", who, pos[m], n_pos);

@@ -481,11 +481,11 @@ class Engine:
 
     # ------------------------------------------------------------------ scenes decoding together
     def new_group(self, n_scenes):
-        """Row buffers for up to 4 scenes whose decode steps run as ONE pass over the weights (the decode step is
-        HBM-bound on the 15 GB of weights: M scenes cost about what one does; every row's arithmetic is the
-        single-scene arithmetic, so grouping never changes a token)."""
-        if not 1 <= n_scenes <= 4:
-            raise V3DError("a decode group holds 1 to 4 scenes")
+        """Row buffers for up to 16 scenes whose decode steps run as ONE pass over the weights (the decode step is
+        HBM-bound on the 15 GB of weights and the weights feed the matrix cores directly, so M scenes cost about
+        what one does; a row's arithmetic does not depend on the other rows, so grouping never changes a token)."""
+        if not 1 <= n_scenes <= 16:
+            raise V3DError("a decode group holds 1 to 16 scenes")
         l = self.cfg.llm
         z = lambda *s: torch.zeros(s, dtype=self.dtype, device=self.device)
         g = SceneContext()
