@@ -34,6 +34,17 @@ int main(int argc, char** argv) {
     if (rc) { printf("error %d: %s\n", rc, v3d_last_error()); return 1; }
   }
   printf("S=%d causal=%d: %.1f us\n", S, causal, ms * 1e3);
+  {   // per-phase split of the pipeline step (stamps cost ~10 % and drain the LDS reads in flight at each stamp)
+    unsigned long long hp[8 * 64];
+    hipMemcpyFromSymbol(hp, HIP_SYMBOL(v3d::g_attn_prof), sizeof(hp));
+    printf("qtile wave tiles | fill+dma+qk  vreads+prep  pv+softmax  vmcnt  barrier | step   (cycles per tile)\n");
+    for (int b = 0; b < 16; b += 5)
+      for (int w = 0; w < 4; ++w) {
+        const unsigned long long* r = hp + (b * 4 + w) * 8;
+        const double n = (double)r[6];
+        printf("%5d %4d %5.0f | %8.0f %10.0f %10.0f %8.0f %7.0f | %6.0f\n", b, w, n, r[0] / n, r[1] / n, r[2] / n, r[3] / n, r[4] / n, r[5] / n);
+      }
+  }
   // schedule: per workgroup realtime window (100 MHz ticks), shader clock, and which CU it ran on
   const int nblk = ((S + 127) / 128) * H;
   std::vector<unsigned long long> hb(4 * 4096);

@@ -70,6 +70,12 @@ struct AttnArgs {
 #ifdef V3D_ATTN_PROF   // tools/probes/attn_prof.hip only: per-wave cycle split of the tile loop (never in the product build)
 __device__ unsigned long long g_attn_prof[8 * 64];
 __device__ unsigned long long g_attn_blocks[4 * 4096];   // per workgroup: realtime start, end, shader-clock delta, HW_ID
+// per-phase shader-clock stamps of the pipeline step (one asm statement each, so the wait stays with the stamp)
+#define V3D_STAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define V3D_ACC(i, a, b) prof_acc[i] += (b) - (a)
+#else
+#define V3D_STAMP(v)
+#define V3D_ACC(i, a, b)
 #endif
 
 __device__ __forceinline__ int kv_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -180,6 +186,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   float m_run = 0.f, l_run = 0.f;              // m_run in scaled log2 units; fixed by the first tile
   const int q_pos = p.q_pos0 + qi;
   const int wave_first_pos = p.q_pos0 + q0 + wave * 32;
+#ifdef V3D_ATTN_PROF
+  unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
 #define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(kaddr0 ^ ((ks) << 5)), "i"(imm))
 #define V3D_KW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
@@ -289,14 +298,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     const unsigned vaddr0 = vaddr0_, vaddr1 = vaddr1_;
     const bool do_qk = FULL || t + 1 < n_wave, do_pv = FULL || t < n_wave;          // wave-uniform
     f32x16 s[2];
+    V3D_STAMP(ts0);
     if (do_qk) qk_fill(IntC<1 - PAR>{});
     if (FULL || t + 2 < n_tiles) stage_k(PAR, t + 2);          // K[PAR] (tile t) was consumed one step ago
     if (FULL || t + 1 < n_tiles) stage_v(1 - PAR, t + 1);      // V[1-PAR] (tile t-1) was consumed one step ago
     if (do_qk) qk_run(IntC<1 - PAR>{}, s);
+    V3D_STAMP(ts1);
     v2i va[8], vc[8];          // V^T fragments [2*s4 + half], ring of two d-tiles
     if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
     float alpha = 1.0f, ls0 = 0.f, ls1 = 0.f;
     if (do_qk) alpha = softmax_prep(s, t + 1);
+    V3D_STAMP(ts2);
     auto mmav = [&](const v2i* f, int dt, int quarter) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -332,8 +344,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       }
       l_run += ls0 + ls1;
     }
+    V3D_STAMP(ts3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V3D_STAMP(ts4);
     __builtin_amdgcn_s_barrier();      // tiles t+1 (V) / t+2 (K) landed and visible; everyone is done with tile t
+    V3D_STAMP(ts5);
+    V3D_ACC(0, ts0, ts1); V3D_ACC(1, ts1, ts2); V3D_ACC(2, ts2, ts3); V3D_ACC(3, ts3, ts4); V3D_ACC(4, ts4, ts5); V3D_ACC(5, ts0, ts5);
   };
 
 #ifdef V3D_ATTN_PROF
@@ -387,6 +403,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       g_attn_blocks[4 * bid + 3] = ((unsigned long long)xcc << 32) | hwid;
       g_attn_blocks[4 * 4095 + (bid & 3)] = (unsigned long long)n_tiles;
     }
+  }
+  if (lane == 0 && blockIdx.x == 3 && blockIdx.z == 0 && blockIdx.y < 16) {
+    unsigned long long* pr = g_attn_prof + (blockIdx.y * 4 + wave) * 8;
+    for (int i = 0; i < 6; ++i) pr[i] = prof_acc[i];
+    pr[6] = (unsigned long long)n_tiles;
   }
 #endif
 
