@@ -271,10 +271,12 @@ def main():
         gemm_peak = 5000.0 if a.fp8 else 2500.0
         attn_us = stamps["attn"].mean_us()
         attn_flops = 2.0 * S * S * 128 * 28                                   # causal: half of 4*S^2*d*H
-        traffic = None
+        traffic, attn_busy = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("visual_tokens_hbm_bytes_per_launch")
+            pm = json.load(open(pmc))
+            traffic = pm.get("visual_tokens_hbm_bytes_per_launch")
+            attn_busy = pm.get("attention_mfma_busy_frac")       # PMC: MFMA-busy share of SIMD cycles at the actual clock
         line = {
             "metric": "scenes/sec ScanQA @32 frames", "value": world * a.steps / dt_s, "unit": "scenes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_s / a.steps * 1e3,
@@ -294,7 +296,8 @@ def main():
                                   "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": None, "us_per_launch": gemm_us},
             "roofline_attention": {"kernel": "attn_prefill_kernel (causal GQA, S=%d, 28q/4kv, hd128)" % S, "bound": "mfma",
                                    "achieved": attn_flops / attn_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
-                                   "frac": attn_flops / attn_us / 1e6 / 2500.0, "traffic": None, "us_per_launch": attn_us},
+                                   "frac": attn_flops / attn_us / 1e6 / 2500.0, "traffic": None, "us_per_launch": attn_us,
+                                   "mfma_busy_frac_pmc": attn_busy},
         }
         if fp8_extra is not None:
             line["fp8_config3"] = fp8_extra
