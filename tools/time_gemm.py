@@ -7,11 +7,13 @@ def t(name, M, N, K, epi=0, iters=20):
     a = torch.randn(M, K, device="cuda", dtype=dt) * 0.5
     w = torch.randn(N, K, device="cuda", dtype=dt) * 0.05
     out = torch.empty(M, N // 2 if epi == 6 else N, device="cuda", dtype=dt)
-    for _ in range(3): ops.gemm(a, w, epilogue=epi, out=out)
+    bias = torch.zeros(N, device="cuda", dtype=dt) if epi in (1, 2, 3) else None
+    kw = dict(bias=bias) if bias is not None else {}
+    for _ in range(3): ops.gemm(a, w, epilogue=epi, out=out, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): ops.gemm(a, w, epilogue=epi, out=out)
+    for _ in range(iters): ops.gemm(a, w, epilogue=epi, out=out, **kw)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * M * N * K
@@ -30,6 +32,8 @@ t("llm down", S, 3584, 18944)
 t("vit qkv", 23328, 4608, 1152)
 t("vit out", 23328, 1152, 1152)
 t("vit fc1", 23328, 4352, 1152)
+t("vit fc1 +bias+gelu_tanh", 23328, 4352, 1152, epi=3)
+t("proj1 +bias+gelu_erf", 23328, 3584, 1152, epi=2)
 t("vit fc2", 23328, 1152, 4352)
 t("proj1", 23328, 3584, 1152)
 t("proj2", 23328, 3584, 3584)
