@@ -33,7 +33,7 @@ struct Fp8GemmArgs {
   int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ float silu8(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu8(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 __device__ __forceinline__ void glds16f(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
