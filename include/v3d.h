@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 1
+#define V3D_ABI_VERSION 2   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries */
 
 enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
 

@@ -22,7 +22,7 @@ def lib():
                 "(or __graft_entry__.build()).  There is no CPU fallback for this path.")
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.v3d_abi_version() != 1:
+        if _lib.v3d_abi_version() != 2:
             raise V3DError("libv3d_hip.so ABI version mismatch")
     return _lib
 
