@@ -206,6 +206,66 @@ def test_attention_decode_split_kv(ops, kind, Sk, H, KV):
     close(out.view(1, 1, H, D), want, kind, ulps=2.0, floor=0.3)
 
 
+@pytest.mark.parametrize("lens", [[6800], [130, 130, 130], [1, 999, 6800, 64, 65], list(range(40, 40 + 16 * 37, 37))])
+def test_attention_decode_rows_ragged(ops, lens):
+    """Scenes decoding together (own cache, own length) in one launch pair: each row equals softmax(q K^T / sqrt(d)) V
+    over its own keys; equal lengths reproduce the single-scene launch bit for bit."""
+    dt = torch.bfloat16
+    H, KV, D = 28, 4, 128
+    M = len(lens)
+    g = torch.Generator().manual_seed(sum(lens))
+    q = torch.randn(M, H * D, generator=g).to(dt)
+    caches = [torch.randn(n + 2, 2 * KV * D, generator=g).to(dt) for n in lens]
+    cds = [c.cuda() for c in caches]
+    out = torch.empty(M, H * D, dtype=dt, device="cuda")
+    one = ops.decode_workspace(H, KV, "cuda")
+    ws = torch.empty(one.numel() * M, dtype=torch.float32, device="cuda")
+    ops.attention_decode_rows(q.cuda(), cds, [c[:, KV * D:] for c in cds], out, lens, H, KV, 1 / math.sqrt(D), ws)
+    for m, n in enumerate(lens):
+        k = caches[m][:n, :KV * D].view(1, n, KV, D)
+        v = caches[m][:n, KV * D:].view(1, n, KV, D)
+        want = ref_attention(q[m].view(1, 1, H, D), k, v, True, 1 / math.sqrt(D), q_pos0=n - 1)
+        close(out[m].view(1, 1, H, D), want, "bf16", ulps=2.0, floor=0.3)
+    if len(set(lens)) == 1:
+        for m, n in enumerate(lens):
+            alone = torch.empty(H * D, dtype=dt, device="cuda")
+            ops.attention_decode(q[m].cuda(), cds[m], cds[m][:, KV * D:], alone, n, H, KV, 1 / math.sqrt(D), one)
+            assert torch.equal(alone, out[m])
+
+
+def test_rope_rows_and_argmax_rows(ops):
+    """Batched rotary + cache append (own position and cache row per scene) and batched argmax == the single-row calls."""
+    dt = torch.bfloat16
+    H, KV, D, M = 4, 2, 128, 5
+    table = ops.RopeTable(D, 512, 1e6, dt, "cuda")
+    g = torch.Generator().manual_seed(3)
+    rows = torch.randn(M, (H + 2 * KV) * D + 64, generator=g).to(dt).cuda()       # padded row stride
+    pos = [0, 77, 511, 3, 200]
+    want_rows, want_cache = [], []
+    for m in range(M):
+        r = rows[m, : (H + 2 * KV) * D].clone()
+        c = torch.zeros(2 * KV * D, dtype=dt, device="cuda")
+        ops.rope_kv_append(r, H, KV, D, table, pos[m], c)
+        want_rows.append(r)
+        want_cache.append(c)
+    got = rows.clone()
+    crow = [torch.zeros(2 * KV * D, dtype=dt, device="cuda") for _ in range(M)]
+    ops.rope_kv_append_rows(got[:, : (H + 2 * KV) * D], H, KV, D, table, pos, crow)
+    for m in range(M):
+        assert torch.equal(got[m, : (H + 2 * KV) * D], want_rows[m]) and torch.equal(crow[m], want_cache[m])
+    assert torch.equal(got[:, (H + 2 * KV) * D:], rows[:, (H + 2 * KV) * D:])       # the padding is untouched
+    with pytest.raises(Exception, match="outside the table"):
+        ops.rope_kv_append_rows(got[:, : (H + 2 * KV) * D], H, KV, D, table, [0, 1, 2, 3, 512], crow)
+    x = torch.randn(M, 152064 + 64, generator=g).to(dt)
+    x[1, 777] = x[1, 12] = 60.0            # tie -> lowest index
+    x[3, 152063] = 70.0                    # last valid column; the padding columns behind it hold larger values
+    x[:, 152064:] = 100.0
+    xd = x.cuda()
+    idx = torch.zeros(M, dtype=torch.int64, device="cuda")
+    ops.argmax_rows(xd[:, :152064], idx, torch.empty(256 * M, dtype=torch.float32, device="cuda"))
+    assert idx.tolist() == x[:, :152064].float().argmax(1).tolist() and idx[1].item() == 12 and idx[3].item() == 152063
+
+
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
 def test_linear_decode_fused_variants(ops, kind):
     """Decode-step linears: fused RMSNorm prologue, bias / residual / SwiGLU epilogues vs the oracle ops."""
