@@ -1,0 +1,124 @@
+"""Size-independent properties at BASELINE.json's full shapes (32 frames, 384 x 384, S = 6794, Qwen2-7B / SigLIP-so400m
+WIDTHS; depth reduced to 4 + 2 layers so the random-init weights build in seconds - every kernel still runs at its full
+per-layer shape).  The CPU oracle cannot run these sizes in test time, so the checks are properties the domain offers:
+
+  * KV-cache consistency: prefill(S rows) + one decode step == prefill(S + 1 rows), last-row logits (rel. L2 < 2e-2);
+  * determinism: the same scene twice gives bit-identical logits and tokens (no atomics-order or uninitialised-pad effects);
+  * grouped decode == single-scene decode, token for token, at full sequence length;
+  * causality: changing the LAST prompt token leaves every K/V cache row before it bit-identical;
+  * the e4m3 path (configs[3]) stays within its re-stated tolerance of the bf16 path at full size (noise grows ~sqrt(#GEMMs)).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FRAMES, TEXT_PRE, TEXT_POST = 32, 14, 60
+
+
+@pytest.fixture(scope="module")
+def full():
+    from v3d import ops
+    from v3d.engine import Engine, EngineConfig, LlmConfig, VitConfig, random_state_dict
+    from v3d.token_ids import IMAGE_TOKEN_INDEX
+    cfg = EngineConfig(vit=VitConfig(layers=2), llm=LlmConfig(layers=4))
+    dev = torch.device("cuda")
+    sd = random_state_dict(cfg, torch.bfloat16, dev, seed=0)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device=dev, max_frames=FRAMES)
+    g = torch.Generator(device=dev).manual_seed(1)
+    frames = torch.randint(0, 256, (FRAMES, 384, 384, 3), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+    coords = ((torch.rand(FRAMES, 384, 384, 3, generator=g, device=dev) - 0.5) * torch.tensor([30.0, 30.0, 10.0], device=dev)).to(torch.bfloat16)
+    text = torch.randint(0, 151000, (TEXT_PRE + TEXT_POST,), generator=g, device=dev).cpu()
+    ids = torch.cat([text[:TEXT_PRE], torch.tensor([IMAGE_TOKEN_INDEX]), text[TEXT_PRE:]])
+    images = ops.preprocess_rgb(frames, torch.bfloat16)
+    return dict(eng=eng, cfg=cfg, sd=sd, ids=ids, images=images, coords=coords, ops=ops)
+
+
+def _prefill(eng, ctx, ids, images, coords):
+    eng.use(ctx)
+    feats = eng.encode_images(images)
+    vox = eng.voxel_ids(coords)
+    x = eng.build_inputs_embeds(ids, feats, vox)
+    logits = eng.llm_forward(x, 0)
+    return x.shape[0], logits
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-9)).item()
+
+
+def test_sequence_length_is_the_baseline_shape(full):
+    eng = full["eng"]
+    S, _ = _prefill(eng, eng.new_context(), full["ids"], full["images"], full["coords"])
+    assert S == TEXT_PRE + FRAMES * 14 * 15 + TEXT_POST == 6794
+
+
+def test_kv_cache_consistency_prefill_vs_decode(full):
+    eng, ops, ids = full["eng"], full["ops"], full["ids"]
+    extra = torch.tensor([4242])
+    c1 = eng.new_context()
+    S, _ = _prefill(eng, c1, ids, full["images"], full["coords"])
+    xe = ops.embed_gather(eng.embed, extra.cuda(), out=c1.l_x[S: S + 1])
+    step = eng.decode_forward(xe, S).float().clone()
+    c2 = eng.new_context()
+    S2, whole = _prefill(eng, c2, torch.cat([ids, extra]), full["images"], full["coords"])
+    assert S2 == S + 1
+    assert rel(step, whole) < 2e-2
+    for i in range(full["cfg"].llm.layers):                 # the caches agree too (decode wrote row S, prefill wrote all rows)
+        assert torch.equal(c1.kv[i][:S], c2.kv[i][:S])
+        assert rel(c1.kv[i][S], c2.kv[i][S]) < 2e-2
+
+
+def test_determinism_bit_identical(full):
+    eng = full["eng"]
+    outs = []
+    for _ in range(2):
+        c = eng.new_context()
+        S, logits = _prefill(eng, c, full["ids"], full["images"], full["coords"])
+        toks = eng.decode_loop(logits, S, 4).clone()
+        outs.append((logits.clone(), toks, c.kv[1][:S].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_grouped_decode_equals_single_at_full_length(full):
+    eng, ids = full["eng"], full["ids"]
+    prompts = [ids, torch.cat([ids[:-1], torch.tensor([77])]), torch.cat([ids[:-2], torch.tensor([5, 9])])]
+    alone = []
+    for p in prompts:
+        c = eng.new_context()
+        S, logits = _prefill(eng, c, p, full["images"], full["coords"])
+        alone.append(eng.decode_loop(logits, S, 5).clone())
+    ctxs = [eng.new_context() for _ in prompts]
+    lens = [_prefill(eng, c, p, full["images"], full["coords"])[0] for c, p in zip(ctxs, prompts)]
+    toks = eng.decode_group(eng.new_group(3), ctxs, lens, 5)
+    for m in range(3):
+        assert torch.equal(toks[m], alone[m])
+
+
+def test_causality_of_the_cache(full):
+    eng, ids = full["eng"], full["ids"]
+    c1, c2 = eng.new_context(), eng.new_context()
+    S, _ = _prefill(eng, c1, ids, full["images"], full["coords"])
+    other = ids.clone()
+    other[-1] = (int(ids[-1]) + 1) % 1000
+    _prefill(eng, c2, other, full["images"], full["coords"])
+    for i in range(full["cfg"].llm.layers):
+        assert torch.equal(c1.kv[i][: S - 1], c2.kv[i][: S - 1])
+        assert not torch.equal(c1.kv[i][S - 1], c2.kv[i][S - 1])
+
+
+def test_fp8_path_close_to_bf16_at_full_size(full):
+    """configs[3]: 4 layers = 16 e4m3 GEMMs at S = 6794.  Per-GEMM error ~3.6 % (tests/test_gpu_fp8.py); on a random-init
+    network the errors add like independent noise, sqrt(16) x 3.6 % = 14 % - bound 20 % on the last hidden state, 6 % on the
+    caches of layer 0 (one GEMM deep)."""
+    from v3d.engine import Engine
+    eng = full["eng"]
+    e8 = Engine(full["cfg"], full["sd"], dtype=torch.bfloat16, device=torch.device("cuda"), max_frames=FRAMES, llm_fp8=True)
+    c = eng.new_context()
+    S, _ = _prefill(eng, c, full["ids"], full["images"], full["coords"])
+    ref_hidden = eng.last_hidden().float().clone()
+    S8, _ = _prefill(e8, e8.ctx, full["ids"], full["images"], full["coords"])
+    assert S8 == S
+    assert rel(e8.ctx.kv[0][:S], c.kv[0][:S]) < 0.06
+    assert rel(e8.last_hidden(), ref_hidden) < 0.20
