@@ -77,3 +77,15 @@ for i in range(56): ops.attention_decode(q, caches[i % 28], caches[i % 28][:, KV
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 56
 print(f"attn_decode Sk={Sk} {us:8.1f} us  {Sk*2*KV*D*2/us/1e6:6.2f} TB/s")
+for M in (4, 8, 16):
+    qs = torch.randn(M, H * D, device="cuda", dtype=dt)
+    outs = torch.empty(M, H * D, device="cuda", dtype=dt)
+    wsM = torch.empty(ws.numel() * M, dtype=torch.float32, device="cuda")
+    cs = [caches[i % 28] for i in range(M)]
+    f = lambda: ops.attention_decode_rows(qs, cs, [c[:, KV * D:] for c in cs], outs, [Sk] * M, H, KV, 0.088, wsM)
+    for _ in range(3): f()
+    torch.cuda.synchronize(); e0.record()
+    for i in range(40): f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 40
+    print(f"attn_decode_rows M={M} Sk={Sk} {us:8.1f} us  ({us/M:.1f} us per scene, {M*Sk*2*KV*D*2/us/1e6:5.2f} TB/s)")

@@ -41,6 +41,17 @@ template <> struct Mfma32<f16_t> {
   }
 };
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<f16_t> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
 union Frag16 {   // 16 bytes viewed as MFMA fragment / raw words
   uint4 u;
   bf16x8 b;
@@ -51,6 +62,7 @@ union Frag16 {   // 16 bytes viewed as MFMA fragment / raw words
 template <typename T> __device__ __forceinline__ typename Mfma32<T>::frag as_frag(const Frag16& f);
 template <> __device__ __forceinline__ bf16x8 as_frag<bf16_t>(const Frag16& f) { return f.b; }
 template <> __device__ __forceinline__ f16x8 as_frag<f16_t>(const Frag16& f) { return f.h; }
+template <typename T> __device__ __forceinline__ typename Mfma16<T>::frag as_frag16(const Frag16& f) { return as_frag<T>(f); }
 
 constexpr int AT_BQ = 128, AT_BKV = 64, AT_ROW = 256;           // LDS row bytes (D padded to 128)
 constexpr int AT_TILE = AT_BKV * AT_ROW;                        // 16 KiB per K or V tile
@@ -654,6 +666,156 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecR
   }
 }
 
+// Matrix-core variant of the split kernel: the scores of a wave's 16 keys against all G query heads are ONE chain of four
+// v_mfma_f32_16x16x32 (A = the query heads as rows, zero above G; B = K rows straight from HBM, lane (key, g) holds
+// K[key][32t + 8g .. +8)), instead of G x 4 shuffle reductions per key.  Softmax runs on the 16 x 16 score tile (lane =
+// one key column, 4 heads), probabilities and rescale factors go through 2 KB of LDS into the V layout (16 lanes per key
+// row, as in the kernel above), where O accumulates on the VALU.  Same partial format, same merge kernel.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void attn_decode_split_mm_kernel(AttnArgs p, DecRows rw, int n_split, float* __restrict__ ws) {
+  constexpr int D = 128;
+  {
+    const int sc = blockIdx.z;
+    p.k = rw.k[sc]; p.v = rw.v[sc]; p.Sk = rw.sk[sc]; p.q_pos0 = rw.sk[sc] - 1;
+    p.q = (const uint16_t*)p.q + sc * rw.q_stride;
+    ws += sc * rw.ws_stride;
+  }
+  __shared__ float sm_m[16][G], sm_l[16][G];
+  __shared__ float sm_o[16][G][D + 4];
+  __shared__ __attribute__((aligned(16))) float sm_p[4][16][8];     // [wave][key][head]
+  __shared__ __attribute__((aligned(16))) float sm_a[4][8];         // [wave][head] rescale factor of this chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hr = lane & 15, g4 = lane >> 4;        // score tile: column (key) hr, heads 4 g4 + i;  V layout: slot g4, dims 8 hr..
+  const int hk = blockIdx.x, split = blockIdx.y;
+  const int n_keys = p.q_pos0 + 1 < p.Sk ? p.q_pos0 + 1 : p.Sk;
+  const int per = (n_keys + n_split - 1) / n_split;
+  const int k_begin = split * per;
+  int k_end = k_begin + per;
+  k_end = k_end < n_keys ? k_end : n_keys;
+  const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * p.hsk;
+  const uint16_t* V = (const uint16_t*)p.v + (int64_t)hk * p.hsk;
+  Frag16 qf[4];                                    // A operand: head hr (zero rows above G), dims 32t + 8 g4 ..
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    qf[t].u = make_uint4(0u, 0u, 0u, 0u);
+    if (hr < G) qf[t].u = *reinterpret_cast<const uint4*>((const uint16_t*)p.q + (int64_t)(hk * G + hr) * p.hsq + 32 * t + 8 * g4);
+  }
+  float m[4], lp[4], acc[G][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { m[i] = -INFINITY; lp[i] = 0.f; }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+  for (int kb = k_begin; kb < k_end; kb += 64) {
+    const int kw0 = kb + 16 * wave;                // this wave's 16 keys of the chunk
+    Frag16 kf[4];
+    uint4 v4[4];
+    {
+      const int key = kw0 + hr;
+      const int kc = key < k_end ? key : k_begin;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) kf[t].u = *reinterpret_cast<const uint4*>(K + (int64_t)kc * p.ldk + 32 * t + 8 * g4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kv = kw0 + 4 * r + g4;
+        const int vc = kv < k_end ? kv : k_begin;
+        v4[r] = *reinterpret_cast<const uint4*>(V + (int64_t)vc * p.ldv + hr * 8);
+      }
+    }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = Mfma16<T>::run(as_frag16<T>(qf[t]), as_frag16<T>(kf[t]), c);
+    const bool key_ok = kw0 + hr < k_end;
+    float alpha[4], pr[4];
+    bool moved = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = key_ok && 4 * g4 + i < G;
+      const float sc = ok ? c[i] * p.scale_log2 : -INFINITY;
+      float mx = sc;
+      mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+      mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+      const float mn = fmaxf(m[i], mx);
+      alpha[i] = mn == -INFINITY ? 1.0f : __builtin_amdgcn_exp2f(m[i] - mn);      // m = -inf -> 0
+      pr[i] = ok ? __builtin_amdgcn_exp2f(sc - mn) : 0.f;
+      lp[i] = lp[i] * alpha[i] + pr[i];
+      m[i] = mn;
+      moved |= alpha[i] != 1.0f;
+    }
+    if (g4 < 2) {
+      *reinterpret_cast<float4*>(&sm_p[wave][hr][4 * g4]) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+      if (hr == 0) *reinterpret_cast<float4*>(&sm_a[wave][4 * g4]) = make_float4(alpha[0], alpha[1], alpha[2], alpha[3]);
+    }
+    const bool any_moved = __any(moved);            // wave-uniform
+    __syncthreads();
+    if (any_moved) {
+      float a8[8];
+      *reinterpret_cast<float4*>(&a8[0]) = *reinterpret_cast<const float4*>(&sm_a[wave][0]);
+      *reinterpret_cast<float4*>(&a8[4]) = *reinterpret_cast<const float4*>(&sm_a[wave][4]);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] *= a8[g];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                   // V layout: key 4r + g4 of the wave's 16, dims 8 hr ..
+      float ph[8], vf[8];
+      *reinterpret_cast<float4*>(&ph[0]) = *reinterpret_cast<const float4*>(&sm_p[wave][4 * r + g4][0]);
+      *reinterpret_cast<float4*>(&ph[4]) = *reinterpret_cast<const float4*>(&sm_p[wave][4 * r + g4][4]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vf[j] = vec_get<T>(v4[r], j);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = fmaf(ph[g], vf[j], acc[g][j]);
+    }
+    __syncthreads();                                // sm_p / sm_a are rewritten by the next chunk
+  }
+  // per-wave (m, l) -> the four slots of the wave (l counted once); accumulators -> slot 4 wave + g4
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float l = lp[i];
+    l += __shfl_xor(l, 8); l += __shfl_xor(l, 4); l += __shfl_xor(l, 2); l += __shfl_xor(l, 1);
+    if (hr == 0 && 4 * g4 + i < G) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) { sm_m[4 * wave + s_][4 * g4 + i] = m[i]; sm_l[4 * wave + s_][4 * g4 + i] = s_ == 0 ? l : 0.f; }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float4* dst = reinterpret_cast<float4*>(&sm_o[4 * wave + g4][g][hr * 8]);
+    dst[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    dst[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+  }
+  __syncthreads();
+  if (tid < G) {
+    const int g = tid;
+    float mm = -INFINITY;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) mm = fmaxf(mm, sm_m[s_][g]);
+    const float mu = mm == -INFINITY ? 0.f : mm;
+    float lt = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const float f = __builtin_amdgcn_exp2f(sm_m[s_][g] - mu);      // empty waves (m = -inf) -> 0
+      lt += sm_l[s_][g] * f;
+      sm_m[s_][g] = f;                                                 // reuse as the factor table
+    }
+    float* w = ws + ((size_t)split * p.Hq + hk * G + g) * (D + 2);
+    w[D] = mm;
+    w[D + 1] = lt;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < G * D; idx += 256) {
+    const int g = idx / D, d = idx - g * D;
+    float ot = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) ot = fmaf(sm_o[s_][g][d], sm_m[s_][g], ot);
+    ws[((size_t)split * p.Hq + hk * G + g) * (D + 2) + d] = ot;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, DecRows rw, int n_split, const float* __restrict__ ws) {
   constexpr int D = 128;
@@ -771,9 +933,13 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
     rw.k[m] = k_caches[m]; rw.v[m] = v_caches[m]; rw.sk[m] = Sk[m];
     sk_max = Sk[m] > sk_max ? Sk[m] : sk_max;
   }
-  static int kps = 0;
-  if (!kps) { const char* e = getenv("V3D_DEC_KEYS_PER_SPLIT"); kps = e ? atoi(e) : 64; }
-  int n_split = (sk_max + kps - 1) / kps;            // >= 64 keys per split: 4 x 107 workgroups at S = 6.8k
+  static int kps_env = -1;
+  if (kps_env < 0) { const char* e = getenv("V3D_DEC_KEYS_PER_SPLIT"); kps_env = e ? atoi(e) : 0; }
+  // keys per split: enough workgroups to cover the chip, few enough that the per-split merge stays small.  Independent of
+  // M, so that a scene's split count - and with it every bit of its output - does not depend on its group (measured at
+  // S = 6.8k: 128 is 10 % faster for a single scene, 256 is 20-25 % faster from four scenes on)
+  const int kps = kps_env > 0 ? kps_env : 256;
+  int n_split = (sk_max + kps - 1) / kps;
   const int cap = 1024 / Hkv;                        // ~4 workgroups per CU and scene
   if (n_split > cap) n_split = cap;
   if (n_split < 1) n_split = 1;
@@ -788,7 +954,11 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const int G = Hq / Hkv;
-#define V3D_DEC(TT, GG) hipLaunchKernelGGL((attn_decode_split_kernel<TT, GG>), dim3(Hkv, n_split, M), dim3(256), 0, st, p, rw, n_split, ws)
+  static int use_mm = -1;
+  if (use_mm < 0) { const char* e = getenv("V3D_DEC_ATTN"); use_mm = e && e[0] == 'v' ? 0 : 1; }     // "valu" selects the shuffle-reduction kernel
+#define V3D_DEC(TT, GG)                                                                                                          \
+  { if (use_mm) hipLaunchKernelGGL((attn_decode_split_mm_kernel<TT, GG>), dim3(Hkv, n_split, M), dim3(256), 0, st, p, rw, n_split, ws); \
+    else hipLaunchKernelGGL((attn_decode_split_kernel<TT, GG>), dim3(Hkv, n_split, M), dim3(256), 0, st, p, rw, n_split, ws); }
 #define V3D_DEC_G(TT)                                                                          \
   switch (G) {                                                                                 \
     case 1: V3D_DEC(TT, 1); break; case 2: V3D_DEC(TT, 2); break; case 4: V3D_DEC(TT, 4); break; \
