@@ -221,10 +221,10 @@ int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const v
                       void* stream);
 /* The same linear for M activation rows at once (M scenes decoding together share one pass over the weights; the
  * step is HBM-bound on them).  x [M, K] row stride ldx, res [M, N] row stride ldr, out [M, N'] row stride ldo.
- * M = 1..4: row m's result is bit-identical to v3d_linear_decode on that row alone.  M = 5..16 (no fused norm,
- * K % 64 == 0, N % 16 == 0): the weights feed the matrix cores straight from HBM (v_mfma_f32_16x16x32, activation rows
- * as the B operand), so the cost does not grow with M; same values up to the f32 summation order, and a row's result
- * still does not depend on the other rows. */
+ * M = 1 is v3d_linear_decode.  M = 2..16 (no fused norm, K % 128 == 0, N % 16 == 0): the weights feed the matrix cores
+ * (v_mfma_f32_16x16x32, activation rows as the B operand), so the cost does not grow with M and a row's result does not
+ * depend on the other rows or on M; against the one-row form it differs by the f32 summation order only.  Other shapes
+ * (fused norm, odd sizes): VALU form, M = 1..4, each row bit-identical to v3d_linear_decode on it. */
 int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W,
                            int64_t ldw, const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N,
                            int K, int dtype, int epilogue, void* stream);

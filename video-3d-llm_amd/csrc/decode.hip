@@ -159,12 +159,15 @@ __global__ __launch_bounds__(256, M == 1 ? 8 : 4) void linear_decode_kernel(
 }
 
 // Matrix-core form of the decode linear for up to 16 activation rows (scenes decoding together): the weights are the
-// MFMA A operand straight from HBM - lane (r, g) of v_mfma_f32_16x16x32 holds W[row0 + r][k0 + 8g .. +8), one 16-byte
-// non-temporal load, no LDS - and the activation rows are the B operand (x[m][k0 + 8g .. +8) for column m < M, zero
+// MFMA A operand of v_mfma_f32_16x16x32 and the activation rows the B operand (x[m][k .. k+8) for column m < M, zero
 // beyond), so 1..16 scenes cost the same VALU-free pass over the weights.  A workgroup owns 16 output rows (SWIGLU:
-// 16 gate + 16 up rows sharing the B fragments) and its 8 waves split K in interleaved 32-element steps (a row's eight
-// waves read 512 contiguous bytes per round); partial 16 x 16 tiles meet in LDS.  Column m of the result depends on
-// row m of x only, so a scene's numbers do not depend on its group.
+// 16 gate + 16 up rows sharing the B fragments) and its 8 waves split K in interleaved 128-element tiles.  A wave loads
+// a tile with FULL-LINE coalescing (one load instruction = 4 rows x 256 contiguous bytes; the operand layout itself -
+// lane (r, g) <- W[r][k0 + 8g .. +8) - would touch 16 rows x 64 B, i.e. half lines, and measured 3.5 TB/s), parks it in
+// its private 4 KB LDS tile (272-byte row pitch: conflict-free ds_write_b128 / ds_read_b128) and reads the fragments
+// back; two tiles of loads stay in flight in registers.  No workgroup barrier in the loop: the tile is wave-private and
+// the LDS pipeline keeps a wave's writes and reads in order.  Partial 16 x 16 tiles meet in LDS at the end.  Column m of
+// the result depends on row m of x only, so a scene's numbers do not depend on its group.
 using dec_f32x4 = __attribute__((ext_vector_type(4))) float;
 using dec_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using dec_f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -180,46 +183,60 @@ __global__ __launch_bounds__(512) void linear_decode_mfma_kernel(const T* __rest
                                                                  int64_t ldw, const T* __restrict__ bias, const T* __restrict__ res,
                                                                  int64_t ldr, T* __restrict__ out, int64_t ldo, int N, int K) {
   constexpr int RG = EPI == DEC_EPI_SWIGLU ? 2 : 1;        // 16-row groups per workgroup
-  constexpr int UN = 4;                                     // 64-element K steps in flight per wave (8 x 16 B of weights per lane)
+  constexpr int UN = 2;                                     // 128-element K tiles in flight per wave (8 x 16 B of weights per lane and group)
+  constexpr int PITCH = 272;                                // LDS row pitch in bytes (256 + 16)
+  __shared__ __attribute__((aligned(16))) char tile[8][RG][16 * PITCH];
   __shared__ float part[8][RG][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
+  const int r = lane & 15, g = lane >> 4;                   // operand layout: row / scene r, k group g
+  const int lr = lane >> 4, lc = lane & 15;                 // load layout: row 4j + lr of the tile, 16-byte chunk lc
   const int o0 = blockIdx.x * 16;                           // first output of this workgroup
-  const T* wrow[RG];
+  const T* wbase[RG];                                       // row lr of the group, chunk lc
   if (EPI == DEC_EPI_SWIGLU) {
-    const int gate = (o0 >> 6) * 128 + (o0 & 63) + r;       // tile-interleaved rows: 64 gate rows, then their 64 up rows
-    wrow[0] = W + (int64_t)gate * ldw + 8 * g;
-    wrow[RG - 1] = W + (int64_t)(gate + 64) * ldw + 8 * g;
+    const int gate = (o0 >> 6) * 128 + (o0 & 63);           // tile-interleaved rows: 64 gate rows, then their 64 up rows
+    wbase[0] = W + (int64_t)(gate + lr) * ldw + 8 * lc;
+    wbase[RG - 1] = W + (int64_t)(gate + 64 + lr) * ldw + 8 * lc;
   } else {
-    wrow[0] = W + (int64_t)(o0 + r) * ldw + 8 * g;
+    wbase[0] = W + (int64_t)(o0 + lr) * ldw + 8 * lc;
   }
   const bool col_ok = r < M;
   const T* xrow = x + (int64_t)(col_ok ? r : 0) * ldx + 8 * g;
   dec_f32x4 acc[RG];
 #pragma unroll
   for (int q = 0; q < RG; ++q) acc[q] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
-  const int steps = K / 64;                                  // a step = 64 elements: each row's two loads fill one 128-byte line
-  for (int s0 = wave; s0 < steps; s0 += 8 * UN) {
-    uint4 a[UN][2][RG], b[UN][2];
+  const int tiles = K / 128;
+  for (int s0 = wave; s0 < tiles; s0 += 8 * UN) {
+    uint4 wreg[UN][RG][4], xb[UN][4];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int s = s0 + 8 * u;
-      const bool ok = s < steps;
-      const int k0 = 64 * (ok ? s : s0);                    // past the end: re-read a valid step, its x is zeroed
+      const bool ok = s < tiles;
+      const int k0 = 128 * (ok ? s : s0);                   // past the end: re-read a valid tile, its x is zeroed
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
+      for (int q = 0; q < RG; ++q)
 #pragma unroll
-        for (int q = 0; q < RG; ++q) a[u][hf][q] = ldg_nt(reinterpret_cast<const uint4*>(wrow[q] + k0 + 32 * hf));
-        b[u][hf] = make_uint4(0u, 0u, 0u, 0u);
-        if (col_ok && ok) b[u][hf] = *reinterpret_cast<const uint4*>(xrow + k0 + 32 * hf);     // lanes of absent scenes load nothing
+        for (int j = 0; j < 4; ++j) wreg[u][q][j] = ldg_nt(reinterpret_cast<const uint4*>(wbase[q] + (int64_t)(4 * j) * ldw + k0));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xb[u][t] = make_uint4(0u, 0u, 0u, 0u);
+        if (col_ok && ok) xb[u][t] = *reinterpret_cast<const uint4*>(xrow + k0 + 32 * t);     // lanes of absent scenes load nothing
       }
     }
 #pragma unroll
-    for (int u = 0; u < UN; ++u)
+    for (int u = 0; u < UN; ++u) {
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
+      for (int q = 0; q < RG; ++q)
 #pragma unroll
-        for (int q = 0; q < RG; ++q) acc[q] = dec_mfma(T{}, a[u][hf][q], b[u][hf], acc[q]);
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<uint4*>(&tile[wave][q][(4 * j + lr) * PITCH + lc * 16]) = wreg[u][q][j];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+          const uint4 a = *reinterpret_cast<const uint4*>(&tile[wave][q][r * PITCH + (4 * t + g) * 16]);
+          acc[q] = dec_mfma(T{}, a, xb[u][t], acc[q]);
+        }
+    }
   }
 #pragma unroll
   for (int q = 0; q < RG; ++q)
@@ -441,10 +458,12 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
   V3D_REQUIRE(x && W && out, "%s: null pointer", who);
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
   V3D_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldw >= K, "%s: bad shape N=%d K=%d", who, N, K);
-  // 1..4 rows: the VALU form (bit-identical to the single-row kernel, and the faster one at these sizes); 5..16 rows: the
-  // matrix-core form, whose cost does not grow with M (same values up to the f32 summation order)
-  const bool mfma_ok = !norm_weight && K % 64 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
-  const bool mfma = mfma_ok && M > 4;
+  // one row: the VALU form (fastest for a single scene, fuses the norm); 2..16 rows: the matrix-core form, whose cost does
+  // not grow with M and whose columns are independent - a scene's bits are the same in every group of two or more.
+  // (Against the one-row form the values differ by the f32 summation order.)  Shapes the matrix-core form does not take
+  // fall back to the VALU form with up to 4 rows.
+  const bool mfma_ok = !norm_weight && K % 128 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
+  const bool mfma = mfma_ok && M >= 2;
   V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? 16 : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? 16 : 4, M);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
   V3D_REQUIRE(aligned16(x) && aligned16(W) && (!norm_weight || aligned16(norm_weight)), "%s: alignment", who);

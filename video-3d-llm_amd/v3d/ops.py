@@ -400,9 +400,10 @@ def linear_decode(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=None, ep
 
 
 def linear_decode_rows(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=None, epilogue=DEC_NONE):
-    """M activation rows x [M, K] against w [N, K] in ONE pass over the weights (scenes decoding together).  M <= 4: row m
-    of out [M, N'] is bit-identical to linear_decode(x[m], ...); 5 <= M <= 16 (no fused norm, K % 64 == 0, N % 16 == 0):
-    matrix-core form, same values up to the f32 summation order."""
+    """M activation rows x [M, K] against w [N, K] in ONE pass over the weights (scenes decoding together).  2 <= M <= 16
+    (no fused norm, K % 128 == 0, N % 16 == 0): matrix-core form - a row's result depends neither on the other rows nor
+    on M, and equals linear_decode(x[m], ...) up to the f32 summation order.  Other shapes: VALU form, M <= 4, rows
+    bit-identical to linear_decode."""
     N, K = w.shape
     M = x.shape[0]
     check(lib().v3d_linear_decode_rows(_p(x), x.stride(0), M, _p(norm_weight), eps, _p(w), w.stride(0), _p(bias), _p(res),
