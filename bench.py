@@ -6,7 +6,10 @@ One step = one (scene, question) through the whole hot path with inputs resident
   (K3+K4) -> SigLIP-so400m tower, 26 layers (K10-K11) -> mlp2x_gelu projector (K12) -> bilinear 27->14 pool
   + 3-D sinusoid PE add + newline rows, written into inputs_embeds (K5-K9) -> Qwen2-7B prefill over
   6720 visual + 74 text tokens (K13-K18) -> 16 greedy decode steps.
-Random-init weights at the true widths, synthetic inputs, bf16.
+Random-init weights at the true widths, synthetic inputs, bf16.  Every scene runs the complete path; scenes
+are prefilled one by one and decoded in groups (--decode-group, default 16) that share each pass over the weights.
+The default N = 1 line also carries `fp8_config3` (the same step with e4m3 LLM weights, BASELINE configs[3]), `roofline`
+(north-star 3D-PE+fusion kernel, HBM), `roofline_dominant` (largest GEMM), `roofline_attention` and `cpu_baseline`.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
@@ -175,11 +178,11 @@ def cpu_baseline(threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one scene at a time: no decode groups, no prefill/decode overlap")
-    ap.add_argument("--decode-group", type=int, default=8, help="scenes decoded together per pass over the weights (1..16)")
+    ap.add_argument("--decode-group", type=int, default=16, help="scenes decoded together per pass over the weights (1..16)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[3]: e4m3 linears in the Qwen2 prefill; the headline line becomes that run")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip the extra configs[3] measurement appended to the default N=1 line")
     a = ap.parse_args()
