@@ -224,7 +224,7 @@ def main():
 
     def measure(eng, stamps):
         """W untimed warm-up scenes, then EXACTLY `steps` scenes between barrier + synchronize; max over ranks."""
-        G = min(G_ALL, 4) if eng.llm_fp8 else G_ALL          # the e4m3 decode linear takes up to 4 rows
+        G = G_ALL
         sets = [[eng.ctx] + [eng.new_context() for _ in range(G - 1)], [eng.new_context() for _ in range(G)]]
         groups = [eng.new_group(G), eng.new_group(G)]
         for w in range(a.warmup):

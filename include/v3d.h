@@ -230,7 +230,9 @@ int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_w
                            int K, int dtype, int epilogue, void* stream);
 /* The decode linear over OCP e4m3 weights (BASELINE configs[3]; W8A16): W8 [N,K] bytes (row stride ldw) with one
  * f32 scale per output row as v3d_quantize_fp8_rows writes them; y[m,n] = scale_w[n] * sum_k W8[n,k] x[m,k], then
- * the epilogue of v3d_linear_decode.  K % 16 == 0.  Not a reference code path (tolerance: tests/test_gpu_fp8.py). */
+ * the epilogue of v3d_linear_decode.  K % 16 == 0.  M = 1: VALU form; M = 2..16 with K % 256 == 0, N % 16 == 0: matrix-core
+ * form (weights widened to the activation type in registers; a row's result depends neither on the other rows nor on
+ * M); other shapes: VALU form, M <= 4.  Not a reference code path (tolerance: tests/test_gpu_fp8.py). */
 int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8, int64_t ldw, const float* scale_w,
                                const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K,
                                int dtype, int epilogue, void* stream);

@@ -140,8 +140,8 @@ def test_engine_prefill_fp8_close_to_bf16():
     assert torch.isfinite(lb2).all()
 
 
-@pytest.mark.parametrize("M", [1, 2, 4])
-@pytest.mark.parametrize("K,N", [(3584, 512), (18944, 256), (256, 384)])
+@pytest.mark.parametrize("M", [1, 2, 4, 9, 16])
+@pytest.mark.parametrize("K,N", [(3584, 512), (18944, 256), (256, 384), (400, 64)])
 def test_linear_decode_fp8_rows(M, K, N):
     """W8A16 decode linear: e4m3 weights (per-row scales) x 16-bit activations, against an f64 product of the SAME
     dequantised weights: only f32 accumulation and the output rounding remain (|err| <= 2^-8 |ref| + 2^-9 rms)."""
@@ -150,6 +150,10 @@ def test_linear_decode_fp8_rows(M, K, N):
     x = torch.randn(M, K, generator=g).to(dt).to(DEV)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dt).to(DEV)
     qw, sw = ops.quantize_fp8_rows(w)
+    if M > 4 and K % 256:                              # odd shapes have no matrix-core form: up to 4 rows only
+        with pytest.raises(Exception, match="activation rows"):
+            ops.linear_decode_fp8_rows(x, qw, sw, torch.empty(M, N, dtype=dt, device=DEV))
+        return
     wd = _deq(qw, sw)                                            # [N, K] f64
     ref = x.double() @ wd.T
     b = torch.randn(N, generator=g).to(dt).to(DEV)
@@ -174,8 +178,14 @@ def test_linear_decode_fp8_rows(M, K, N):
         rr = ref.to(dt).float().view(M, N // 128, 2, 64)
         want = (torch.nn.functional.silu(rr[:, :, 0]).to(dt).float() * rr[:, :, 1]).reshape(M, N // 2).double()
         check(act, want, slack=4.0)
-    # a row's result does not depend on the other rows of the batch
-    one = torch.empty(1, N, dtype=dt, device=DEV)
-    ops.linear_decode_fp8_rows(x[M - 1: M], qw, sw, one)
+    # a row's result does not depend on the other rows of the batch (nor on M within the same form: M >= 2 matrix-core
+    # when K % 256 == 0, else VALU)
     ops.linear_decode_fp8_rows(x, qw, sw, out)
-    assert torch.equal(out[M - 1], one[0])
+    if M >= 3:
+        sub = torch.empty(2, N, dtype=dt, device=DEV)
+        ops.linear_decode_fp8_rows(x[M - 2:], qw, sw, sub)
+        assert torch.equal(out[M - 2:], sub)
+    if M == 1 or K % 256:
+        one = torch.empty(1, N, dtype=dt, device=DEV)
+        ops.linear_decode_fp8_rows(x[M - 1: M], qw, sw, one)
+        assert torch.equal(out[M - 1], one[0])

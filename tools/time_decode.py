@@ -58,7 +58,7 @@ def tm8(name, N, K, epi, M, iters=40):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print(f"fp8 {name:8s} M={M} N={N:6d} K={K:6d} {us:8.1f} us  {N*K/us/1e6:6.2f} TB/s")
-for M in (1, 4):
+for M in (1, 4, 16):
     tm8("qkv", 4608, 3584, 0, M)
     tm8("o_proj", 3584, 3584, 2, M)
     tm8("gate_up", 37888, 3584, 3, M)

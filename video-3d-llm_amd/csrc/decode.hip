@@ -523,20 +523,137 @@ extern "C" int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const v
                             "v3d_linear_decode_rows");
 }
 
+// Matrix-core form of the e4m3 decode linear (W8A16, 2..16 scenes): as linear_decode_mfma_kernel, but a tile is 16 rows x
+// 256 BYTES = 256 weights, loaded with full-line coalescing into the wave-private LDS tile; the fragment of a k step is 8
+// bytes per lane, widened to the activation type by v_cvt_scalef32_pk_{bf16,f16}_fp8 (exact: e4m3 has 3 mantissa bits)
+// and fed to v_mfma_f32_16x16x32 against the 16-bit activation rows.  The per-row weight scale is applied in the epilogue.
+__device__ __forceinline__ uint4 dec_widen_fp8(bf16_t, uint2 w8) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 p0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w8.x, 1.0f, false), p1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w8.x, 1.0f, true);
+  const b2 p2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w8.y, 1.0f, false), p3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w8.y, 1.0f, true);
+  return make_uint4(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1), __builtin_bit_cast(uint32_t, p2), __builtin_bit_cast(uint32_t, p3));
+}
+__device__ __forceinline__ uint4 dec_widen_fp8(f16_t, uint2 w8) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 p0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w8.x, 1.0f, false), p1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w8.x, 1.0f, true);
+  const h2 p2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w8.y, 1.0f, false), p3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w8.y, 1.0f, true);
+  return make_uint4(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1), __builtin_bit_cast(uint32_t, p2), __builtin_bit_cast(uint32_t, p3));
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void linear_decode_fp8_mfma_kernel(const T* __restrict__ x, int64_t ldx, int M, const uint8_t* __restrict__ W,
+                                                                     int64_t ldw, const float* __restrict__ sw, const T* __restrict__ bias,
+                                                                     const T* __restrict__ res, int64_t ldr, T* __restrict__ out, int64_t ldo,
+                                                                     int N, int K) {
+  constexpr int RG = EPI == DEC_EPI_SWIGLU ? 2 : 1;
+  constexpr int PITCH = 272;
+  __shared__ __attribute__((aligned(16))) char tile[8][RG][16 * PITCH];
+  __shared__ float part[8][RG][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int o0 = blockIdx.x * 16;
+  int row0[RG];
+  if (EPI == DEC_EPI_SWIGLU) { row0[0] = (o0 >> 6) * 128 + (o0 & 63); row0[RG - 1] = row0[0] + 64; }
+  else row0[0] = o0;
+  const uint8_t* wbase[RG];
+#pragma unroll
+  for (int q = 0; q < RG; ++q) wbase[q] = W + (int64_t)(row0[q] + lr) * ldw + 16 * lc;
+  const bool col_ok = r < M;
+  const T* xrow = x + (int64_t)(col_ok ? r : 0) * ldx + 8 * g;
+  dec_f32x4 acc[RG];
+#pragma unroll
+  for (int q = 0; q < RG; ++q) acc[q] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tiles = K / 256;
+  for (int s = wave; s < tiles; s += 8) {
+    const int k0 = 256 * s;
+    uint4 wreg[RG][4], xb[8];
+#pragma unroll
+    for (int q = 0; q < RG; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wreg[q][j] = ldg_nt(reinterpret_cast<const uint4*>(wbase[q] + (int64_t)(4 * j) * ldw + k0));
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      xb[t] = make_uint4(0u, 0u, 0u, 0u);
+      if (col_ok) xb[t] = *reinterpret_cast<const uint4*>(xrow + k0 + 32 * t);
+    }
+#pragma unroll
+    for (int q = 0; q < RG; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<uint4*>(&tile[wave][q][(4 * j + lr) * PITCH + lc * 16]) = wreg[q][j];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int q = 0; q < RG; ++q) {
+        const uint2 w8 = *reinterpret_cast<const uint2*>(&tile[wave][q][r * PITCH + (4 * t + g) * 8]);
+        acc[q] = dec_mfma(T{}, dec_widen_fp8(T{}, w8), xb[t], acc[q]);
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < RG; ++q)
+    *reinterpret_cast<float4*>(&part[wave][q][lane * 4]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+  __syncthreads();
+  if (tid < 256) {
+    const int l = tid >> 2, i = tid & 3;
+    const int row = 4 * (l >> 4) + i, m = l & 15;
+    float v[RG];
+#pragma unroll
+    for (int q = 0; q < RG; ++q) {
+      v[q] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v[q] += part[w][q][tid];
+      v[q] *= sw[row0[q] + row];
+    }
+    if (m < M) {
+      const int n = o0 + row;
+      if (EPI == DEC_EPI_SWIGLU) {
+        const float gt = round_to<T>(v[0]), up = round_to<T>(v[RG - 1]);
+        out[m * ldo + n] = from_f32<T>(round_to<T>(silu_f(gt)) * up);
+      } else {
+        float y = v[0];
+        if (EPI == DEC_EPI_BIAS) y += to_f32(bias[n]);
+        y = round_to<T>(y);
+        if (EPI == DEC_EPI_RES) y += to_f32(res[m * ldr + n]);
+        out[m * ldo + n] = from_f32<T>(y);
+      }
+    }
+  }
+}
+
 extern "C" int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8, int64_t ldw, const float* scale_w,
                                           const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K,
                                           int dtype, int epilogue, void* stream) {
   const char* who = "v3d_linear_decode_fp8_rows";
   V3D_REQUIRE(x && W8 && scale_w && out, "%s: null pointer", who);
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
-  V3D_REQUIRE(M >= 1 && M <= 4, "%s: 1 to 4 activation rows (got %d)", who, M);
   V3D_REQUIRE(N > 0 && K > 0 && K % 16 == 0 && ldw % 16 == 0 && ldw >= K, "%s: bad shape N=%d K=%d", who, N, K);
+  // one row: VALU form; 2..16 rows: matrix-core form when the shape allows (a row's bits then depend neither on the other
+  // rows nor on M); other shapes: VALU form with up to 4 rows
+  const bool mfma_ok = K % 256 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
+  const bool mfma = mfma_ok && M >= 2;
+  V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? 16 : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? 16 : 4, M);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
   V3D_REQUIRE(aligned16(x) && aligned16(W8) && (M == 1 || (ldx % 8 == 0 && ldx >= K)), "%s: alignment", who);
   V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "%s: bias epilogue without bias", who);
   V3D_REQUIRE(epilogue != DEC_EPI_RES || res, "%s: residual epilogue without residual", who);
-  const int blocks = N / 4;
   hipStream_t st = (hipStream_t)stream;
+  if (mfma) {
+    const int mblocks = (epilogue == DEC_EPI_SWIGLU ? N / 2 : N) / 16;
+#define V3D_LD8M(TT, EE) hipLaunchKernelGGL((linear_decode_fp8_mfma_kernel<TT, EE>), dim3(mblocks), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                            (const uint8_t*)W8, ldw, scale_w, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LD8M_E(TT)                                                                                \
+  switch (epilogue) {                                                                                 \
+    case DEC_EPI_NONE: V3D_LD8M(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LD8M(TT, DEC_EPI_BIAS); break; \
+    case DEC_EPI_RES: V3D_LD8M(TT, DEC_EPI_RES); break; case DEC_EPI_SWIGLU: V3D_LD8M(TT, DEC_EPI_SWIGLU); break; \
+    default: set_error("%s: unknown epilogue %d", who, epilogue); return V3D_E_INVALID;               \
+  }
+    if (dtype == V3D_BF16) { V3D_LD8M_E(bf16_t) } else { V3D_LD8M_E(f16_t) }
+#undef V3D_LD8M_E
+#undef V3D_LD8M
+    return check_launch(who);
+  }
+  const int blocks = N / 4;
 #define V3D_LD8(TT, EE, MM)                                                                                                   \
   hipLaunchKernelGGL((linear_decode_fp8_kernel<TT, EE, MM>), dim3(blocks), dim3(256), 0, st, (const TT*)x, ldx, (const uint8_t*)W8, ldw, \
                      scale_w, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
