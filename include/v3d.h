@@ -154,6 +154,11 @@ int v3d_quantize_fp8_rows(const void* x, int64_t ldx, int64_t rows, int cols, in
 int v3d_gemm_fp8(const void* A, int64_t lda, const float* scale_a, const void* W, int64_t ldw, const float* scale_w,
                  const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int M, int N, int K,
                  int out_dtype, int epilogue, void* stream);
+/* v3d_rmsnorm fused with v3d_quantize_fp8_rows of its output (the 16-bit normalised row is formed and rounded exactly as
+ * v3d_rmsnorm does, but never stored): q [rows, cols] e4m3 + scale[rows].  Bit-identical to the two calls in sequence
+ * (rows > 4; v3d_rmsnorm's decode-order kernel for <= 4 rows sums in another order).  cols <= 4096. */
+int v3d_rmsnorm_quantize_fp8(const void* x, int64_t ldx, const void* weight, float eps, int64_t rows, int cols, int dtype,
+                             void* q, int64_t ldq, float* scale, void* stream);
 
 /* ------------------------------------------------------------------ norms / rotary ------ */
 

@@ -189,3 +189,16 @@ def test_linear_decode_fp8_rows(M, K, N):
         one = torch.empty(1, N, dtype=dt, device=DEV)
         ops.linear_decode_fp8_rows(x[M - 1: M], qw, sw, one)
         assert torch.equal(out[M - 1], one[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols", [(5, 3584), (300, 256), (6794, 3584)])
+def test_rmsnorm_quantize_fused_bit_identical_to_two_calls(dtype, rows, cols):
+    x = _rand(rows, cols, dtype, rows + cols)
+    w = (1 + 0.1 * _rand(1, cols, dtype, 3, outlier=False)[0]).to(dtype)
+    h = ops.rmsnorm(x, w, 1e-6)
+    q_ref, s_ref = ops.quantize_fp8_rows(h)
+    q = torch.empty_like(q_ref)
+    s = torch.empty_like(s_ref)
+    ops.rmsnorm_quantize_fp8(x, w, 1e-6, q, s)
+    assert torch.equal(s, s_ref) and torch.equal(q, q_ref)

@@ -267,6 +267,67 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restr
   }
 }
 
+// Qwen2RMSNorm (modeling_qwen2.py:85-90) fused with the row-wise e4m3 quantisation of its output: the normalised row
+// y = w * T(x * rstd) is formed exactly as v3d_rmsnorm forms it (rounded to T), its amax gives the scale, and only the
+// e4m3 image + scale leave the chip (one read of x, half a write) - the 16-bit y is never stored.  One wave per row,
+// cols <= 4096.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_quantize_fp8_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, float eps,
+                                                                   int64_t rows, int cols, uint8_t* __restrict__ q, int64_t ldq,
+                                                                   float* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = cols / 8;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + row * ldx);
+  uint4 v[8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = i * 64 + lane;
+    if (k < nv) {
+      v[i] = xr[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(v[i], j); ss = fmaf(f, f, ss); }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  const float r = 1.0f / sqrtf(ss / (float)cols + eps);
+  float y[8][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = i * 64 + lane;
+    if (k < nv) {
+      const uint4 wv = reinterpret_cast<const uint4*>(w)[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        y[i][j] = round_to<T>(vec_get<T>(wv, j) * round_to<T>(vec_get<T>(v[i], j) * r));
+        amax = fmaxf(amax, fabsf(y[i][j]));
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  uint2* qr = reinterpret_cast<uint2*>(q + row * ldq);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = i * 64 + lane;
+    if (k < nv) {
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][0] * inv, y[i][1] * inv, w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][2] * inv, y[i][3] * inv, w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][4] * inv, y[i][5] * inv, w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(y[i][6] * inv, y[i][7] * inv, w1, true);
+      qr[k] = make_uint2((uint32_t)w0, (uint32_t)w1);
+    }
+  }
+}
+
 template <typename T, int MT>
 static int launch_fp8(Fp8GemmArgs p, int epi, hipStream_t st) {
   constexpr int BM = MT * 32;
@@ -328,4 +389,18 @@ extern "C" int v3d_gemm_fp8(const void* A, int64_t lda, const float* scale_a, co
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldo = ldo;
   hipStream_t st = (hipStream_t)stream;
   return out_dtype == V3D_BF16 ? launch_fp8<bf16_t, 8>(p, epilogue, st) : launch_fp8<f16_t, 8>(p, epilogue, st);
+}
+
+extern "C" int v3d_rmsnorm_quantize_fp8(const void* x, int64_t ldx, const void* weight, float eps, int64_t rows, int cols, int dtype,
+                                        void* q, int64_t ldq, float* scale, void* stream) {
+  V3D_REQUIRE(x && weight && q && scale, "v3d_rmsnorm_quantize_fp8: null pointer");
+  V3D_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096, "v3d_rmsnorm_quantize_fp8: cols=%d unsupported", cols);
+  V3D_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && aligned16(x) && aligned16(weight) && (reinterpret_cast<uintptr_t>(q) & 7) == 0,
+              "v3d_rmsnorm_quantize_fp8: alignment");
+  if (rows == 0) return V3D_OK;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  if (dtype == V3D_BF16) hipLaunchKernelGGL(rmsnorm_quantize_fp8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const bf16_t*)weight, eps, rows, cols, (uint8_t*)q, ldq, scale);
+  else if (dtype == V3D_F16) hipLaunchKernelGGL(rmsnorm_quantize_fp8_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, ldx, (const f16_t*)weight, eps, rows, cols, (uint8_t*)q, ldq, scale);
+  else { set_error("v3d_rmsnorm_quantize_fp8: dtype must be f16 or bf16"); return V3D_E_INVALID; }
+  return check_launch("v3d_rmsnorm_quantize_fp8");
 }

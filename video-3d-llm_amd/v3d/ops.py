@@ -294,6 +294,15 @@ def quantize_fp8_rows(x, q=None, scale=None):
     return q, scale
 
 
+def rmsnorm_quantize_fp8(x, weight, eps, q, scale):
+    """RMSNorm + row-wise e4m3 quantisation in one pass: q [rows, cols] uint8 and scale [rows] f32 are written, the 16-bit
+    normalised rows are not."""
+    rows, cols = x.shape
+    check(lib().v3d_rmsnorm_quantize_fp8(_p(x), x.stride(0), _p(weight), eps, rows, cols, _code(x), _p(q), q.stride(0), _p(scale),
+                                         _stream()), "v3d_rmsnorm_quantize_fp8")
+    return q, scale
+
+
 def gemm_fp8(qa, sa, qw, sw, out_dtype, bias=None, res=None, epilogue=EPI_NONE, out=None):
     """out = epilogue( (qa @ qw.T) * sa[:,None] * sw[None,:] ); qa [M,K], qw [N,K] e4m3 bytes."""
     M, K = qa.shape
