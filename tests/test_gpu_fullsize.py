@@ -135,3 +135,45 @@ def test_fp8_path_close_to_bf16_at_full_size(full):
     assert S8 == S
     assert rel(e8.ctx.kv[0][:S], c.kv[0][:S]) < 0.06
     assert rel(e8.last_hidden(), ref_hidden) < 0.20
+
+
+@pytest.mark.parametrize("S", [6794, 8192])
+def test_prefill_attention_full_length_vs_f32_reference(full, S):
+    """Causal GQA prefill attention at the bench length and at the engine's capacity against a plain f32 torch reference
+    (computed head by head on the device): |err| <= 6 ulp(bf16) of max(|ref|, 0.3).  The small-size tests hold 3 ulp; at
+    6.8k keys the largest scores reach |s| ~ 5, where the 16-bit rounding of the pre-scaled Q (2^-9 relative on a score)
+    moves a probability by 1-2 % - the same size of error the reference's eager path makes by rounding the scores
+    themselves to 16 bits (modeling_qwen2.py:289-299)."""
+    import math
+    ops = full["ops"]
+    H, KV, D = 28, 4, 128
+    g = torch.Generator(device="cuda").manual_seed(S)
+    q = torch.randn(1, S, H, D, generator=g, device="cuda").bfloat16()
+    k = torch.randn(1, S, KV, D, generator=g, device="cuda").bfloat16()
+    v = torch.randn(1, S, KV, D, generator=g, device="cuda").bfloat16()
+    got = ops.attention_bshd(q, k, v, causal=True)[0].float()          # [S, H, D]
+    scale = 1 / math.sqrt(D)
+    mask = torch.ones(S, S, dtype=torch.bool, device="cuda").triu(1)
+    worst = 0.0
+    for h in range(0, H, 3):                                             # every third head: all four kv heads are covered
+        s = (q[0, :, h].float() @ k[0, :, h // 7].float().t()) * scale
+        s.masked_fill_(mask, float("-inf"))
+        want = torch.softmax(s, -1) @ v[0, :, h // 7].float()
+        err = (got[:, h] - want).abs() / want.abs().clamp_min(0.3)
+        worst = max(worst, err.max().item())
+    assert worst <= 6.0 * 2.0 ** -8, worst
+
+
+def test_engine_capacity_errors(full):
+    from v3d._native import V3DError
+    eng = full["eng"]
+    with pytest.raises(V3DError, match="frames"):
+        eng.encode_images(torch.zeros(FRAMES + 1, 3, 384, 384, dtype=torch.bfloat16, device="cuda"))
+    feats = torch.zeros(FRAMES, 729, 3584, dtype=torch.bfloat16, device="cuda")
+    vox = torch.zeros(FRAMES, 14, 14, 3, dtype=torch.int32, device="cuda")
+    two = torch.cat([full["ids"], torch.tensor([-200])])
+    with pytest.raises(V3DError, match="exactly one"):
+        eng.build_inputs_embeds(two, feats, vox)
+    long = torch.cat([full["ids"], torch.zeros(8192 - 6794 + 1, dtype=torch.int64)])
+    with pytest.raises(V3DError, match="exceeds engine capacity"):
+        eng.build_inputs_embeds(long, feats, vox)
