@@ -280,3 +280,23 @@ def test_decode_group_ragged_lengths_close_to_single_scene():
 def ops_embed(eng, tok, ctx, S):
     from v3d import ops
     return ops.embed_gather(eng.embed, tok, out=ctx.l_x[S: S + 1])
+
+
+def test_generate_group_matches_group_decode_and_cuts_at_eos():
+    """Engine.generate_group = prefill each sample + decode them together; with an EOS id every row is cut after its
+    first EOS (as generate does); without one it equals decode_group on the same scenes."""
+    from v3d.engine import Engine, random_state_dict
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=15, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    scenes = _scenes(3, 16)
+    want = _group_decode(eng, scenes, 6)
+    got = eng.generate_group(scenes, max_new_tokens=6)
+    assert len(got) == 3 and all(torch.equal(g, w) for g, w in zip(got, want))
+    eos = int(want[1, 2])                          # pretend the third token of scene 1 is EOS
+    cut = eng.generate_group(scenes, max_new_tokens=6, eos_token_id=eos)
+    for m in range(3):
+        row = want[m].tolist()
+        n = row.index(eos) + 1 if eos in row else len(row)
+        assert cut[m].tolist() == row[:n]
+    assert eng.generate_group(scenes[:1], max_new_tokens=3)[0].shape[0] == 3

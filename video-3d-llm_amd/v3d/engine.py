@@ -491,6 +491,40 @@ class Engine:
         logits = self.llm_forward(x, 0)
         return self.decode_loop(logits, S, max_new_tokens, eos_token_id)
 
+    @torch.no_grad()
+    def generate_group(self, samples, max_new_tokens=16, eos_token_id=None):
+        """Throughput form of `generate` for up to 16 (input_ids, images, world_coords) samples: each is prefilled into its
+        own context, then all decode together (one pass over the weights per step).  Returns a list of token-id tensors,
+        each cut after its first EOS like `generate` does.  The contexts and the row buffers are cached on the engine."""
+        n = len(samples)
+        if not 1 <= n <= 16:
+            raise V3DError("generate_group takes 1 to 16 samples")
+        pool = self.__dict__.setdefault("_group_ctxs", [])
+        while len(pool) < n:
+            pool.append(self.new_context())
+        grp = self.__dict__.get("_group_rows")
+        if grp is None or grp.n < n:
+            grp = self._group_rows = self.new_group(16 if n > 4 else 4)
+        keep = self.ctx
+        lens = []
+        for c, (input_ids, images, world_coords) in zip(pool, samples):
+            self.use(c)
+            feats = self.encode_images(images)
+            ids = self.voxel_ids(world_coords.to(self.dtype))
+            x = self.build_inputs_embeds(input_ids, feats, ids)
+            self.llm_forward(x, 0)
+            lens.append(x.shape[0])
+        self.use(keep)
+        toks = self.decode_group(grp, pool[:n], lens, max_new_tokens)
+        out = []
+        for row in toks.cpu():
+            if eos_token_id is not None:
+                hit = (row == eos_token_id).nonzero()
+                if hit.numel():
+                    row = row[: int(hit[0]) + 1]
+            out.append(row.to(self.device))
+        return out
+
     # ------------------------------------------------------------------ scenes decoding together
     def new_group(self, n_scenes):
         """Row buffers for up to 16 scenes whose decode steps run as ONE pass over the weights (the decode step is
