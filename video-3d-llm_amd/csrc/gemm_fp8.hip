@@ -267,6 +267,52 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restr
   }
 }
 
+// Long rows (4096 < cols <= 32768, the SwiGLU output): one WORKGROUP per row with the row held in registers between the
+// amax reduction and the conversion - one read of the row instead of two.  Same arithmetic as the wave-per-row kernel
+// (amax is order-independent), so the results are bit-identical.
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_row_block_fp8_kernel(const T* __restrict__ x, int64_t ldx, int cols, uint8_t* __restrict__ q,
+                                                                     int64_t ldq, float* __restrict__ scale) {
+  constexpr int MAXV = 16;                          // 16-byte vectors per thread: 256 x 16 x 8 = 32768 columns
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + row * ldx);
+  const int nv = cols / 8;
+  uint4 v[MAXV];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv) {
+      v[i] = xr[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(vec_get<T>(v[i], j)));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+  const float inv = 1.0f / sc;
+  if (tid == 0) scale[row] = sc;
+  uint2* qr = reinterpret_cast<uint2*>(q + row * ldq);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv) {
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(vec_get<T>(v[i], 0) * inv, vec_get<T>(v[i], 1) * inv, w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(vec_get<T>(v[i], 2) * inv, vec_get<T>(v[i], 3) * inv, w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(vec_get<T>(v[i], 4) * inv, vec_get<T>(v[i], 5) * inv, w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(vec_get<T>(v[i], 6) * inv, vec_get<T>(v[i], 7) * inv, w1, true);
+      qr[k] = make_uint2((uint32_t)w0, (uint32_t)w1);
+    }
+  }
+}
+
 // Qwen2RMSNorm (modeling_qwen2.py:85-90) fused with the row-wise e4m3 quantisation of its output: the normalised row
 // y = w * T(x * rstd) is formed exactly as v3d_rmsnorm forms it (rounded to T), its amax gives the scale, and only the
 // e4m3 image + scale leave the chip (one read of x, half a write) - the 16-bit y is never stored.  One wave per row,
@@ -365,6 +411,12 @@ extern "C" int v3d_quantize_fp8_rows(const void* x, int64_t ldx, int64_t rows, i
   V3D_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && ldq >= cols, "v3d_quantize_fp8_rows: bad shape");
   V3D_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(q) & 7) == 0, "v3d_quantize_fp8_rows: alignment");
   if (rows == 0) return V3D_OK;
+  if (cols > 4096 && cols <= 32768 && rows < (1ll << 31)) {       // long rows: one workgroup per row, single read
+    if (dtype == V3D_BF16) hipLaunchKernelGGL(quantize_row_block_fp8_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, cols, (uint8_t*)q, ldq, scale);
+    else if (dtype == V3D_F16) hipLaunchKernelGGL(quantize_row_block_fp8_kernel<f16_t>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, ldx, cols, (uint8_t*)q, ldq, scale);
+    else { set_error("v3d_quantize_fp8_rows: dtype must be f16 or bf16"); return V3D_E_INVALID; }
+    return check_launch("v3d_quantize_fp8_rows");
+  }
   const unsigned blocks = (unsigned)((rows + 3) / 4);
   if (dtype == V3D_BF16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, rows, cols, (uint8_t*)q, ldq, scale);
   else if (dtype == V3D_F16) hipLaunchKernelGGL(quantize_rows_fp8_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)x, ldx, rows, cols, (uint8_t*)q, ldq, scale);
