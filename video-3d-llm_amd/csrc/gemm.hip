@@ -52,6 +52,7 @@ struct GemmArgs {
   int64_t lda, ldw, ldr, ldo;
   int res_mod;        // >0: residual row = m % res_mod (ViT position embedding)
   int tiles_m, tiles_n;
+  int dma_late;       // 256-wide kernel: restage after (1) or before (0) the last phase's MFMAs of a K-step
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -267,6 +268,13 @@ constexpr int GEMM3_LDS_BYTES = 2 * S3_BYTES;           // 128 KiB
 // fills whole rounds of the 256 CUs, e.g. M = 6794, N = 3584: 27 x 14 = 378 tiles (74 %) vs 36 x 14 = 504 (98 %)).
 // Register budget: <= 224 per lane (2 waves/SIMD = 448 of 512) leaves one 64-register slot per SIMD, which is
 // what a linear_decode wave of ANOTHER scene needs to stream weights beside this kernel (bench.py run_pipelined).
+#ifdef V3D_GEMM_PROF   // tools/probes/gemm_prof.hip only: per-wave shader-clock split of the K loop (never in the product build)
+__device__ unsigned long long g_gemm_prof[8 * 64];
+#define V3D_GSTAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#else
+#define V3D_GSTAMP(v)
+#endif
+
 template <typename T, int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -355,6 +363,11 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
     V3D_RDA(A0, a);
     V3D_RD4(B0, w);
   }
+#ifdef V3D_GEMM_PROF
+  unsigned long long gp_mma = 0, gp_wait = 0, gp_bar = 0, gp_tail = 0;
+  V3D_GSTAMP(gp_t0);
+  unsigned long long gp_prev = gp_t0;
+#endif
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     const unsigned ah0 = offA_hi + cur * S3_BYTES + fo0, al1 = offA + cur * S3_BYTES + fo1, ah1 = offA_hi + cur * S3_BYTES + fo1;
@@ -373,16 +386,34 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
     if constexpr (MG == 4) V3D_W8("lgkmcnt(4)", A0, B1); else V3D_W8("lgkmcnt(3)", A0, B1);
     V3D_MMA(A0, B1, 0);
     // phase 3: k-half 1, second group; tile t fully read, tile t+1 landed -> rendezvous, restage
+    V3D_GSTAMP(gp_a);
     V3D_W4("vmcnt(0) lgkmcnt(0)", A1);
+    V3D_GSTAMP(gp_b);
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nt) stage(cur, t + 2);
+    V3D_GSTAMP(gp_c);
+    if (!p.dma_late && t + 2 < nt) stage(cur, t + 2);
     {
       const unsigned a = offA + (cur ^ 1) * S3_BYTES + fo0, w = offW + (cur ^ 1) * S3_BYTES + fo0;
       V3D_RDA(A0, a);      // next tile's phase-0 fragments (last step: stale, unused)
       V3D_RD4(B0, w);
     }
     V3D_MMA(A1, B1, 1);
+    // dma_late: restage AFTER the phase's MFMAs.  All eight waves issue their DMAs right after the barrier, the
+    // vector-memory path backs up, and a wave stuck on DMA issue cannot issue the MFMAs behind it (tools/probes/
+    // gemm_prof.hip: the second wave of every SIMD spent 2000 cycles in this section, the first 830).  Short-K shapes
+    // gain 4-8 %; with a long K loop the later landing of the tile costs more than it saves, so the host picks by K.
+    if (p.dma_late && t + 2 < nt) stage(cur, t + 2);
+#ifdef V3D_GEMM_PROF
+    { V3D_GSTAMP(gp_d);
+      gp_mma += gp_a - gp_prev; gp_wait += gp_b - gp_a; gp_bar += gp_c - gp_b; gp_tail += gp_d - gp_c; gp_prev = gp_d; }
+#endif
   }
+#ifdef V3D_GEMM_PROF
+  if (lane == 0 && blockIdx.x < 8) {
+    unsigned long long* pr = g_gemm_prof + (blockIdx.x * 8 + wave) * 8;
+    pr[0] = gp_mma; pr[1] = gp_wait; pr[2] = gp_bar; pr[3] = gp_tail; pr[4] = gp_prev - gp_t0; pr[5] = (unsigned long long)nt;
+  }
+#endif
   V3D_W8("lgkmcnt(0)", A0, B0);
 #undef V3D_DSR
 #undef V3D_RD4
@@ -559,9 +590,21 @@ static int gemm_variant() {   // 0 = auto, 1 = force 128x128, 3 = force 256x256 
   return v;
 }
 
+static int gemm_dma_mode() {   // -1 = auto, 0 / 1 = force (A/B runs)
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("V3D_GEMM_DMA"); v = e ? atoi(e) : -1; }
+  return v;
+}
+
 template <typename T, int MT>
 static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
   constexpr int BM = MT * 32;
+  // late restage when both operands can live in the 256 MB Infinity Cache (their tiles then arrive well inside one K-step);
+  // operands streamed from HBM (gate/up: 271 MB of weights, down: 257 MB of activations) need the earlier issue.
+  // Measured (tools/gemm_ab.py): qkv 210 -> 199 us, o_proj 158 -> 152, SigLIP qkv 230 -> 220, fc1 245 -> 237; gate/up and
+  // down lose 3-5 % with the late form.
+  const double operand_bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
+  p.dma_late = gemm_dma_mode() >= 0 ? gemm_dma_mode() : (operand_bytes <= 200e6 ? 1 : 0);
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / B3N;
 #define V3D_GEMM3_CASE(E)                                                                                 \
