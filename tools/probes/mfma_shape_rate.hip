@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters, unsigned long
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 7) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
-int main() {
+int main(int argc, char** argv) {
+  const int nb = argc > 1 ? atoi(argv[1]) : 512;
   float* out; unsigned long long* clk; hipMalloc(&out, 512 * 256 * 4); hipMalloc(&clk, 16);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20000;
@@ -39,13 +40,13 @@ int main() {
     for (int shape : {16, 32}) {
       hipEventRecord(e0, 0);
       for (int l = 0; l < 5; ++l) {
-        if (shape == 16) hipLaunchKernelGGL(k<16>, dim3(512), dim3(256), 0, 0, out, iters, clk);
-        else hipLaunchKernelGGL(k<32>, dim3(512), dim3(256), 0, 0, out, iters, clk);
+        if (shape == 16) hipLaunchKernelGGL(k<16>, dim3(nb), dim3(256), 0, 0, out, iters, clk);
+        else hipLaunchKernelGGL(k<32>, dim3(nb), dim3(256), 0, 0, out, iters, clk);
       }
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
-      const double flops = 5.0 * 512 * 4 * (double)iters * (shape == 16 ? 32 * 16384.0 : 16 * 32768.0);
+      const double flops = 5.0 * nb * 4 * (double)iters * (shape == 16 ? 32 * 16384.0 : 16 * 32768.0);
       printf("mfma %dx%d: %.1f ms  %.0f TF/s  in-kernel clock %.0f MHz\n", shape, shape, ms, flops / ms / 1e9, (double)h[0] / h[1] * 100.0);
     }
   return 0;

@@ -295,30 +295,45 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
   const int m0 = tm * BM, n0 = tn * B3N;
 
   // per-lane source offsets in elements (32 bit: M*lda and N*ldw stay below 2^31 on this path; checked by the host)
-  unsigned a_off[APW], w_off[4];   // BYTE offsets, unsigned: lets the DMA use the SGPR-base + 32-bit VGPR-offset form
+  // Staging alternates between the two waves that share a SIMD (w and w ^ 4): in K-step t the waves with wm == (t & 1)
+  // issue the DMAs of BOTH (16 instructions), the others none.  When all eight waves restage right after the barrier the
+  // vector-memory path backs up and a wave stuck on DMA issue cannot issue the MFMAs behind it - with both waves of a SIMD
+  // stuck at once the matrix pipe idles (tools/probes/gemm_prof.hip); now one of them always runs MFMAs.
+  unsigned a_off[2][APW], w_off[2][4];   // [own / partner] BYTE offsets, unsigned: SGPR-base + 32-bit VGPR-offset DMA form
 #pragma unroll
-  for (int i = 0; i < APW; ++i) {
-    const int row = wave * (APW * 8) + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    int gm = m0 + row;
-    gm = gm < p.M ? gm : p.M - 1;
-    a_off[i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
-  }
+  for (int o = 0; o < 2; ++o) {
+    const int wv = o == 0 ? wave : (wave ^ 4);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    w_off[i] = (unsigned)((n0 + row) * (int)p.ldw + chunk * 8) * 2u;
+    for (int i = 0; i < APW; ++i) {
+      const int row = wv * (APW * 8) + i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int gm = m0 + row;
+      gm = gm < p.M ? gm : p.M - 1;
+      a_off[o][i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wv * 32 + i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      w_off[o][i] = (unsigned)((n0 + row) * (int)p.ldw + chunk * 8) * 2u;
+    }
   }
-  auto stage = [&](int buf, int kt) {
-    char* ba = smem + buf * S3_BYTES + (wave * APW * 8) * (BK * 2);
-    char* bw = smem + buf * S3_BYTES + T3_BYTES + (wave * 32) * (BK * 2);
+  auto stage_one = [&](int buf, int kt, int o) {
+    const int wv = o == 0 ? wave : (wave ^ 4);
+    char* ba = smem + buf * S3_BYTES + (wv * APW * 8) * (BK * 2);
+    char* bw = smem + buf * S3_BYTES + T3_BYTES + (wv * 32) * (BK * 2);
     const char* Ak = (const char*)p.A + (size_t)kt * (BK * 2);
     const char* Wk = (const char*)p.W + (size_t)kt * (BK * 2);
 #pragma unroll
-    for (int i = 0; i < APW; ++i) glds16(Ak + a_off[i], ba + i * 8 * (BK * 2));
+    for (int i = 0; i < APW; ++i) glds16(Ak + a_off[o][i], ba + i * 8 * (BK * 2));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(Wk + w_off[i], bw + i * 8 * (BK * 2));
+    for (int i = 0; i < 4; ++i) glds16(Wk + w_off[o][i], bw + i * 8 * (BK * 2));
+  };
+  auto stage = [&](int buf, int kt) {          // every wave its own share (prologue)
+    stage_one(buf, kt, 0);
+  };
+  auto stage_alt = [&](int buf, int kt, int turn) {      // steady state: the waves whose turn it is stage for the pair
+    if (wm == (turn & 1)) { stage_one(buf, kt, 0); stage_one(buf, kt, 1); }
   };
 
   // all wave row bases are multiples of 16, so ((row>>1)&7) == ((lane>>1)&7)
@@ -341,8 +356,13 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
 #define V3D_RD4(f, base) { V3D_DSR(f[0], base, 0); V3D_DSR(f[1], base, 2048); V3D_DSR(f[2], base, 4096); V3D_DSR(f[3], base, 6144); }
 #define V3D_RD3(f, base) { V3D_DSR(f[0], base, 0); V3D_DSR(f[1], base, 2048); V3D_DSR(f[2], base, 4096); }
 #define V3D_RDA(f, base) { if constexpr (MG == 4) V3D_RD4(f, base) else V3D_RD3(f, base) }
+#ifdef V3D_GEMM_NOWAIT   // probe only (WRONG RESULTS): fragment waits removed, to see how much of a K-step is LDS latency
+#define V3D_W4(cnt, f) asm volatile("s_nop 0" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+#define V3D_W8(cnt, f, g) asm volatile("s_nop 0" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : : "memory")
+#else
 #define V3D_W4(cnt, f) asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
 #define V3D_W8(cnt, f, g) asm volatile("s_waitcnt " cnt : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : : "memory")
+#endif
 #define V3D_MMA(FA, FB, G)                                                                             \
   {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                     \
@@ -391,18 +411,15 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
     V3D_GSTAMP(gp_b);
     __builtin_amdgcn_s_barrier();
     V3D_GSTAMP(gp_c);
-    if (!p.dma_late && t + 2 < nt) stage(cur, t + 2);
+    if (!p.dma_late && t + 2 < nt) stage_alt(cur, t + 2, t);
     {
       const unsigned a = offA + (cur ^ 1) * S3_BYTES + fo0, w = offW + (cur ^ 1) * S3_BYTES + fo0;
       V3D_RDA(A0, a);      // next tile's phase-0 fragments (last step: stale, unused)
       V3D_RD4(B0, w);
     }
     V3D_MMA(A1, B1, 1);
-    // dma_late: restage AFTER the phase's MFMAs.  All eight waves issue their DMAs right after the barrier, the
-    // vector-memory path backs up, and a wave stuck on DMA issue cannot issue the MFMAs behind it (tools/probes/
-    // gemm_prof.hip: the second wave of every SIMD spent 2000 cycles in this section, the first 830).  Short-K shapes
-    // gain 4-8 %; with a long K loop the later landing of the tile costs more than it saves, so the host picks by K.
-    if (p.dma_late && t + 2 < nt) stage(cur, t + 2);
+    // dma_late (A/B option): restage after the phase's MFMAs instead of before them
+    if (p.dma_late && t + 2 < nt) stage_alt(cur, t + 2, t);
 #ifdef V3D_GEMM_PROF
     { V3D_GSTAMP(gp_d);
       gp_mma += gp_a - gp_prev; gp_wait += gp_b - gp_a; gp_bar += gp_c - gp_b; gp_tail += gp_d - gp_c; gp_prev = gp_d; }
@@ -599,12 +616,8 @@ static int gemm_dma_mode() {   // -1 = auto, 0 / 1 = force (A/B runs)
 template <typename T, int MT>
 static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
   constexpr int BM = MT * 32;
-  // late restage when both operands can live in the 256 MB Infinity Cache (their tiles then arrive well inside one K-step);
-  // operands streamed from HBM (gate/up: 271 MB of weights, down: 257 MB of activations) need the earlier issue.
-  // Measured (tools/gemm_ab.py): qkv 210 -> 199 us, o_proj 158 -> 152, SigLIP qkv 230 -> 220, fc1 245 -> 237; gate/up and
-  // down lose 3-5 % with the late form.
-  const double operand_bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K);
-  p.dma_late = gemm_dma_mode() >= 0 ? gemm_dma_mode() : (operand_bytes <= 200e6 ? 1 : 0);
+  // (V3D_GEMM_DMA=1 moves the restage behind the last phase's MFMAs; with the alternating staging it no longer pays)
+  p.dma_late = gemm_dma_mode() > 0 ? 1 : 0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / B3N;
 #define V3D_GEMM3_CASE(E)                                                                                 \
