@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import random
+import re
 import sys
 import types
 
@@ -487,6 +488,118 @@ def g_imgproc():
     assert pv.dtype == torch.float32 and tuple(pv.shape) == (2, 3, 384, 384)
     save("imgproc", frames=frames[:, :96, :96].copy(), pixel_values=pv[:, :, :96, :96].numpy().copy(),
          full_sum=np.array(pv.double().sum().item()), small=small, small_pixel_values=pv_small[0, :, ::16, ::16].numpy().copy())
+
+
+def _bits(t):
+    """bf16-representable f32 tensor -> raw bf16 bits (uint16), the compact storage form of the tiny-model weights."""
+    b = t.detach().to(torch.bfloat16)
+    assert torch.equal(b.float(), t.detach().float())
+    return b.view(torch.int16).numpy().view(np.uint16)
+
+
+def g_tiny_model():
+    """Whole-model golden: a random-init tiny LlavaQwenForCausalLM (the reference's own class: llava_qwen.py:43-119)
+    with a 2-layer SigLIP tower (siglip_encoder.py:538-589, true 384/14 geometry and head dim 72), the mlp2x_gelu projector,
+    PositionEmbeddingSine3D and a 2-layer Qwen2 (head dim 128), run through the reference's own
+    prepare_inputs_labels_for_multimodal (llava_arch.py:336-836) + Qwen2ForCausalLM.forward (modeling_qwen2.py:1132-1217):
+    inputs_embeds, last-row logits, greedy continuation (each step = the reference forward over the sequence extended by the
+    chosen token, use_cache=False: HF's cache classes drifted under the installed transformers, the arithmetic of the
+    eager path is the same) and the ScanRefer-style grounding forward (use_object_proposals=True -> predict_box, infonce).
+    Cases: F = 2 frames in f32 / bf16 / f16, F = 8 frames (BASELINE configs[0]) in f16 (the eval dtype, builder.py:27)."""
+    from llava.model.language_model import llava_qwen as lq
+    from llava.model.multimodal_encoder import siglip_encoder as se
+    from llava.model.multimodal_projector.builder import build_vision_projector
+    H, VH = 256, 144
+    cfg = lq.LlavaQwenConfig(vocab_size=320, hidden_size=H, intermediate_size=384, num_hidden_layers=2, num_attention_heads=2,
+                             num_key_value_heads=1, max_position_embeddings=4096, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                             use_sliding_window=False, attention_dropout=0.0)
+    cfg.rope_theta = 1000000.0
+    cfg._attn_implementation = "eager"
+    for k, v in dict(world_position_embedding_type="avg-discrete-sin3d", mm_spatial_pool_mode="bilinear", mm_spatial_pool_stride=2,
+                     voxel_size=0.1, min_xyz_range=[-15, -15, -5], max_xyz_range=[15, 15, 5], mm_patch_merge_type="spatial_unpad",
+                     mm_newline_position="grid", ground_head_type="infonce", ground_head_temperature=0.07,
+                     object_feature_type="patch14-pe", ground_token_ids=[318]).items():
+        setattr(cfg, k, v)
+    torch.manual_seed(71)
+    m = lq.LlavaQwenForCausalLM(cfg)
+    vcfg = se.SigLipVisionConfig(hidden_size=VH, intermediate_size=272, num_hidden_layers=3, num_attention_heads=2, image_size=384, patch_size=14)
+    tower = object.__new__(se.SigLipVisionTower)          # the class's forward/properties, without its hub download
+    torch.nn.Module.__init__(tower)
+    tower.is_loaded, tower.config, tower.vision_tower_name = True, vcfg, "tiny-random"
+    tower.vision_tower = se.SigLipVisionModel(vcfg)
+    del tower.vision_tower.vision_model.encoder.layers[-1:]          # load_model, siglip_encoder.py:570-571
+    tower.vision_tower.vision_model.head = torch.nn.Identity()
+    m.model.vision_tower = tower
+    m.model.mm_projector = build_vision_projector(types.SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=VH, hidden_size=H))
+    m.model.image_newline = torch.nn.Parameter(torch.zeros(H))
+    m.eval()
+    g = torch.Generator().manual_seed(72)
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            r = torch.randn(p_.shape, generator=g)
+            if ("norm" in n and n.endswith("weight")) or re.search(r"ground_head_(obj|query)\.2\.weight", n):
+                v = 1.0 + 0.1 * r
+            elif n.endswith("bias"):
+                v = 0.1 * r
+            elif "ground_head_zero_target" in n:
+                v = r
+            else:
+                v = 0.05 * r
+            p_.copy_(v.to(torch.bfloat16).float())                 # bf16-representable: one stored array serves every dtype
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()
+          if "post_layernorm" not in k and "position_ids" not in k and "inv_freq" not in k}
+    inv = {k: v.detach().clone() for k, v in m.named_buffers() if "inv_freq" in k}
+
+    def up8(x, dims):                                              # low-res -> 384 by 8x repetition (the stored form)
+        for d in dims:
+            x = x.repeat_interleave(8, dim=d)
+        return x
+
+    out = {}
+    cases = {"F2": (2, ("f32", "bf16", "f16")), "F8": (8, ("f16",))}
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+    for case, (Fr, kinds) in cases.items():
+        img_lo = torch.randn(Fr, 3, 48, 48, generator=g).half().float()
+        wc_lo = ((torch.rand(Fr, 48, 48, 3, generator=g) - 0.5) * torch.tensor([14.0, 14.0, 5.0])).half().float()
+        boxes = torch.cat([(torch.rand(5, 3, generator=g) - 0.5) * torch.tensor([8.0, 8.0, 2.0]), torch.rand(5, 3, generator=g) * 5 + 1.0], 1).half().float()
+        boxes[4] = torch.tensor([40.0, 40.0, 40.0, 0.5, 0.5, 0.5])            # selects nothing
+        text = torch.randint(0, 300, (11,), generator=g)
+        ids = torch.cat([text[:5], torch.tensor([-200]), text[5:]])[None]
+        gids = torch.cat([text[:5], torch.tensor([-200]), text[5:9], torch.tensor([318]), text[9:]])[None]      # one <ground> label
+        glabels = torch.full_like(gids, -100)
+        glabels[0, 10] = 318
+        images = up8(img_lo, (2, 3))[None]
+        wc = up8(wc_lo, (1, 2))[None]
+        out.update({f"{case}_img_lo": img_lo.numpy(), f"{case}_wc_lo": wc_lo.numpy(), f"{case}_boxes": boxes.numpy(),
+                    f"{case}_ids": ids[0].numpy(), f"{case}_gids": gids[0].numpy(), f"{case}_glabels": glabels[0].numpy()})
+        for kind in kinds:
+            dt = DT[kind]
+            m.to(dt)
+            for mod_name, b in inv.items():                       # from_pretrained(torch_dtype=...) keeps inv_freq f32 (see g_llm)
+                mod = m.get_submodule(mod_name.rsplit(".", 1)[0])
+                mod.inv_freq = b.float().clone()
+            vd = {"world_coords": wc.to(dt), "box_input": [], "objects": boxes.to(dt)[None]}
+            _, _, _, _, emb, _, _, _ = m.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images.to(dt), ["video"], None, vd)
+            logits = m(input_ids=ids, images=images.to(dt), modalities=["video"], video_dict=vd, use_cache=False).logits
+            seq, toks, steps = emb, [], []
+            lg = logits[0, -1]
+            for _ in range(4):
+                toks.append(int(torch.argmax(lg)))
+                if len(toks) == 4:
+                    break
+                seq = torch.cat([seq, m.get_model().embed_tokens(torch.tensor([[toks[-1]]]))], 1)
+                lg = m(inputs_embeds=seq, use_cache=False).logits[0, -1]
+                steps.append(lg)
+            _, scores = m(input_ids=gids, images=images.to(dt), modalities=["video"], video_dict=vd, labels=glabels,
+                          use_object_proposals=True, use_cache=False)
+            raw = (lambda t: t2n(t)) if dt == torch.bfloat16 else (lambda t: t.numpy())
+            out[f"{case}_embeds_{kind}"] = raw(emb[0])
+            out[f"{case}_logits_{kind}"] = logits[0, -1].numpy()          # lm_head(...).float(): f32 in every dtype
+            out[f"{case}_tokens_{kind}"] = np.array(toks, np.int64)
+            out[f"{case}_step_logits_{kind}"] = torch.stack(steps).numpy()
+            out[f"{case}_scores_{kind}"] = raw(scores)
+            m.float()
+    save("tiny_model", **{"w." + k: _bits(v) for k, v in sd.items()}, **out)
 
 
 GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}
