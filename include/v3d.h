@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 2   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries */
+#define V3D_ABI_VERSION 3   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ... */
 
 enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
 
@@ -57,6 +57,14 @@ int v3d_unproject_f32(const float* depth_mm, const float* intrinsics, const floa
  * `.half()` / model-dtype cast, llava/eval/model_scanqa.py:163-165). */
 int v3d_unproject_sampled_u16(const uint16_t* depth, const float* intrinsics, const float* poses,
                               void* out, int out_dtype, int V, int H, int W, int crop, void* stream);
+
+/* llava/video_utils.py:268-273 `boundry`: [x_min, x_max, y_min, y_max, z_min, z_max] of `unproject` over ALL V*H*W pixels (taken
+ * before the resize and crop), computed without materialising the full-resolution tensor: same per-pixel arithmetic as
+ * v3d_unproject_f32 on the u16 depth, reduced on the fly.  bounds: 6 floats (device).  workspace: device scratch of at
+ * least v3d_unproject_bounds_workspace_bytes(V) bytes. */
+int64_t v3d_unproject_bounds_workspace_bytes(int V);
+int v3d_unproject_bounds_u16(const uint16_t* depth, const float* intrinsics, const float* poses, int V, int H, int W,
+                             float* bounds, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* K3+K4  llava/model/llava_arch.py:213-223 `average_coordinate_in_patch` and :259-272
  * `discrete_coords`.  coords [V,S,S,3] (dtype), the last S - n*patch rows/cols are dropped
@@ -183,6 +191,19 @@ int v3d_rope_apply(void* x, int64_t ldx, int64_t tokens, int n_heads, int head_d
                    const void* cos_table, const void* sin_table, int n_pos, const int32_t* positions,
                    int pos0, int dtype, void* stream);
 
+/* Prefill form of K14 + the KV-cache append in one pass (modeling_qwen2.py:141-173, then DynamicCache.update as called at
+ * :283-285): rotary in place on the n_q query heads of every QKV row; the rotated key heads and the value heads of token t
+ * go to cache + r*ldc, r = dst_rows[t] (device int64 array) or row0 + t, laid out [k heads | v heads].  The k/v columns of
+ * the QKV buffer itself are left unrotated.  Token t uses positions[t] (device int32) or pos0 + t.  dst_rows lets several
+ * questions of one scene, prefilled together, append to their own caches inside one allocation. */
+int v3d_rope_kv_store(void* qkv, int64_t ldx, int64_t tokens, int n_q_heads, int n_kv_heads, int head_dim,
+                      const void* cos_table, const void* sin_table, int n_pos, const int32_t* positions, int pos0,
+                      void* cache, int64_t ldc, const int64_t* dst_rows, int64_t row0, int dtype, void* stream);
+
+/* llava_arch.py:697-700: x[rows[i], 0:C] += add[0:C] (the box-centre PE on the <coord> token rows of inputs_embeds);
+ * rows: device int64 [n_rows]; 16-bit dtypes; the sum is rounded once to dtype. */
+int v3d_add_row(void* x, int64_t ldx, const int64_t* rows, int n_rows, int C, const void* add, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ attention ----------- */
 
 /* K16 / K11  softmax(Q K^T * scale [+ causal mask]) V without materialising the scores.
@@ -209,8 +230,8 @@ int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache
 /* The same for M = 1..16 scenes decoding together in ONE launch pair (the single-scene kernels are latency-bound, not
  * bandwidth-bound): query rows q + m*q_stride, outputs o + m*o_stride (elements), per-scene cache pointers and lengths
  * in HOST arrays of M entries; workspace >= M * v3d_attention_decode_workspace_bytes(Hq, 1024/Hkv).  Scene m's output
- * is bit-identical to v3d_attention_decode on it alone when all scenes have the same length; with different lengths
- * the split count follows the longest scene (same values up to the f32 order of the split merge). */
+ * is bit-identical to v3d_attention_decode on it alone, whatever the other scenes' lengths: every scene partitions its keys
+ * by its own length (256 keys per split), the launch only adds empty splits for the shorter ones. */
 int v3d_attention_decode_rows(const void* q, int64_t q_stride, int M, const void* const* k_caches,
                               const void* const* v_caches, const int* Sk, void* o, int64_t o_stride, int dtype, int Hq,
                               int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale, void* workspace,
@@ -279,6 +300,12 @@ int v3d_ground_scores(const void* obj, int64_t ldo, int n_rows, const void* quer
 /* out[r, 0:cols] = in[r, 0:cols] for strided rows (KV-cache append). */
 int v3d_copy_rows(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int dtype,
                   void* stream);
+
+/* The same rows to n_copies destinations: out[c*copy_stride + r*ldo + 0:cols] = in[r*ldi + 0:cols], c < n_copies (the cached
+ * K/V prefix of a scene handed to the caches of the questions that are answered together; not a reference code path - the
+ * reference recomputes the prefix per question, llava/eval/model_scanqa.py:130-185). */
+int v3d_copy_rows_bcast(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int n_copies,
+                        int64_t copy_stride, int dtype, void* stream);
 
 /* a7: SigLipImageProcessor.preprocess, siglip_encoder.py:47-67, for frames that already have the tower's size (the
  * 384 x 384 crops of VideoProcessor.preprocess, video_utils.py:292-308, for which its bicubic resize is the identity):

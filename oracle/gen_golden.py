@@ -602,6 +602,48 @@ def g_tiny_model():
     save("tiny_model", **{"w." + k: _bits(v) for k, v in sd.items()}, **out)
 
 
+def g_world_coords():
+    """a4: VideoProcessor.calculate_world_coords (video_utils.py:196-238) on files written here the way the dataset holds
+    them (16-bit depth PNGs, 4x4 pose text files, an EmbodiedScan-style scene record): PIL u16 -> int32 -> f32, np.loadtxt,
+    axis_align @ pose in f64 then .float(), unproject; plus the `boundry` expression of preprocess (:268-273) on that output.
+    The file CONTENTS are stored (depth array, pose values as f64: np.savetxt's default %.18e round-trips them), the test
+    writes them back to disk and runs the mirror's loader."""
+    import tempfile
+    from PIL import Image
+    from llava.video_utils import VideoProcessor
+    rng = np.random.default_rng(81)
+    V, H, W = 3, 48, 64
+    depth = rng.integers(300, 6000, size=(V, H, W)).astype(np.uint16)
+    depth[1, :5, :7] = 0                                            # holes in the depth map
+    depth[2, 10, 10] = 40000                                        # above int16 range: the u16 -> int32 conversion must not wrap
+    poses = np.zeros((V, 4, 4))
+    for v in range(V):
+        a, b = 0.4 * v + 0.1, 0.3 - 0.25 * v
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        poses[v, :3, :3] = Rz @ Ry
+        poses[v, :3, 3] = rng.normal(size=3) * 1.5
+        poses[v, 3, 3] = 1
+    t = 0.7
+    align = np.array([[np.cos(t), np.sin(t), 0, -1.25], [-np.sin(t), np.cos(t), 0, 2.5], [0, 0, 1, -0.0625], [0, 0, 0, 1]])
+    K = np.array([[57.787, 0, 31.5, 0], [0, 57.9, 23.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    with tempfile.TemporaryDirectory() as d:
+        files = []
+        for v in range(V):
+            base = os.path.join(d, f"{v * 10:05d}")
+            Image.fromarray(depth[v]).save(base + ".png")
+            np.savetxt(base + ".txt", poses[v])
+            files.append(base + ".jpg")
+        vp = object.__new__(VideoProcessor)
+        vp.scene = {"scannet/scene0000_00": {"axis_align_matrix": align.tolist(), "depth_cam2img": K.tolist()}}
+        wc = vp.calculate_world_coords("scannet/scene0000_00", files)["world_coords"]
+    flat = wc.reshape(-1, 3)
+    boundry = torch.tensor([flat[:, 0].min().item(), flat[:, 0].max().item(), flat[:, 1].min().item(), flat[:, 1].max().item(),
+                            flat[:, 2].min().item(), flat[:, 2].max().item()])
+    save("world_coords", depth=depth, poses=poses, axis_align=align, cam2img=K, world=wc.numpy(), boundry=boundry.numpy(),
+         aligned_f32=torch.stack([torch.from_numpy(align) @ torch.from_numpy(p_) for p_ in poses]).float().numpy())
+
+
 GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}
 
 

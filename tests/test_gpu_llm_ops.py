@@ -209,7 +209,8 @@ def test_attention_decode_split_kv(ops, kind, Sk, H, KV):
 @pytest.mark.parametrize("lens", [[6800], [130, 130, 130], [1, 999, 6800, 64, 65], list(range(40, 40 + 16 * 37, 37))])
 def test_attention_decode_rows_ragged(ops, lens):
     """Scenes decoding together (own cache, own length) in one launch pair: each row equals softmax(q K^T / sqrt(d)) V
-    over its own keys; equal lengths reproduce the single-scene launch bit for bit."""
+    over its own keys, and reproduces the single-scene launch bit for bit whatever the other scenes' lengths (every scene
+    partitions its keys by its own length)."""
     dt = torch.bfloat16
     H, KV, D = 28, 4, 128
     M = len(lens)
@@ -226,11 +227,42 @@ def test_attention_decode_rows_ragged(ops, lens):
         v = caches[m][:n, KV * D:].view(1, n, KV, D)
         want = ref_attention(q[m].view(1, 1, H, D), k, v, True, 1 / math.sqrt(D), q_pos0=n - 1)
         close(out[m].view(1, 1, H, D), want, "bf16", ulps=2.0, floor=0.3)
-    if len(set(lens)) == 1:
-        for m, n in enumerate(lens):
-            alone = torch.empty(H * D, dtype=dt, device="cuda")
-            ops.attention_decode(q[m].cuda(), cds[m], cds[m][:, KV * D:], alone, n, H, KV, 1 / math.sqrt(D), one)
-            assert torch.equal(alone, out[m])
+    for m, n in enumerate(lens):
+        alone = torch.empty(H * D, dtype=dt, device="cuda")
+        ops.attention_decode(q[m].cuda(), cds[m], cds[m][:, KV * D:], alone, n, H, KV, 1 / math.sqrt(D), one)
+        assert torch.equal(alone, out[m]), f"scene {m} (length {n}) depends on its group"
+
+
+def test_rope_kv_store_equals_rope_apply_plus_copy(ops):
+    """The fused prefill rotary + cache append (contiguous and indexed destination rows, given positions) against
+    v3d_rope_apply + v3d_copy_rows, bit for bit."""
+    dt = torch.bfloat16
+    H, KV, D, S = 6, 2, 128, 333
+    table = ops.RopeTable(D, 1024, 1e6, dt, "cuda")
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(S, (H + 2 * KV) * D + 128, generator=g).to(dt).cuda()          # padded row stride
+    ref = qkv.clone()
+    ops.rope_apply(ref, H + KV, D, table, pos0=100)
+    cache = torch.zeros(700, 2 * KV * D + 64, dtype=dt, device="cuda")
+    got = qkv.clone()
+    ops.rope_kv_store(got, H, KV, D, table, cache, pos0=100)
+    assert torch.equal(got[:, : H * D], ref[:, : H * D])
+    assert torch.equal(got[:, H * D:], qkv[:, H * D:])                                # k / v columns of the buffer untouched
+    assert torch.equal(cache[100:100 + S, : 2 * KV * D], ref[:, H * D: (H + 2 * KV) * D])
+    assert not bool(cache[:100].any()) and not bool(cache[100 + S:].any()) and not bool(cache[:, 2 * KV * D:].any())
+    # indexed form: two "questions" of one scene appending at rows 50.. of their own caches inside one allocation
+    pos = torch.cat([torch.arange(50, 50 + 200), torch.arange(50, 50 + 133)]).to(torch.int32).cuda()
+    rows = torch.cat([torch.arange(50, 250), 350 + torch.arange(50, 183)]).to(torch.int64).cuda()
+    ref2 = qkv.clone()
+    ops.rope_apply(ref2, H + KV, D, table, positions=pos)
+    cache2 = torch.zeros(700, 2 * KV * D, dtype=dt, device="cuda")
+    got2 = qkv.clone()
+    ops.rope_kv_store(got2, H, KV, D, table, cache2, positions=pos, dst_rows=rows)
+    assert torch.equal(got2[:, : H * D], ref2[:, : H * D])
+    assert torch.equal(cache2[rows], ref2[:, H * D: (H + 2 * KV) * D])
+    from v3d._native import V3DError
+    with pytest.raises(V3DError):
+        ops.rope_kv_store(got, H, KV, D, table, cache, pos0=100, row0=500)            # 500 + 333 rows > 700
 
 
 def test_rope_rows_and_argmax_rows(ops):

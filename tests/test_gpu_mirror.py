@@ -62,12 +62,15 @@ def test_arch_mixin_methods(golden):
 def test_llava_qwen_generate_and_grounding_call_contract():
     """The overlay's LlavaQwenForCausalLM keeps the 3-D eval drivers' call shapes
     (model_scanqa.py:173-185, model_scanrefer.py:165-173) on a tiny random-init model."""
-    from llava.model.language_model.llava_qwen import LlavaQwenForCausalLM
+    from llava.model.language_model.llava_qwen import LlavaQwenConfig, LlavaQwenForCausalLM
     from v3d.engine import EngineConfig, LlmConfig, VitConfig, random_state_dict
     cfg = EngineConfig(vit=VitConfig(hidden=144, inter=272, layers=1, heads=2),
                        llm=LlmConfig(hidden=256, inter=384, layers=1, heads=2, kv_heads=1, vocab=320, max_pos=1024))
     sd = random_state_dict(cfg, torch.float32, "cpu", seed=9, std=0.05, ground_head=True)
-    model = LlavaQwenForCausalLM(cfg, sd, dtype=torch.float16, device="cuda")
+    hf = LlavaQwenConfig(vocab_size=320, hidden_size=256, intermediate_size=384, num_hidden_layers=1, num_attention_heads=2,
+                         num_key_value_heads=1, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=1000000.0)
+    hf.rope_theta, hf.ground_head_type, hf.world_position_embedding_type = 1000000.0, "infonce", "avg-discrete-sin3d"
+    model = LlavaQwenForCausalLM(hf, sd, dtype=torch.float16, device="cuda")
     g = torch.Generator().manual_seed(10)
     images = torch.randn(1, 2, 3, 384, 384, generator=g).half().cuda()
     video_dict = {"world_coords": ((torch.rand(1, 2, 384, 384, 3, generator=g) - 0.5) * 10).half().cuda(),
@@ -102,3 +105,40 @@ def test_siglip_image_processor_mirror(golden):
     full = SigLipImageProcessor()
     pv = full.preprocess(Image.fromarray(g["small"]))["pixel_values"]
     assert np.array_equal(pv[0, :, ::16, ::16].cpu().numpy(), g["small_pixel_values"])
+
+
+def test_video_processor_on_scene_files(golden, tmp_path):
+    """a4-a6 end to end through the mirror's VideoProcessor on files the test writes (16-bit depth PNGs, pose txt, JPEG frames):
+    calculate_world_coords against the REFERENCE's own output on the same files (tests/golden/world_coords.npz: u16 -> f32,
+    f64 axis_align @ pose, unproject), preprocess(center_crop): `boundry` = the reference's expression over the FULL-resolution
+    coordinates (video_utils.py:268-273), world_coords = the restated cv2.INTER_NEAREST + centre-crop index map
+    applied to them (parity unpinned for the index rule itself: cv2 is absent, oracle/v3d_oracle.py:76), images resized and
+    cropped as the reference's PIL calls do."""
+    import llava.video_utils as vu
+    from scene_files import write_frames
+    g = golden("world_coords")
+    V, H, W = g["depth"].shape
+    rgb = np.random.default_rng(3).integers(0, 256, size=(V, H, W, 3), dtype=np.uint8)
+    files = write_frames(str(tmp_path / "posed_images" / "scene0000_00"), g["depth"], g["poses"], rgb=rgb, ext=".jpg")
+    vp = object.__new__(vu.VideoProcessor)
+    vp.video_folder = str(tmp_path)
+    vp.frame_sampling_strategy = "uniform"
+    vid = "scannet/scene0000_00"
+    vp.scene = {vid: {"axis_align_matrix": g["axis_align"].tolist(), "depth_cam2img": g["cam2img"].tolist(),
+                      "images": [{"img_path": "posed_images/scene0000_00/" + f.split("/")[-1]} for f in files]}}
+    vp.scan2obj = {vid: [[0.0, 0.1, 0.2, 1.0, 1.0, 1.0], [1.0, 1.0, 0.5, 0.4, 0.6, 0.8]]}
+    wc = vp.calculate_world_coords(vid, files)["world_coords"]
+    assert wc.is_cuda and tuple(wc.shape) == (V, H, W, 3)
+    np.testing.assert_allclose(wc.cpu().numpy(), g["world"], rtol=2e-6, atol=2e-6)
+    crop = 24                                                   # new_width = int(64 * 24/48) = 32, left = 4
+    proc = types.SimpleNamespace(crop_size={"height": crop, "width": crop})
+    out = vp.preprocess(vid, proc, force_sample=True, frames_upbound=V)
+    np.testing.assert_allclose(out["boundry"].numpy(), g["boundry"], rtol=2e-6, atol=2e-6)
+    assert out["video_size"] == V and tuple(out["objects"].shape) == (2, 6)
+    want = O.resize_crop_coords(g["world"], crop)
+    np.testing.assert_allclose(out["world_coords"].cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+    assert len(out["images"]) == V and all(im.size == (crop, crop) for im in out["images"])
+    from PIL import Image
+    with Image.open(files[1]) as im:
+        ref = im.convert("RGB").resize((32, crop)).crop((4, 0, 4 + crop, crop))
+    assert np.array_equal(np.asarray(out["images"][1]), np.asarray(ref))

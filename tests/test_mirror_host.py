@@ -97,3 +97,26 @@ def test_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(V3DError):
         vu.unproject(torch.eye(4)[None], torch.eye(4)[None], torch.zeros(1, 4, 4))
+
+
+def test_load_depth_pose_matches_reference_loader(tmp_path):
+    """a4, host half (video_utils.py:206-230): 16-bit PNG -> the u16 values (incl. > 32767, which must not wrap), pose text ->
+    f64, axis_align @ pose in f64 and only then .float() - against the reference's own loader output
+    (tests/golden/world_coords.npz, oracle/gen_golden.py g_world_coords), bit for bit; the oracle's unproject on these
+    inputs reproduces the reference's world coordinates."""
+    from scene_files import write_frames
+    from oracle import v3d_oracle as O
+    g = np.load(os.path.join(GOLDEN, "world_coords.npz"))
+    files = write_frames(str(tmp_path / "scene0000_00"), g["depth"], g["poses"])
+    vp = bare_processor(scene={"scannet/scene0000_00": {"axis_align_matrix": g["axis_align"].tolist(), "depth_cam2img": g["cam2img"].tolist()}})
+    depth, K, pose = vp._load_depth_pose("scannet/scene0000_00", files)
+    assert depth.dtype == torch.int16 and tuple(depth.shape) == (3, 48, 64)
+    assert np.array_equal(depth.numpy().view(np.uint16), g["depth"]) and int(depth.numpy().view(np.uint16).max()) == 40000
+    assert pose.dtype == torch.float32 and np.array_equal(pose.numpy(), g["aligned_f32"])
+    assert K.shape == (3, 4, 4) and np.array_equal(K[1].numpy(), g["cam2img"].astype(np.float32))
+    world = O.unproject(K.numpy(), pose.numpy(), depth.numpy().view(np.uint16).astype(np.float32))
+    np.testing.assert_allclose(world, g["world"], rtol=2e-6, atol=2e-6)
+    b = g["boundry"]
+    flat = world.reshape(-1, 3)
+    np.testing.assert_allclose([flat[:, 0].min(), flat[:, 0].max(), flat[:, 1].min(), flat[:, 1].max(), flat[:, 2].min(), flat[:, 2].max()],
+                               b, rtol=2e-6, atol=2e-6)

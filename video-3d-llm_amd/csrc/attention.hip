@@ -265,7 +265,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     float alpha = 1.0f;
     if (t == 0 || __any(mx > AT_RAISE)) {              // wave-uniform
       const float mp = fmaxf(mx, __shfl_xor(mx, 32));    // both key halves of the query
-      float d = t == 0 ? mp : fmaxf(mp, 0.f);            // the first tile FIXES the maximum, later ones only raise it
+      // the first tile FIXES the maximum, later ones only raise it - and only for the queries that crossed the threshold
+      // themselves: the branch is wave-uniform, the decision per lane, so a query's rounding history depends on its own
+      // scores alone and its output bits do not change with the rows that happen to share its wave (batch composition,
+      // position of the row inside the query tile: tests/test_gpu_scene_reuse.py)
+      float d = t == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);
       d = mp == -INFINITY ? 0.f : d;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -555,7 +559,8 @@ struct DecRows {
   int sk[DEC_MAXROWS];
   int64_t q_stride, o_stride;       // elements between the scenes' query / output rows
   int64_t ws_stride;                // floats between the scenes' workspace slices
-};
+  int kps, cap;                     // keys per split / most splits per scene: a scene's OWN split count min(cap, ceil(n_keys / kps))
+};                                  // decides its key partition, so its output does not depend on the other scenes of the launch
 
 template <typename T, int G>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecRows rw, int n_split, float* __restrict__ ws) {
@@ -572,7 +577,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecR
   const int slot = tid >> 4, cl = tid & 15;       // 16 key slots, 16 lanes per key row
   const int hk = blockIdx.x, split = blockIdx.y;
   const int n_keys = p.q_pos0 + 1 < p.Sk ? p.q_pos0 + 1 : p.Sk;
-  const int per = (n_keys + n_split - 1) / n_split;
+  const int ns_own = min(rw.cap, (n_keys + rw.kps - 1) / rw.kps);      // splits >= ns_own are empty: (m, l, o) = (-inf, 0, 0)
+  const int per = (n_keys + ns_own - 1) / ns_own;
   const int k_begin = split * per;
   int k_end = k_begin + per;
   k_end = k_end < n_keys ? k_end : n_keys;
@@ -688,7 +694,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_mm_kernel(AttnArgs p, D
   const int hr = lane & 15, g4 = lane >> 4;        // score tile: column (key) hr, heads 4 g4 + i;  V layout: slot g4, dims 8 hr..
   const int hk = blockIdx.x, split = blockIdx.y;
   const int n_keys = p.q_pos0 + 1 < p.Sk ? p.q_pos0 + 1 : p.Sk;
-  const int per = (n_keys + n_split - 1) / n_split;
+  const int ns_own = min(rw.cap, (n_keys + rw.kps - 1) / rw.kps);      // splits >= ns_own are empty: (m, l, o) = (-inf, 0, 0)
+  const int per = (n_keys + ns_own - 1) / ns_own;
   const int k_begin = split * per;
   int k_end = k_begin + per;
   k_end = k_end < n_keys ? k_end : n_keys;
@@ -935,8 +942,10 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
   }
   static int kps_env = -1;
   if (kps_env < 0) { const char* e = getenv("V3D_DEC_KEYS_PER_SPLIT"); kps_env = e ? atoi(e) : 0; }
-  // keys per split: enough workgroups to cover the chip, few enough that the per-split merge stays small.  Independent of
-  // M, so that a scene's split count - and with it every bit of its output - does not depend on its group (measured at
+  // keys per split: enough workgroups to cover the chip, few enough that the per-split merge stays small.  The launch's
+  // split dimension follows the longest scene, but every scene partitions its keys by its OWN count min(cap, ceil(n/kps))
+  // (shorter scenes leave the trailing splits empty; the merge adds their exact zeros), so a scene's split boundaries - and
+  // with them every bit of its output - depend neither on M nor on the other scenes' lengths (measured at
   // S = 6.8k: 128 is 10 % faster for a single scene, 256 is 20-25 % faster from four scenes on)
   const int kps = kps_env > 0 ? kps_env : 256;
   int n_split = (sk_max + kps - 1) / kps;
@@ -946,6 +955,7 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
   const int64_t ws_one = v3d_attention_decode_workspace_bytes(Hq, n_split);
   V3D_REQUIRE(workspace_bytes >= ws_one * M, "%s: workspace too small for %d scenes x %d splits", who, M, n_split);
   rw.q_stride = q_stride; rw.o_stride = o_stride; rw.ws_stride = ws_one / (int64_t)sizeof(float);
+  rw.kps = kps; rw.cap = cap;
   AttnArgs p{};
   p.q = q; p.o = o;
   p.ldk = ldk; p.ldv = ldv; p.hsq = hsq; p.hsk = hsk; p.hso = hso;

@@ -91,6 +91,36 @@ __global__ __launch_bounds__(256) void unproject_f32_scalar_kernel(const float* 
 // (llava/video_utils.py:296-308).  OpenCV rule: src = min(floor(dst * src/dst_size), src-1),
 // computed in double like cv::resize does.  One thread = one output pixel (3 values).
 // ----------------------------------------------------------------------------------------
+// One thread = 8 consecutive output pixels of a row (crop % 8 == 0): eight gathered u16 depth reads that fall into one or
+// two cache lines, 24 values = three (16-bit) or six (f32) 16-byte stores.  The scalar form below serves other crops.
+template <typename T>
+__global__ __launch_bounds__(256) void unproject_sampled_x8_kernel(const uint16_t* __restrict__ depth,
+                                                                   const float* __restrict__ K,
+                                                                   const float* __restrict__ P,
+                                                                   T* __restrict__ out, int H, int W, int crop,
+                                                                   int left, double inv_fx, double inv_fy, int groups_per_frame) {
+  const int v = blockIdx.y;
+  const int grp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (grp >= groups_per_frame) return;
+  const Cam c = load_cam(K, P, v);
+  const int gpr = crop / 8;
+  const int r = grp / gpr, col0 = (grp - r * gpr) * 8;
+  int sr = (int)floor((double)r * inv_fy);
+  sr = sr < H - 1 ? sr : H - 1;
+  const uint16_t* drow = depth + ((size_t)v * H + sr) * W;
+  float o[24];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int sc = (int)floor((double)(col0 + j + left) * inv_fx);
+    sc = sc < W - 1 ? sc : W - 1;
+    backproject(c, (float)sc, (float)sr, (float)(int)drow[sc], o + 3 * j);
+  }
+  T* dst = out + ((size_t)v * crop * crop + (size_t)r * crop + col0) * 3;
+  constexpr int VEC = 16 / sizeof(T);
+#pragma unroll
+  for (int k = 0; k < 24 / VEC; ++k) reinterpret_cast<uint4*>(dst)[k] = vec_pack<T>(o + k * VEC);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void unproject_sampled_kernel(const uint16_t* __restrict__ depth,
                                                                 const float* __restrict__ K,
@@ -111,6 +141,63 @@ __global__ __launch_bounds__(256) void unproject_sampled_kernel(const uint16_t* 
     backproject(c, (float)sc, (float)sr, d, o);
     T* dst = out + ((size_t)v * n + pix) * 3;
     dst[0] = from_f32<T>(o[0]); dst[1] = from_f32<T>(o[1]); dst[2] = from_f32<T>(o[2]);
+  }
+}
+
+// Bounds of the FULL-resolution back-projection (llava/video_utils.py:268-273: min / max of world_coords over all V*H*W
+// pixels, taken before the resize and crop) without materialising the 118 MB tensor: every pixel is back-projected with the
+// same arithmetic as unproject_f32_kernel and only the running min / max survive.  Stage 1: one partial (6 floats) per block;
+// stage 2: one block folds the partials.  min / max are exact, so the two-stage order does not matter.
+__global__ __launch_bounds__(256) void unproject_bounds_kernel(const uint16_t* __restrict__ depth, const float* __restrict__ K,
+                                                               const float* __restrict__ P, int H, int W, float* __restrict__ partial) {
+  const int v = blockIdx.y;
+  const Cam c = load_cam(K, P, v);
+  const int n = H * W;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += gridDim.x * blockDim.x) {
+    const int row = pix / W, col = pix - row * W;
+    float o[3];
+    backproject(c, (float)col, (float)row, (float)(int)depth[(size_t)v * n + pix], o);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], o[a]); hi[a] = fmaxf(hi[a], o[a]); }
+  }
+  __shared__ float sm[4][6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { sm[wave][2 * a] = lo[a]; sm[wave][2 * a + 1] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float r = sm[0][a];
+    for (int w = 1; w < 4; ++w) r = (a & 1) ? fmaxf(r, sm[w][a]) : fminf(r, sm[w][a]);
+    partial[((size_t)v * gridDim.x + blockIdx.x) * 6 + a] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void bounds_fold_kernel(const float* __restrict__ partial, int n_partials, float* __restrict__ bounds) {
+  __shared__ float sm[256][6];
+  float r[6] = {INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY};
+  for (int i = threadIdx.x; i < n_partials; i += 256)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) r[a] = (a & 1) ? fmaxf(r[a], partial[(size_t)i * 6 + a]) : fminf(r[a], partial[(size_t)i * 6 + a]);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) sm[threadIdx.x][a] = r[a];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float x = sm[0][a];
+    for (int i = 1; i < 256; ++i) x = (a & 1) ? fmaxf(x, sm[i][a]) : fminf(x, sm[i][a]);
+    bounds[a] = x;
   }
 }
 
@@ -283,12 +370,35 @@ extern "C" int v3d_unproject_sampled_u16(const uint16_t* depth, const float* int
   const double inv_fx = (double)W / (double)new_w;   // cv::resize: scale_x = src.cols / dst.cols
   const double inv_fy = (double)H / (double)new_h;
   hipStream_t st = (hipStream_t)stream;
+  if (crop % 8 == 0 && aligned16(out)) {
+    const int groups = crop * crop / 8;
+    V3D_DISPATCH_DTYPE(out_dtype,
+                       hipLaunchKernelGGL(unproject_sampled_x8_kernel<T>, dim3((groups + 255) / 256, V), dim3(256), 0, st, depth, intrinsics,
+                                          poses, (T*)out, H, W, crop, left, inv_fx, inv_fy, groups));
+    return check_launch("v3d_unproject_sampled_u16");
+  }
   int bx = (crop * crop + 255) / 256;
   if (bx > 1024) bx = 1024;
   V3D_DISPATCH_DTYPE(out_dtype,
                      hipLaunchKernelGGL(unproject_sampled_kernel<T>, dim3(bx, V), dim3(256), 0, st, depth, intrinsics,
                                         poses, (T*)out, H, W, crop, new_w, left, inv_fx, inv_fy));
   return check_launch("v3d_unproject_sampled_u16");
+}
+
+constexpr int BOUNDS_BLOCKS = 64;       // per frame: 64 x 256 threads, ~19 pixels each at 480 x 640
+
+extern "C" int64_t v3d_unproject_bounds_workspace_bytes(int V) { return (int64_t)(V > 0 ? V : 0) * BOUNDS_BLOCKS * 6 * (int64_t)sizeof(float); }
+
+extern "C" int v3d_unproject_bounds_u16(const uint16_t* depth, const float* intrinsics, const float* poses, int V, int H, int W,
+                                        float* bounds, void* workspace, int64_t workspace_bytes, void* stream) {
+  V3D_REQUIRE(depth && intrinsics && poses && bounds && workspace, "v3d_unproject_bounds_u16: null pointer");
+  V3D_REQUIRE(V > 0 && H > 0 && W > 0, "v3d_unproject_bounds_u16: bad shape");
+  V3D_REQUIRE(workspace_bytes >= v3d_unproject_bounds_workspace_bytes(V), "v3d_unproject_bounds_u16: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(unproject_bounds_kernel, dim3(BOUNDS_BLOCKS, V), dim3(256), 0, st, depth, intrinsics, poses, H, W, (float*)workspace);
+  if (int e = check_launch("v3d_unproject_bounds_u16")) return e;
+  hipLaunchKernelGGL(bounds_fold_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, V * BOUNDS_BLOCKS, bounds);
+  return check_launch("v3d_unproject_bounds_u16");
 }
 
 static int fill_range(Range& rg, const float* lo, const float* hi, float voxel, const char* who) {

@@ -146,6 +146,67 @@ __global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ x, int64_t ld
   }
 }
 
+// Prefill K14 + KV-cache append in ONE pass over the QKV rows (replaces rope_kernel + copy_rows_kernel): rotary in place on
+// the n_q query heads; the n_kv key heads are rotated and written straight to the cache row of their token together with the
+// value heads (the QKV buffer's own k/v columns are left as the GEMM wrote them: attention reads K/V from the cache).
+// Token t sits at position positions[t] (or pos0 + t) and its cache row is cache + dst_rows[t] * ldc (or (row0 + t) * ldc):
+// the indexed form serves several questions of one scene prefilled together, each appending to its own cache
+// (all caches live in one allocation, so a row index addresses any of them).
+// Same arithmetic and rounding points as rope_kernel (modeling_qwen2.py:141-173).
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_store_kernel(T* __restrict__ qkv, int64_t ldx, int64_t tokens, int n_q, int n_kv, int hd,
+                                                            const T* __restrict__ cos_t, const T* __restrict__ sin_t,
+                                                            const int32_t* __restrict__ positions, int pos0,
+                                                            T* __restrict__ cache, int64_t ldc, const int64_t* __restrict__ dst_rows,
+                                                            int64_t row0) {
+  const int half = hd / 2, vper = half / 8;
+  const int units = (n_q + 2 * n_kv) * vper;          // per token: (q | k) heads rotate a vector pair, v heads copy one
+  const int64_t total = tokens * units;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tok = i / units;
+    const int u = (int)(i - tok * units);
+    const int head = u / vper, c = u - head * vper;
+    T* src = qkv + tok * ldx + (int64_t)head * hd + c * 8;
+    const int64_t drow = dst_rows ? dst_rows[tok] : row0 + tok;
+    const uint4 lo = *reinterpret_cast<const uint4*>(src);
+    const uint4 hi = *reinterpret_cast<const uint4*>(src + half);
+    if (head >= n_q + n_kv) {                          // value head: copy both halves
+      T* d = cache + drow * ldc + (int64_t)(head - n_q) * hd + c * 8;
+      *reinterpret_cast<uint4*>(d) = lo;
+      *reinterpret_cast<uint4*>(d + half) = hi;
+      continue;
+    }
+    const int pos = positions ? positions[tok] : pos0 + (int)tok;
+    const uint4 cv = *reinterpret_cast<const uint4*>(cos_t + (int64_t)pos * half + c * 8);
+    const uint4 sv = *reinterpret_cast<const uint4*>(sin_t + (int64_t)pos * half + c * 8);
+    float ol[8], oh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = vec_get<T>(lo, j), b = vec_get<T>(hi, j);
+      const float cs = vec_get<T>(cv, j), sn = vec_get<T>(sv, j);
+      ol[j] = round_to<T>(a * cs) + round_to<T>(-b * sn);
+      oh[j] = round_to<T>(b * cs) + round_to<T>(a * sn);
+    }
+    T* d = head < n_q ? src : cache + drow * ldc + (int64_t)(head - n_q) * hd + c * 8;
+    *reinterpret_cast<uint4*>(d) = vec_pack<T>(ol);
+    *reinterpret_cast<uint4*>(d + half) = vec_pack<T>(oh);
+  }
+}
+
+// x[rows[i], :] = T(x[rows[i], :] + add[:])  (llava_arch.py:697-700: the box-centre PE added to the <coord> token rows)
+template <typename T>
+__global__ __launch_bounds__(256) void add_row_kernel(T* __restrict__ x, int64_t ldx, const int64_t* __restrict__ rows, int C,
+                                                      const T* __restrict__ add) {
+  T* r = x + rows[blockIdx.x] * ldx;
+  for (int k = threadIdx.x; k < C / 8; k += blockDim.x) {
+    const uint4 a = reinterpret_cast<const uint4*>(r)[k], b = reinterpret_cast<const uint4*>(add)[k];
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = vec_get<T>(a, j) + vec_get<T>(b, j);
+    reinterpret_cast<uint4*>(r)[k] = vec_pack<T>(o);
+  }
+}
+
 // strided row copy (KV-cache append, im2col-free patch gather, ...): out[r, :cols] = in[r, :cols]
 template <typename T>
 __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out,
@@ -156,6 +217,21 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ in
     const int64_t r = i / nv;
     const int k = (int)(i - r * nv);
     reinterpret_cast<uint4*>(out + r * ldo)[k] = reinterpret_cast<const uint4*>(in + r * ldi)[k];
+  }
+}
+
+// the same rows written to n_copies destinations copy_stride elements apart (the cached K/V prefix of a scene handed to every
+// question context of a group): one read of the source per destination vector group, all copies in one launch
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_bcast_kernel(const T* __restrict__ in, int64_t ldi, T* __restrict__ out, int64_t ldo,
+                                                              int64_t rows, int cols, int n_copies, int64_t copy_stride) {
+  const int nv = cols / 8;
+  const int64_t total = rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nv;
+    const int k = (int)(i - r * nv);
+    const uint4 v = reinterpret_cast<const uint4*>(in + r * ldi)[k];
+    for (int c = 0; c < n_copies; ++c) reinterpret_cast<uint4*>(out + c * copy_stride + r * ldo)[k] = v;
   }
 }
 
@@ -278,6 +354,34 @@ extern "C" int v3d_rope_apply(void* x, int64_t ldx, int64_t tokens, int n_heads,
   return check_launch("v3d_rope_apply");
 }
 
+extern "C" int v3d_rope_kv_store(void* qkv, int64_t ldx, int64_t tokens, int n_q_heads, int n_kv_heads, int head_dim,
+                                 const void* cos_table, const void* sin_table, int n_pos, const int32_t* positions, int pos0,
+                                 void* cache, int64_t ldc, const int64_t* dst_rows, int64_t row0, int dtype, void* stream) {
+  V3D_REQUIRE(qkv && cos_table && sin_table && cache, "v3d_rope_kv_store: null pointer");
+  V3D_REQUIRE(tokens >= 0 && n_q_heads > 0 && n_kv_heads > 0 && head_dim % 16 == 0 && ldx % 8 == 0 && ldc % 8 == 0 && aligned16(qkv) &&
+                  aligned16(cache), "v3d_rope_kv_store: bad shape");
+  V3D_REQUIRE(ldx >= (int64_t)(n_q_heads + 2 * n_kv_heads) * head_dim && ldc >= (int64_t)2 * n_kv_heads * head_dim,
+              "v3d_rope_kv_store: row strides shorter than the heads they hold");
+  V3D_REQUIRE(positions || (pos0 >= 0 && pos0 + tokens <= n_pos), "v3d_rope_kv_store: positions exceed the table (%d)", n_pos);
+  V3D_REQUIRE(dst_rows || row0 >= 0, "v3d_rope_kv_store: negative cache row");
+  if (tokens == 0) return V3D_OK;
+  int64_t blocks = (tokens * (n_q_heads + 2 * n_kv_heads) * (head_dim / 16) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(rope_kv_store_kernel<T>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (T*)qkv, ldx,
+                                            tokens, n_q_heads, n_kv_heads, head_dim, (const T*)cos_table, (const T*)sin_table, positions,
+                                            pos0, (T*)cache, ldc, dst_rows, row0));
+  return check_launch("v3d_rope_kv_store");
+}
+
+extern "C" int v3d_add_row(void* x, int64_t ldx, const int64_t* rows, int n_rows, int C, const void* add, int dtype, void* stream) {
+  V3D_REQUIRE(x && rows && add && n_rows >= 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && aligned16(x) && aligned16(add),
+              "v3d_add_row: bad arguments");
+  if (n_rows == 0) return V3D_OK;
+  V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(add_row_kernel<T>, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (T*)x, ldx, rows, C,
+                                            (const T*)add));
+  return check_launch("v3d_add_row");
+}
+
 extern "C" int v3d_copy_rows(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int dtype, void* stream) {
   V3D_REQUIRE(in && out && rows >= 0 && cols > 0 && cols % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && aligned16(in) && aligned16(out),
               "v3d_copy_rows: bad arguments");
@@ -287,6 +391,18 @@ extern "C" int v3d_copy_rows(const void* in, int64_t ldi, void* out, int64_t ldo
   V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(copy_rows_kernel<T>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
                                             (const T*)in, ldi, (T*)out, ldo, rows, cols));
   return check_launch("v3d_copy_rows");
+}
+
+extern "C" int v3d_copy_rows_bcast(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int n_copies,
+                                   int64_t copy_stride, int dtype, void* stream) {
+  V3D_REQUIRE(in && out && rows >= 0 && cols > 0 && cols % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0 && copy_stride % 8 == 0 && n_copies >= 1 &&
+                  aligned16(in) && aligned16(out), "v3d_copy_rows_bcast: bad arguments");
+  if (rows == 0) return V3D_OK;
+  int64_t blocks = (rows * (cols / 8) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(copy_rows_bcast_kernel<T>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream,
+                                            (const T*)in, ldi, (T*)out, ldo, rows, cols, n_copies, copy_stride));
+  return check_launch("v3d_copy_rows_bcast");
 }
 
 extern "C" int v3d_patchify(const void* images, void* out, int B, int S, int patch, int kpad, int dtype, void* stream) {

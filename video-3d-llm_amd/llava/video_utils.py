@@ -132,10 +132,9 @@ class VideoProcessor:
         dev = _device()
         depth, K, pose = self._load_depth_pose(video_id, frame_files)
         crop = image_processor.crop_size["width"]
-        coords = ops.unproject_sampled(depth.to(dev), K.to(dev), pose.to(dev), crop, torch.float32)
-        flat = coords.reshape(-1, 3)
-        lo, hi = flat.min(0).values, flat.max(0).values
-        boundry = torch.stack([lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]).cpu()
+        depth, K, pose = depth.to(dev), K.to(dev), pose.to(dev)
+        coords = ops.unproject_sampled(depth, K, pose, crop, torch.float32)
+        boundry = ops.unproject_bounds(depth, K, pose).cpu()      # over the full-resolution back-projection (:268-273)
         images = []
         for path in frame_files:
             with Image.open(path) as im:

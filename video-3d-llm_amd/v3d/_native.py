@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libv3d_hip.so")
 
 _lib = None
+ABI_VERSION = 3      # include/v3d.h V3D_ABI_VERSION
 
 
 class V3DError(RuntimeError):
@@ -22,8 +23,8 @@ def lib():
                 "(or __graft_entry__.build()).  There is no CPU fallback for this path.")
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
-        if _lib.v3d_abi_version() != 2:
-            raise V3DError("libv3d_hip.so ABI version mismatch")
+        if _lib.v3d_abi_version() != ABI_VERSION:
+            raise V3DError(f"libv3d_hip.so has ABI version {_lib.v3d_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
     return _lib
 
 
@@ -38,6 +39,8 @@ SIGNATURES = {
     "v3d_last_error": (ctypes.c_char_p, []),
     "v3d_unproject_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "v3d_unproject_sampled_u16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_unproject_bounds_workspace_bytes": (c_l, [c_i]),
+    "v3d_unproject_bounds_u16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "v3d_coord_pool_voxel": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),
     "v3d_discrete_coords": (c_i, [c_p, c_i, c_l, c_p, c_p, c_f, c_p, c_p, c_p]),
     "v3d_sin3d_table_row_elems": (c_l, [c_i, c_i]),
@@ -70,6 +73,9 @@ SIGNATURES = {
     "v3d_object_patch_mask": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p]),
     "v3d_masked_mean": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "v3d_ground_scores": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "v3d_rope_kv_store": (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_i, c_p]),
+    "v3d_add_row": (c_i, [c_p, c_l, c_p, c_i, c_i, c_p, c_i, c_p]),
+    "v3d_copy_rows_bcast": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_l, c_i, c_p]),
     "v3d_copy_rows": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p]),
     "v3d_patchify": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),

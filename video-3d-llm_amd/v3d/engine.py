@@ -326,9 +326,11 @@ class Engine:
         _, _, ids = ops.coord_pool_voxel(world_coords, 27, c.min_xyz, c.max_xyz, c.voxel_size, want_avg=False, want_vox=False)
         return ids
 
-    def build_inputs_embeds(self, input_ids, feats, ids, image_token=-200):
+    def build_inputs_embeds(self, input_ids, feats, ids, image_token=-200, box_input=None, coord_token_id=None):
         """prepare_inputs_labels_for_multimodal for one video sample (llava_arch.py:336-836, eval branch):
-        text embeddings around the <image> slot, visual tokens written in place.  Returns [S, hidden] view."""
+        text embeddings around the <image> slot, visual tokens written in place.  Returns [S, hidden] view.
+        box_input [1,3] + coord_token_id: the PE of the discretised box centre is added to the rows of every <coord> text token
+        (llava_arch.py:416-417, 697-700; the Scan2Cap prompt)."""
         F_ = feats.shape[0]
         n = self.cfg.pool_out
         side = int(math.isqrt(feats.shape[1]))
@@ -348,13 +350,24 @@ class Engine:
         ops.visual_tokens(feats, ids, self.pe_table, self.newline, side=side, n=n, pool=True, out=x[len(pre): len(pre) + n_vis])
         if len(post):
             ops.embed_gather(self.embed, post.to(self.device), out=x[len(pre) + n_vis:])
+        if coord_token_id is not None and box_input is not None and len(box_input):
+            rows = [r if r < at else r + n_vis - 1 for r, t in enumerate(ids_list) if t == coord_token_id]
+            if rows:
+                c = self.cfg
+                centre = ops.discrete_coords(box_input.to(device=self.device, dtype=self.dtype).reshape(-1, 3)[:1].contiguous(),
+                                             c.min_xyz, c.max_xyz, c.voxel_size)
+                pe = ops.sin3d_pe(centre[None], c.llm.hidden, dim_t=self.pe_table.dim_t)[0, 0]
+                ops.add_row(x, torch.tensor(rows, dtype=torch.int64, device=self.device), pe)
         return x
 
     # ------------------------------------------------------------------ Qwen2 decoder (a18-a22)
-    def llm_forward(self, x, pos0, stamps=None):
+    def llm_forward(self, x, pos0, stamps=None, head=True, batch=None):
         """Runs the decoder over rows x [S, hidden] (in place) at positions pos0.., appends K/V to the
         cache and returns the f32 logits of the LAST row only ([vocab]); the reference materialises all
-        S rows of logits (modeling_qwen2.py:1190-1192) but generation reads only the last."""
+        S rows of logits (modeling_qwen2.py:1190-1192) but generation reads only the last.
+        batch (answer_group): x holds B sequences of Sq rows each, all starting at position pos0 behind the same cached prefix;
+        batch.kv[i] is [B, max_pos, 2*kv_width] (sequence b appends to and attends over its own slice), batch.positions /
+        batch.dst_rows give every row's position and flat cache row."""
         l = self.cfg.llm
         S = x.shape[0]
         hd, nh, nkv = self.hd, l.heads, l.kv_heads
@@ -385,9 +398,19 @@ class Engine:
                 return ops.gemm(h, L[key], out=out, **kw)
         for i, L in enumerate(self.l_layers):
             norm_lin(L["ln1"], L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.EPI_BIAS)
-            ops.rope_apply(qkv, nh + nkv, hd, self.rope, pos0=pos0)
+            if batch is not None:
+                c3 = batch.kv[i]
+                cache = c3.view(-1, c3.shape[-1])
+                ops.rope_kv_store(qkv, nh, nkv, hd, self.rope, cache, positions=batch.positions, dst_rows=batch.dst_rows)
+                B, Sq = batch.B, batch.Sq
+                ops.attention(qkv, cache, cache[:, kvw:], att, B, Sq, pos0 + Sq, nh, nkv, hd, hd, qkv.stride(0), cache.stride(0),
+                              cache.stride(0), att.stride(0), Sq * qkv.stride(0), c3.stride(0), Sq * att.stride(0), hd, hd, hd, True, pos0, scale)
+                lin(att, L, "wo", x, res=x, epilogue=ops.EPI_RES)
+                norm_lin(L["ln2"], L, "wgu", act, epilogue=ops.EPI_SWIGLU)
+                lin(act, L, "wd", x, res=x, epilogue=ops.EPI_RES)
+                continue
             cache = self.kv[i]
-            ops.copy_rows(qkv[:, nh * hd:], cache[pos0: pos0 + S], cols=2 * kvw)
+            ops.rope_kv_store(qkv, nh, nkv, hd, self.rope, cache, pos0=pos0)       # K14 + cache append (rows pos0 .. pos0+S)
             attn = lambda: ops.attention(qkv, cache, cache[:, kvw:], att, 1, S, pos0 + S, nh, nkv, hd, hd, qkv.stride(0),
                                          cache.stride(0), cache.stride(0), att.stride(0), 0, 0, 0, hd, hd, hd, True, pos0, scale)
             if S == 1:
@@ -406,8 +429,10 @@ class Engine:
             else:
                 norm_lin(L["ln2"], L, "wgu", act, epilogue=ops.EPI_SWIGLU)
             lin(act, L, "wd", x, res=x, epilogue=ops.EPI_RES)
+        if batch is not None:
+            return None
         self.kv_len = pos0 + S
-        return self._head(x[S - 1:])
+        return self._head(x[S - 1:]) if head else None
 
     def _head(self, x_row):
         """final RMSNorm + LM head on ONE row (K18: only the last position feeds generation)."""
@@ -450,6 +475,25 @@ class Engine:
     def last_hidden(self):
         return self.l_last[0]
 
+    def logits_all_rows(self, x):
+        """final norm + LM head over EVERY row of the residual stream x [S, hidden] -> f32 [S, vocab]: what
+        Qwen2ForCausalLM.forward returns (modeling_qwen2.py:1188-1192: 16-bit linear output, then .float()).  Generation never
+        needs it (only the last row is read); the plain `forward` of the mirror class does."""
+        l = self.cfg.llm
+        S = x.shape[0]
+        h = ops.rmsnorm(x, self.l_norm, l.eps, out=self.l_h[:S])
+        out = ops.gemm(h, self.l_head)
+        return out[:, : l.vocab].float()
+
+    def _check_room(self, S, max_new_tokens):
+        """The KV cache / residual stream hold llm.max_pos rows: a generation that would run past them is refused up front
+        (the last generated token is never fed back, so S + max_new_tokens - 1 rows are written)."""
+        if max_new_tokens < 1:
+            raise V3DError("max_new_tokens must be at least 1")
+        if S + max_new_tokens - 1 > self.cfg.llm.max_pos:
+            raise V3DError(f"prompt of {S} rows + {max_new_tokens} new tokens exceeds the engine capacity of {self.cfg.llm.max_pos} "
+                           "positions (LlmConfig.max_pos): lower max_new_tokens or build the engine with a larger max_pos")
+
     # ------------------------------------------------------------------ grounding (a24)
     @torch.no_grad()
     def ground_scores(self, input_ids, ground_index, images, world_coords, objects):
@@ -458,8 +502,6 @@ class Engine:
         ground_index: index IN input_ids of the <ground> label token whose hidden state is the query."""
         if self.ground is None:
             raise V3DError("this engine was built without ground_head_* weights")
-        l, g = self.cfg.llm, self.ground
-        H = l.hidden
         coords = world_coords.to(self.dtype)
         boxes = objects.to(device=self.device, dtype=self.dtype).contiguous()
         feats = self.encode_images(images)
@@ -468,13 +510,17 @@ class Engine:
         at = input_ids.tolist().index(-200)
         n_vis = feats.shape[0] * self.cfg.pool_out * (self.cfg.pool_out + 1)
         gpos = ground_index if ground_index < at else ground_index + n_vis - 1
-        self.llm_forward(x, 0)
+        self.llm_forward(x, 0, head=False)
+        return self.predict_box(x, gpos, self.object_features(feats, coords, boxes))
+
+    def predict_box(self, x, gpos, object_features):
+        """predict_box, ground_head_type 'infonce' (llava_qwen.py:280-300): x = the residual stream after the decoder (before the
+        final norm), gpos = the row of the <ground> label token, object_features [n, H] -> cosine scores [n + 1]."""
+        if self.ground is None:
+            raise V3DError("this engine was built without ground_head_* weights")
+        l, g = self.cfg.llm, self.ground
         query = ops.rmsnorm(x[gpos: gpos + 1], self.l_norm, l.eps, out=self.l_last[1:2])        # outputs[0][ground_locations]
-        mask = ops.object_patch_mask(coords, boxes)                                               # K19
-        centres = ops.discrete_coords(boxes[:, :3].contiguous(), self.cfg.min_xyz, self.cfg.max_xyz, self.cfg.voxel_size)
-        pe = ops.sin3d_pe(centres[None], H, dim_t=self.pe_table.dim_t)[0]
-        objf = ops.masked_mean(feats.reshape(-1, H), mask.view(mask.shape[0], -1), add=pe)
-        of = torch.cat([objf, g["ground_head_zero_target"][None]], 0).contiguous()
+        of = torch.cat([object_features, g["ground_head_zero_target"][None]], 0).contiguous()
 
         def head(xin, pfx):
             h = ops.gemm(xin, g[pfx + "0.weight"], bias=g[pfx + "0.bias"], epilogue=ops.EPI_BIAS_RELU)
@@ -483,17 +529,141 @@ class Engine:
 
         return ops.ground_scores(head(of, "ground_head_obj."), head(query, "ground_head_query.")[0])      # K20
 
+    def object_features(self, feats, coords, boxes):
+        """Object-proposal features, object_feature_type 'patch14-pe' (llava_arch.py:351-376, 479-501): per box, the mean of
+        the projector rows of the ViT patches with >= 98 of their 196 pixels inside the box, plus the PE of the discretised box
+        centre.  feats [F,729,H] (encode_images), coords [F,384,384,3] and boxes [n,6] in the model dtype -> [n, H]."""
+        H = self.cfg.llm.hidden
+        mask = ops.object_patch_mask(coords, boxes)                                               # K19
+        centres = ops.discrete_coords(boxes[:, :3].contiguous(), self.cfg.min_xyz, self.cfg.max_xyz, self.cfg.voxel_size)
+        pe = ops.sin3d_pe(centres[None], H, dim_t=self.pe_table.dim_t)[0]
+        return ops.masked_mean(feats.reshape(-1, H), mask.view(mask.shape[0], -1), add=pe)
+
     # ------------------------------------------------------------------ generate (a23)
     @torch.no_grad()
-    def generate(self, input_ids, images, world_coords, max_new_tokens=16, eos_token_id=None):
+    def generate(self, input_ids, images, world_coords, max_new_tokens=16, eos_token_id=None, stopping=None, box_input=None,
+                 coord_token_id=None):
         """Greedy decoding of one (scene, question): LlavaQwenForCausalLM.generate (llava_qwen.py:208-236)
-        with do_sample=False, num_beams=1 as model_scanqa.py:173-185 calls it."""
+        with do_sample=False, num_beams=1 as model_scanqa.py:173-185 calls it.  eos_token_id: an int or a collection of ints;
+        stopping: optional host callback(token_ids_so_far: LongTensor [n]) -> bool, checked after every token (HF's
+        stopping_criteria; forces one host synchronisation per step)."""
         feats = self.encode_images(images)
         ids = self.voxel_ids(world_coords.to(self.dtype))
-        x = self.build_inputs_embeds(input_ids, feats, ids)
+        x = self.build_inputs_embeds(input_ids, feats, ids, box_input=box_input, coord_token_id=coord_token_id)
         S = x.shape[0]
+        self._check_room(S, max_new_tokens)
         logits = self.llm_forward(x, 0)
-        return self.decode_loop(logits, S, max_new_tokens, eos_token_id)
+        return self.decode_loop(logits, S, max_new_tokens, eos_token_id, stopping)
+
+    # ------------------------------------------------------------------ scene-level reuse (SURVEY 8 f1)
+    @torch.no_grad()
+    def prefill_scene(self, prefix_ids, images, world_coords):
+        """Everything of a (scene, question) pass that does not depend on the question, done once per scene: ViT + projector,
+        voxel ids, the visual tokens and the decoder over the prompt prefix [system | user | <image>] - the reference's eval loop
+        recomputes all of it for every question of a scene (model_scanqa.py:130-185; the prefix is question-independent,
+        :46-60).  prefix_ids: the prompt ids up to and INCLUDING the <image> placeholder (-200) (further question-independent
+        ids may follow it).  The K/V rows of the prefix stay in the current context's cache; returns the prefix length P.
+        Follow with answer(question_ids) any number of times."""
+        feats = self.encode_images(images)
+        ids = self.voxel_ids(world_coords.to(self.dtype))
+        x = self.build_inputs_embeds(prefix_ids, feats, ids)
+        self.llm_forward(x, 0, head=False)
+        self.ctx.prefix_len = x.shape[0]
+        return self.ctx.prefix_len
+
+    @torch.no_grad()
+    def answer(self, question_ids, max_new_tokens=16, eos_token_id=None, stopping=None):
+        """Greedy answer to one question about the scene prefilled by prefill_scene: only the question's rows (the ids that follow
+        the prefix in the full prompt) run through the decoder, at positions P.., attending to the cached prefix; then the
+        usual decode loop.  Causality makes the prefix rows of the uncached pass independent of the question, so the tokens are
+        those of generate(prefix_ids + question_ids, ...) (tests/test_gpu_scene_reuse.py).  The prefix rows are left intact."""
+        P = getattr(self.ctx, "prefix_len", 0)
+        if not P or self.ctx.kv_len < P:
+            raise V3DError("answer() needs prefill_scene() on this context first")
+        q = question_ids.to(self.device)
+        Q = q.numel()
+        if Q < 1:
+            raise V3DError("answer() needs at least one question token")
+        self._check_room(P + Q, max_new_tokens)
+        x = ops.embed_gather(self.embed, q, out=self.l_x[P: P + Q])
+        logits = self.llm_forward(x, P)
+        return self.decode_loop(logits, P + Q, max_new_tokens, eos_token_id, stopping)
+
+    def _answer_state(self, n):
+        """Buffers of answer_group, allocated once: per layer ONE K/V allocation [16, max_pos, 2*kv_width] whose slices are the
+        caches of the questions answered together (so one batched attention launch can address them by a batch stride), the
+        contexts that view them, the residual stream of the batched question rows and the decode group's row buffers."""
+        st = self.__dict__.get("_answer_st")
+        if st is None:
+            l = self.cfg.llm
+            st = self._answer_st = SceneContext()
+            st.n = 16
+            st.kv = [torch.zeros((st.n, l.max_pos, 2 * l.kv_heads * self.hd), dtype=self.dtype, device=self.device) for _ in range(l.layers)]
+            st.x = torch.zeros((l.max_pos, l.hidden), dtype=self.dtype, device=self.device)
+            st.ctxs = []
+            for g in range(st.n):
+                c = SceneContext()
+                c.kv = [k[g] for k in st.kv]
+                c.kv_len = 0
+                st.ctxs.append(c)
+            st.rows = self.new_group(st.n)
+        if n > st.n:
+            raise V3DError(f"answer_group takes 1 to {st.n} questions")
+        return st
+
+    @torch.no_grad()
+    def answer_group(self, questions, max_new_tokens=16, eos_token_id=None):
+        """Up to 16 questions about the scene prefilled by prefill_scene, answered together: the cached prefix K/V is handed to
+        each question's own cache (one broadcast copy per layer), the questions' rows run through the decoder as ONE batch
+        (one pass over the weights; rows padded to the longest question, which causality keeps from affecting the real rows),
+        then all answers decode as one group (decode_group).  Returns a list of token-id tensors, each cut after its first EOS.
+        A question's rows do not depend on the others (tests/test_gpu_scene_reuse.py: equal to answer() on it alone)."""
+        scene = self.ctx
+        P = getattr(scene, "prefix_len", 0)
+        if not P or scene.kv_len < P:
+            raise V3DError("answer_group() needs prefill_scene() on this context first")
+        G = len(questions)
+        st = self._answer_state(G)
+        lens = [int(q.numel()) for q in questions]
+        if G < 1 or min(lens) < 1:
+            raise V3DError("answer_group() needs 1 to 16 non-empty questions")
+        Sq = max(lens)
+        l = self.cfg.llm
+        if G * Sq > l.max_pos:
+            raise V3DError(f"{G} questions x {Sq} rows exceed the engine's {l.max_pos}-row workspaces")
+        self._check_room(P + Sq, max_new_tokens)
+        for i in range(l.layers):
+            ops.copy_rows_bcast(scene.kv[i][:P], st.kv[i][:G])
+        ids = torch.empty((G, Sq), dtype=torch.int64)
+        for g, q in enumerate(questions):
+            ids[g, : lens[g]] = q.cpu()
+            ids[g, lens[g]:] = q[-1]                        # pad rows: any valid id; they sit AFTER the real rows (causal)
+        x = ops.embed_gather(self.embed, ids.reshape(-1).to(self.device), out=st.x[: G * Sq])
+        b = SceneContext()
+        b.B, b.Sq, b.kv = G, Sq, st.kv
+        j = torch.arange(Sq)
+        b.positions = (P + j).repeat(G).to(torch.int32).to(self.device)
+        b.dst_rows = (torch.arange(G)[:, None] * l.max_pos + P + j[None, :]).reshape(-1).to(self.device)
+        self.llm_forward(x, P, head=False, batch=b)
+        last = torch.tensor([g * Sq + lens[g] - 1 for g in range(G)], dtype=torch.int64, device=self.device)
+        rows = st.rows
+        ops.embed_gather(x, last, out=rows.x[:G])                                     # each question's last real row
+        ops.rmsnorm(rows.x[:G], self.l_norm, l.eps, out=rows.last[:G])
+        if self.llm_fp8:
+            ops.linear_decode_fp8_rows(rows.last[:G], *self.l_head8, rows.logits[:G])
+        else:
+            ops.linear_decode_rows(rows.last[:G], self.l_head, rows.logits[:G])
+        ctxs = st.ctxs[:G]
+        for c, n in zip(ctxs, lens):
+            c.kv_len = P + n
+        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True)
+        self.use(scene)
+        eos = () if eos_token_id is None else ((eos_token_id,) if isinstance(eos_token_id, int) else tuple(eos_token_id))
+        out = []
+        for row in toks.cpu():
+            hit = [i for i, t in enumerate(row.tolist()) if t in eos]
+            out.append((row[: hit[0] + 1] if hit else row).to(self.device))
+        return out
 
     @torch.no_grad()
     def generate_group(self, samples, max_new_tokens=16, eos_token_id=None):
@@ -511,14 +681,17 @@ class Engine:
             grp = self._group_rows = self.new_group(16 if n > 4 else 4)
         keep = self.ctx
         lens = []
-        for c, (input_ids, images, world_coords) in zip(pool, samples):
-            self.use(c)
-            feats = self.encode_images(images)
-            ids = self.voxel_ids(world_coords.to(self.dtype))
-            x = self.build_inputs_embeds(input_ids, feats, ids)
-            self.llm_forward(x, 0)
-            lens.append(x.shape[0])
-        self.use(keep)
+        try:
+            for c, (input_ids, images, world_coords) in zip(pool, samples):
+                self.use(c)
+                feats = self.encode_images(images)
+                ids = self.voxel_ids(world_coords.to(self.dtype))
+                x = self.build_inputs_embeds(input_ids, feats, ids)
+                self._check_room(x.shape[0], max_new_tokens)
+                self.llm_forward(x, 0)
+                lens.append(x.shape[0])
+        finally:
+            self.use(keep)
         toks = self.decode_group(grp, pool[:n], lens, max_new_tokens)
         out = []
         for row in toks.cpu():
@@ -583,16 +756,18 @@ class Engine:
             ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
         return g.logits[:M, : l.vocab]
 
-    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens):
-        """Greedy decoding of M prefilled scenes together (their prefill logits are in ctx.logits[0]); returns the token
-        ids [M, max_new_tokens] (device).  No EOS stop: callers trim per scene."""
+    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False):
+        """Greedy decoding of M prefilled scenes together (their prefill logits are in ctx.logits[0], or already in g.logits
+        with logits_ready); returns the token ids [M, max_new_tokens] (device).  No EOS stop: callers trim per scene."""
         l = self.cfg.llm
         M = len(ctxs)
         if M > g.n:
             raise V3DError("decode group too small")
+        self._check_room(max(prompt_lens), max_new_tokens)
         toks = torch.empty((max_new_tokens, M), dtype=torch.int64, device=self.device)
-        for m, c in enumerate(ctxs):
-            g.logits[m].copy_(c.logits[0])
+        if not logits_ready:
+            for m, c in enumerate(ctxs):
+                ops.copy_rows(c.logits[:1], g.logits[m: m + 1])
         logits = g.logits[:M, : l.vocab]
         for step in range(max_new_tokens):
             ops.argmax_rows(logits, toks[step], g.amax_ws)
@@ -602,15 +777,19 @@ class Engine:
             logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens])
         return toks.t()
 
-    def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None):
+    def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None, stopping=None):
         """Greedy loop; token ids stay on the device (argmax kernel -> embedding gather), the host only
-        synchronises per step when an EOS id has to be checked."""
+        synchronises per step when an EOS id or a stopping callback has to be checked."""
+        self._check_room(S, max_new_tokens)
+        eos = () if eos_token_id is None else ((eos_token_id,) if isinstance(eos_token_id, int) else tuple(eos_token_id))
         toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
         n = 0
         for step in range(max_new_tokens):
             ops.argmax(logits, toks[step: step + 1])
             n = step + 1
-            if eos_token_id is not None and int(toks[step]) == eos_token_id:
+            if eos and int(toks[step]) in eos:
+                break
+            if stopping is not None and stopping(toks[:n]):
                 break
             if step + 1 == max_new_tokens:
                 break

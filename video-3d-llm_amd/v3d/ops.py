@@ -40,6 +40,21 @@ def _f3(v):
     return (ctypes.c_float * 3)(*[float(x) for x in v])
 
 
+def _rows_fit(out, rows, cols, dtype, what):
+    """`out` must hold `rows` x `cols` elements of `dtype` behind its data pointer: the kernels trust the sizes they are
+    given, so an empty or short slice (e.g. a row view taken past the end of its buffer) is refused here."""
+    if not isinstance(out, torch.Tensor) or not out.is_cuda:
+        raise V3DError(f"{what}: out must be a CUDA/HIP tensor")
+    if out.dtype != dtype:
+        raise V3DError(f"{what}: out is {out.dtype}, expected {dtype}")
+    if out.dim() == 1:
+        ok = rows <= 1 and out.shape[0] >= cols
+    else:
+        ok = out.dim() == 2 and out.shape[0] >= rows and out.shape[1] >= cols and out.stride(1) == 1
+    if not ok:
+        raise V3DError(f"{what}: out {tuple(out.shape)} cannot hold [{rows},{cols}]")
+
+
 # ------------------------------------------------------------------------------ geometry
 
 
@@ -65,6 +80,20 @@ def unproject_sampled(depth_u16, intrinsics, poses, crop=384, dtype=torch.float3
     out = torch.empty((V, crop, crop, 3), dtype=dtype, device=d.device)
     check(lib().v3d_unproject_sampled_u16(_p(d), _p(K), _p(P), _p(out), _DT[dtype], V, H, W, crop, _stream()),
           "v3d_unproject_sampled_u16")
+    return out
+
+
+def unproject_bounds(depth_u16, intrinsics, poses):
+    """[x_min, x_max, y_min, y_max, z_min, z_max] of the full-resolution back-projection (video_utils.py:268-273) -> f32 [6] (device)."""
+    d = _dev(depth_u16, "depth")
+    if d.dtype not in (torch.uint16, torch.int16):
+        raise V3DError("depth must be a 16-bit integer tensor (raw PNG millimetres)")
+    K = _dev(intrinsics, "intrinsics").float()
+    P = _dev(poses, "poses").float()
+    V, H, W = d.shape
+    ws = torch.empty(lib().v3d_unproject_bounds_workspace_bytes(V) // 4, dtype=torch.float32, device=d.device)
+    out = torch.empty(6, dtype=torch.float32, device=d.device)
+    check(lib().v3d_unproject_bounds_u16(_p(d), _p(K), _p(P), V, H, W, _p(out), _p(ws), ws.numel() * 4, _stream()), "v3d_unproject_bounds_u16")
     return out
 
 
@@ -181,6 +210,7 @@ def embed_gather(weight, ids, out=None):
     vocab, C = w.shape
     if out is None:
         out = torch.empty((i.numel(), C), dtype=w.dtype, device=w.device)
+    _rows_fit(out, i.numel(), C, w.dtype, "embed_gather")
     check(lib().v3d_embed_gather(_p(w), vocab, C, _p(i), i.numel(), _p(out), out.stride(0), _code(w), _stream()),
           "v3d_embed_gather")
     return out
@@ -266,6 +296,9 @@ def gemm(a, w, bias=None, res=None, epilogue=EPI_NONE, out=None, res_mod=0):
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out is None:
         out = torch.empty((M, n_out), dtype=a.dtype, device=a.device)
+    _rows_fit(out, M, n_out, a.dtype, "gemm")
+    if res is not None and (res.shape[0] < (res_mod or M) or res.shape[1] < n_out):
+        raise V3DError(f"gemm: res {tuple(res.shape)} is smaller than the output [{res_mod or M},{n_out}]")
     check(lib().v3d_gemm(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res),
                          res.stride(0) if res is not None else 0, res_mod, _p(out), out.stride(0), M, N, K, _code(a),
                          epilogue, _stream()), "v3d_gemm")
@@ -323,6 +356,7 @@ def rmsnorm(x, weight, eps=1e-6, out=None):
     rows, cols = x.shape
     if out is None:
         out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    _rows_fit(out, rows, cols, x.dtype, "rmsnorm")
     check(lib().v3d_rmsnorm(_p(x), x.stride(0), _p(weight), _p(out), out.stride(0), rows, cols, eps, _code(x), _stream()),
           "v3d_rmsnorm")
     return out
@@ -332,6 +366,7 @@ def layernorm(x, weight, bias, eps=1e-6, out=None):
     rows, cols = x.shape
     if out is None:
         out = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    _rows_fit(out, rows, cols, x.dtype, "layernorm")
     check(lib().v3d_layernorm(_p(x), x.stride(0), _p(weight), _p(bias), _p(out), out.stride(0), rows, cols, eps, _code(x),
                               _stream()), "v3d_layernorm")
     return out
@@ -359,6 +394,36 @@ def rope_apply(x, n_heads, head_dim, table, pos0=0, positions=None):
     tokens = x.shape[0]
     check(lib().v3d_rope_apply(_p(x), x.stride(0), tokens, n_heads, head_dim, _p(table.cos), _p(table.sin), table.n_pos,
                                _p(positions), pos0, _code(x), _stream()), "v3d_rope_apply")
+    return x
+
+
+def rope_kv_store(qkv, n_q, n_kv, head_dim, table, cache, pos0=0, row0=None, positions=None, dst_rows=None):
+    """Prefill rotary + KV-cache append in one launch (include/v3d.h): q heads rotated in place in qkv [tokens, ld], rotated k and
+    v written to cache rows row0 + t (default row0 = pos0) or dst_rows[t]; token t at position pos0 + t or positions[t]."""
+    tokens = qkv.shape[0]
+    if cache.dim() != 2 or cache.stride(1) != 1 or cache.shape[1] < 2 * n_kv * head_dim:
+        raise V3DError("rope_kv_store: cache must be [rows, >= 2*n_kv*head_dim]")
+    if dst_rows is None:
+        row0 = pos0 if row0 is None else row0
+        if row0 < 0 or row0 + tokens > cache.shape[0]:
+            raise V3DError(f"rope_kv_store: rows {row0}..{row0 + tokens} exceed the cache ({cache.shape[0]} rows)")
+    elif dst_rows.dtype != torch.int64 or dst_rows.numel() != tokens or not dst_rows.is_cuda:
+        raise V3DError("rope_kv_store: dst_rows must be a device int64 tensor with one entry per token")
+    if positions is not None and (positions.dtype != torch.int32 or positions.numel() != tokens or not positions.is_cuda):
+        raise V3DError("rope_kv_store: positions must be a device int32 tensor with one entry per token")
+    check(lib().v3d_rope_kv_store(_p(qkv), qkv.stride(0), tokens, n_q, n_kv, head_dim, _p(table.cos), _p(table.sin), table.n_pos,
+                                  _p(positions), pos0, _p(cache), cache.stride(0), _p(dst_rows), row0 or 0, _code(qkv), _stream()),
+          "v3d_rope_kv_store")
+    return qkv
+
+
+def add_row(x, rows, add):
+    """x[rows[i]] += add for a device int64 index tensor (the box-centre PE on <coord> token rows, llava_arch.py:697-700)."""
+    if rows.dtype != torch.int64 or not rows.is_cuda or rows.numel() == 0:
+        raise V3DError("add_row: rows must be a non-empty device int64 tensor")
+    if add.dtype != x.dtype or add.numel() != x.shape[1]:
+        raise V3DError("add_row: `add` must be one row of x's width and dtype")
+    check(lib().v3d_add_row(_p(x), x.stride(0), _p(rows), rows.numel(), x.shape[1], _p(add.contiguous()), _code(x), _stream()), "v3d_add_row")
     return x
 
 
@@ -520,8 +585,20 @@ def ground_scores(obj, query):
 def copy_rows(src, dst, cols=None):
     rows = src.shape[0]
     cols = cols or src.shape[1]
+    _rows_fit(dst, rows, cols, src.dtype, "copy_rows")
     check(lib().v3d_copy_rows(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, _code(src), _stream()),
           "v3d_copy_rows")
+    return dst
+
+
+def copy_rows_bcast(src, dst, cols=None):
+    """src [rows, >=cols] -> dst [n_copies, >=rows, >=cols] (every copy gets the same rows)."""
+    rows = src.shape[0]
+    cols = cols or src.shape[1]
+    if dst.dim() != 3 or dst.shape[1] < rows or dst.shape[2] < cols or dst.stride(2) != 1 or src.stride(1) != 1 or dst.dtype != src.dtype:
+        raise V3DError(f"copy_rows_bcast: dst {tuple(dst.shape)} cannot hold copies of [{rows},{cols}]")
+    check(lib().v3d_copy_rows_bcast(_p(src), src.stride(0), _p(dst), dst.stride(1), rows, cols, dst.shape[0], dst.stride(0), _code(src),
+                                    _stream()), "v3d_copy_rows_bcast")
     return dst
 
 
