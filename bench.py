@@ -5,11 +5,14 @@ One step = one (scene, question) through the whole hot path with inputs resident
   depth u16 + pose -> world coords at the resized/cropped pixels (K1+K2) -> 27x27 patch mean + voxel ids
   (K3+K4) -> SigLIP-so400m tower, 26 layers (K10-K11) -> mlp2x_gelu projector (K12) -> bilinear 27->14 pool
   + 3-D sinusoid PE add + newline rows, written into inputs_embeds (K5-K9) -> Qwen2-7B prefill over
-  6720 visual + 74 text tokens (K13-K18) -> 16 greedy decode steps.
-Random-init weights at the true widths, synthetic inputs, bf16.  Every scene runs the complete path; scenes
-are prefilled one by one and decoded in groups (--decode-group, default 16) that share each pass over the weights.
-The default N = 1 line also carries `fp8_config3` (the same step with e4m3 LLM weights, BASELINE configs[3]), `roofline`
-(north-star 3D-PE+fusion kernel, HBM), `roofline_dominant` (largest GEMM), `roofline_attention` and `cpu_baseline`.
+  6720 visual + 74 text tokens (K13-K18) -> 17 greedy tokens = 16 decode passes over the weights.
+Random-init weights at the true widths, synthetic inputs, bf16, a DIFFERENT synthetic scene per step (all resident
+in HBM before the timed region).  Every scene runs the complete path; scenes are prefilled one by one and decoded in groups
+(--decode-group, default 16) that share each pass over the weights.
+The default N = 1 line also carries `roofline` (the dominant kernel: the Qwen2 gate/up GEMM, MFMA), `roofline_north_star` (3D-PE +
+fusion kernel, HBM), `roofline_attention`, `fp8_config3` (the same step with e4m3 LLM weights, BASELINE configs[3]),
+`cached_questions` (scene-level reuse, SURVEY 8 f1: further questions about an already prefilled scene), `ground_config2`
+(the ScanRefer / Multi3DRefer grounding forward at 32 frames / 50 proposals, BASELINE configs[2], one GPU) and `cpu_baseline`.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
@@ -31,7 +34,8 @@ import torch  # noqa: E402
 
 FRAMES = 32
 TEXT_PRE, TEXT_POST = 14, 60          # 14 system + 60 question ids around one <image> token
-DECODE_STEPS = 16
+NEW_TOKENS = 17                       # 1 from the prefill logits + 16 decode passes over the weights
+DECODE_STEPS = NEW_TOKENS
 IMAGE_TOKEN_INDEX = -200
 
 
@@ -71,6 +75,12 @@ class Stamp:
         return sum(a.elapsed_time(b) for a, b in self.pairs) * 1e3 / max(1, len(self.pairs))
 
 
+def ids_on_device(inp, dev):
+    ids = inp["input_ids"]
+    inp["ids_pre"], inp["ids_post"] = ids[:TEXT_PRE].to(dev), ids[TEXT_PRE + 1:].to(dev)
+    return inp
+
+
 def prefill_phase(eng, ops, inp, stamps):
     """geometry -> ViT -> projector -> fusion -> Qwen2 prefill; returns the last-row logits (MFMA-bound part)."""
     dt = eng.dtype
@@ -92,7 +102,7 @@ def scene_step(eng, ops, inp, stamps):
     return eng.decode_loop(logits, S, DECODE_STEPS)                                     # 16 greedy tokens, no EOS stop
 
 
-def run_grouped(eng, ops, inp, stamps, null, steps, sets, groups, streams, group_size):
+def run_grouped(eng, ops, scenes, stamps, null, steps, sets, groups, streams, group_size):
     """Scenes are prefilled one by one (MFMA-bound, stream A) and decoded in groups of up to `group_size` (stream B):
     the 16 decode steps of a group stream the 15 GB of weights once per step for ALL its scenes (M-row linears),
     instead of once per scene.  Two context sets alternate, so the prefills of group g+1 run while group g decodes.
@@ -112,7 +122,7 @@ def run_grouped(eng, ops, inp, stamps, null, steps, sets, groups, streams, group
                 eng.use(c)
                 # kernel stamps on the first timed scene only: its prefill runs with nothing else on the chip, so the
                 # HIP-event durations are the kernels' own (later scenes share HBM with the previous group's decode)
-                _, S = prefill_phase(eng, ops, inp, stamps if first else null)
+                _, S = prefill_phase(eng, ops, scenes[(gi * group_size + len(lens)) % len(scenes)], stamps if first else null)
                 first = False
                 lens.append(S)
             pre_done = sA.record_event()
@@ -175,6 +185,67 @@ def cpu_baseline(threads):
             "seconds_measured": geom + vit_layer + llm_layer}
 
 
+def kernel_source_sha(*names):
+    """sha1 over the kernel sources a PMC figure belongs to: profiles/pmc_summary.json carries the value it was measured on,
+    so that a figure taken on an older kernel is reported as stale instead of passing silently."""
+    import hashlib
+    h = hashlib.sha1()
+    for n in names:
+        with open(os.path.join(ROOT, "video-3d-llm_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measure_cached_questions(eng, ops, scene_inp, dev, n_groups, group=16, q_len=TEXT_POST):
+    """SURVEY 8 f1: one scene is prefilled once (geometry, ViT, projector, fusion, the decoder over [system | user | <image>]);
+    then n_groups x `group` DIFFERENT questions about it are answered (question rows batched through the decoder over the cached
+    prefix, then one decode group per batch) - the reference recomputes the whole prompt per question (model_scanqa.py:130-185).
+    Returns (questions/s over the answering alone, ms of the one-off scene prefill)."""
+    dt = eng.dtype
+    g = torch.Generator(device=dev).manual_seed(4242)
+    prefix = scene_inp["input_ids"][: TEXT_PRE + 1]
+    qs = [[torch.randint(0, 151000, (q_len,), generator=g, device=dev) for _ in range(group)] for _ in range(n_groups)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    coords = ops.unproject_sampled(scene_inp["depth"], scene_inp["K"], scene_inp["P"], 384, dt)
+    images = ops.preprocess_rgb(scene_inp["frames"], dt)
+    eng.prefill_scene(prefix, images, coords)
+    torch.cuda.synchronize()
+    t_scene = time.perf_counter() - t0
+    eng.answer_group(qs[0], max_new_tokens=NEW_TOKENS)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for q in qs:
+        eng.answer_group(q, max_new_tokens=NEW_TOKENS)
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    return n_groups * group / dt_s, t_scene * 1e3
+
+
+def measure_grounding(eng, ops, scenes, dev, steps):
+    """BASELINE configs[2] on one GPU: the ScanRefer / Multi3DRefer forward (model_scanrefer.py:165-173): geometry, ViT, projector,
+    object-proposal patch masks + masked means for 50 proposals (extract_pred_box.py:30), fusion, Qwen2 prefill, infonce head."""
+    dt = eng.dtype
+    g = torch.Generator(device=dev).manual_seed(777)
+    boxes = torch.cat([(torch.rand(50, 3, generator=g, device=dev) - 0.5) * torch.tensor([8.0, 8.0, 2.0], device=dev),
+                       torch.rand(50, 3, generator=g, device=dev) * 2.0 + 0.3], 1)
+    gpos = TEXT_PRE + 1 + 40                              # the <ground> label token inside the question
+
+    def one(inp):
+        coords = ops.unproject_sampled(inp["depth"], inp["K"], inp["P"], 384, dt)
+        images = ops.preprocess_rgb(inp["frames"], dt)
+        return eng.ground_scores(inp["input_ids"], gpos, images, coords, boxes)
+
+    one(scenes[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        sc = one(scenes[i % len(scenes)])
+    torch.cuda.synchronize()
+    assert sc.shape == (51,)
+    return steps / (time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,33 +255,39 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="one scene at a time: no decode groups, no prefill/decode overlap")
     ap.add_argument("--decode-group", type=int, default=16, help="scenes decoded together per pass over the weights (1..16)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[3]: e4m3 linears in the Qwen2 prefill; the headline line becomes that run")
-    ap.add_argument("--no-fp8-extra", action="store_true", help="skip the extra configs[3] measurement appended to the default N=1 line")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements appended to the default N=1 line (fp8, cached questions, grounding)")
+    ap.add_argument("--no-fp8-extra", action="store_true", help="skip only the configs[3] extra")
+    ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes resident in HBM, cycled over the steps")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}: launch N > 1 with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus}`")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    from v3d import distributed as v3dist
     from v3d import ops
     from v3d.engine import Engine, EngineConfig, random_state_dict
     dtype = torch.bfloat16
     cfg = EngineConfig()
-    sd = random_state_dict(cfg, dtype, dev, seed=0)
+    sd = random_state_dict(cfg, dtype, dev, seed=0, ground_head=True)
     eng = Engine(cfg, sd, dtype=dtype, device=dev, max_frames=FRAMES, llm_fp8=a.fp8)
-    inp = synth_inputs(dev, dtype, seed=100 + rank)
-    ids = inp["input_ids"]
-    inp["ids_pre"], inp["ids_post"] = ids[:TEXT_PRE].to(dev), ids[TEXT_PRE + 1:].to(dev)
+    # the rank's share of the (scene, question) list: the reference's stride sharding, model_scanqa.py:245
+    n_scenes = max(1, min(a.scenes, a.steps))
+    my_ids = v3dist.shard(list(range(world * a.steps)), rank, world)
+    scenes = [ids_on_device(synth_inputs(dev, dtype, seed=1000 + world * i + rank), dev) for i in range(n_scenes)]
     torch.cuda.synchronize()
 
-    stamps = {"pe": Stamp(), "gemm": Stamp(), "attn": Stamp()}
+    def new_stamps():
+        return {"pe": Stamp(), "gemm": Stamp(), "attn": Stamp()}
+    stamps = new_stamps()
     null = {"pe": (lambda f: f()), "gemm": (lambda f: f()), "attn": (lambda f: f())}
 
     def barrier():
@@ -219,7 +296,6 @@ def main():
         torch.cuda.synchronize()
 
     streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-
     G_ALL = max(1, min(16, a.decode_group))
 
     def measure(eng, stamps):
@@ -229,41 +305,58 @@ def main():
         groups = [eng.new_group(G), eng.new_group(G)]
         for w in range(a.warmup):
             eng.use(sets[0][0])
-            scene_step(eng, ops, inp, null)
+            scene_step(eng, ops, scenes[w % n_scenes], null)
         if a.warmup and not a.no_overlap:                       # warm the grouped kernels' code paths too
-            run_grouped(eng, ops, inp, null, null, min(G, a.steps), sets, groups, streams, G)
+            run_grouped(eng, ops, scenes, null, null, min(G, a.steps), sets, groups, streams, G)
         barrier()
         t0 = time.perf_counter()
         if a.no_overlap:
             eng.use(sets[0][0])
-            answers = torch.stack([scene_step(eng, ops, inp, stamps) for _ in range(a.steps)])
+            answers = torch.stack([scene_step(eng, ops, scenes[i % n_scenes], stamps) for i in range(a.steps)])
         else:
-            answers = run_grouped(eng, ops, inp, stamps, null, a.steps, sets, groups, streams, G)
-        if world > 1:   # eval collation: ONE gather of the generated ids to rank 0 (replaces Ray + file lock)
-            bucket = [torch.empty_like(answers) for _ in range(world)] if rank == 0 else None
-            dist.gather(answers, bucket, dst=0)
+            answers = run_grouped(eng, ops, scenes, stamps, null, a.steps, sets, groups, streams, G)
+        merged = None
+        if world > 1:   # eval collation: ONE variable-length gather of the answer records to rank 0 (replaces Ray + file lock)
+            recs = [{"sample_id": sid, "pred_token_ids": row} for sid, row in zip(my_ids, answers.tolist())]
+            merged = v3dist.gather_records(recs, dev)
         barrier()
         dt_s = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_s = tt.item()
+            if rank == 0:
+                assert [r["sample_id"] for r in merged] == list(range(world * a.steps)), "gathered records are not in question order"
+        eng.use(sets[0][0])
         return dt_s
 
     dt_s = measure(eng, stamps)
-    fp8_extra = None
-    if world == 1 and not a.fp8 and not a.no_fp8_extra:
-        del eng
-        eng8 = Engine(cfg, sd, dtype=dtype, device=dev, max_frames=FRAMES, llm_fp8=True)
-        st8 = {"pe": Stamp(), "gemm": Stamp(), "attn": Stamp()}
-        t8 = measure(eng8, st8)
-        g8 = st8["gemm"].mean_us()
-        fp8_extra = {"what": "BASELINE configs[3]: same scene step with e4m3 (per-row scaled) weights in the Qwen2 linears and LM head "
-                             "(prefill W8A8 on MFMA, decode W8A16 weight streaming); ViT, attention, norms and residual stream stay bf16",
-                     "value": a.steps / t8, "unit": "scenes/s", "ms_per_step": t8 / a.steps * 1e3,
-                     "gate_up_gemm_us": g8, "gate_up_gemm_tflops": 2.0 * (TEXT_PRE + FRAMES * 210 + TEXT_POST) * 37888 * 3584 / g8 / 1e6,
-                     "mfma_peak_tflops": 5000.0}
-        del eng8
+    extras = {}
+    if world == 1 and not a.no_extras:
+        nq, scene_ms = measure_cached_questions(eng, ops, scenes[0], dev, n_groups=max(1, a.steps // 4))
+        extras["cached_questions"] = {
+            "what": "scene-level reuse (SURVEY 8 f1; not the headline): further questions about an ALREADY prefilled scene - %d question rows "
+                    "per question run over the cached prefix of %d rows, 16 questions per batch, %d new tokens each; the one-off scene prefill "
+                    "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, NEW_TOKENS),
+            "value": nq, "unit": "questions/s", "scene_prefill_ms": scene_ms}
+        extras["ground_config2"] = {
+            "what": "BASELINE configs[2] on one GPU: ScanRefer / Multi3DRefer grounding forward, 32 frames, 50 object proposals, "
+                    "infonce head (prefill only, no decode)",
+            "value": measure_grounding(eng, ops, scenes, dev, max(4, a.steps // 2)), "unit": "scenes/s"}
+        if not a.fp8 and not a.no_fp8_extra:
+            del eng
+            torch.cuda.empty_cache()
+            eng8 = Engine(cfg, sd, dtype=dtype, device=dev, max_frames=FRAMES, llm_fp8=True)
+            st8 = new_stamps()
+            t8 = measure(eng8, st8)
+            g8 = st8["gemm"].mean_us()
+            extras["fp8_config3"] = {
+                "what": "BASELINE configs[3]: same scene step with e4m3 (per-row scaled) weights in the Qwen2 linears and LM head "
+                        "(prefill W8A8 on MFMA, decode W8A16 weight streaming); ViT, attention, norms and residual stream stay bf16",
+                "value": a.steps / t8, "unit": "scenes/s", "ms_per_step": t8 / a.steps * 1e3,
+                "gate_up_gemm_us": g8, "gate_up_gemm_tflops": 2.0 * (TEXT_PRE + FRAMES * 210 + TEXT_POST) * 37888 * 3584 / g8 / 1e6,
+                "mfma_peak_tflops": 5000.0}
+            del eng8
 
     if rank == 0:
         S = TEXT_PRE + FRAMES * 210 + TEXT_POST
@@ -274,36 +367,43 @@ def main():
         gemm_peak = 5000.0 if a.fp8 else 2500.0
         attn_us = stamps["attn"].mean_us()
         attn_flops = 2.0 * S * S * 128 * 28                                   # causal: half of 4*S^2*d*H
-        traffic, attn_busy = None, None
+        traffic, traffic_note, attn_busy = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             pm = json.load(open(pmc))
-            traffic = pm.get("visual_tokens_hbm_bytes_per_launch")
             attn_busy = pm.get("attention_mfma_busy_frac")       # PMC: MFMA-busy share of SIMD cycles at the actual clock
+            sha = kernel_source_sha("visual_tokens.hip")
+            if pm.get("visual_tokens_source_sha") == sha:
+                traffic = pm.get("visual_tokens_hbm_bytes_per_launch")
+                traffic_note = "PMC FETCH_SIZE x2 + WRITE_SIZE (separate rocprofv3 --pmc passes, profiles/), measured on this kernel source (%s)" % sha
+            else:
+                traffic_note = "stale: profiles/pmc_summary.json was measured on kernel source %s, this build is %s" % (pm.get("visual_tokens_source_sha"), sha)
         line = {
             "metric": "scenes/sec ScanQA @32 frames", "value": world * a.steps / dt_s, "unit": "scenes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_s / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "ScanQA val, uniform 32 frames, %s, 1xMI355X per rank: 32x(480x640 u16 depth + 384x384 RGB) -> "
-                                   "SigLIP-so400m(26L) + mlp2x_gelu + 3D-PE fusion -> Qwen2-7B prefill S=%d + %d greedy decode steps; "
-                                   "random-init weights at true widths" % ("fp8 LLM linears (configs[3])" if a.fp8 else "bf16", S, DECODE_STEPS),
-                       "frames": FRAMES, "seq_len": S, "decode_steps": DECODE_STEPS, "parallelism": "scene-dp%d" % world,
-                       "decode_group": 1 if a.no_overlap else G_ALL,
+                                   "SigLIP-so400m(26L) + mlp2x_gelu + 3D-PE fusion -> Qwen2-7B prefill S=%d + %d greedy tokens (%d decode passes "
+                                   "over the weights); random-init weights at true widths; %d distinct synthetic scenes cycled"
+                                   % ("fp8 LLM linears (configs[3])" if a.fp8 else "bf16", S, NEW_TOKENS, NEW_TOKENS - 1, n_scenes),
+                       "frames": FRAMES, "seq_len": S, "new_tokens": NEW_TOKENS, "decode_weight_passes": NEW_TOKENS - 1,
+                       "parallelism": "scene-dp%d" % world, "decode_group": 1 if a.no_overlap else G_ALL,
                        "scheduling": "one scene at a time" if a.no_overlap else
-                                     "prefill per scene on stream A; the 16 decode steps of up to %d scenes share each pass over the weights on stream B" % G_ALL},
-            "roofline": {"kernel": "visual_tokens_kernel (bilinear pool + 3D-PE add + newline, K5-K8)", "bound": "hbm",
-                         "achieved": pe_bytes / pe_us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": pe_bytes / pe_us / 1e3 / 8000.0,
-                         "traffic": traffic, "us_per_launch": pe_us, "algorithmic_bytes": pe_bytes},
-            "roofline_dominant": {"kernel": "gemm_kernel (Qwen2 gate/up + SwiGLU, M=%d N=37888 K=3584)" % S, "bound": "mfma",
-                                  "achieved": gemm_flops / gemm_us / 1e6, "peak": gemm_peak, "unit": "TFLOP/s",
-                                  "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": None, "us_per_launch": gemm_us},
+                                     "prefill per scene on stream A; the decode passes of up to %d scenes share each pass over the weights on stream B" % G_ALL},
+            "roofline": {"kernel": "%s (Qwen2 gate/up + SwiGLU, M=%d N=37888 K=3584): the largest share of the step" %
+                                   ("gemm_fp8_kernel" if a.fp8 else "gemm256pp_kernel", S), "bound": "mfma",
+                         "achieved": gemm_flops / gemm_us / 1e6, "peak": gemm_peak, "unit": "TFLOP/s",
+                         "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": None, "us_per_launch": gemm_us,
+                         "algorithmic_flops": gemm_flops},
+            "roofline_north_star": {"kernel": "visual_tokens_kernel (bilinear pool + 3D-PE add + newline, K5-K8)", "bound": "hbm",
+                                    "achieved": pe_bytes / pe_us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": pe_bytes / pe_us / 1e3 / 8000.0,
+                                    "traffic": traffic, "traffic_note": traffic_note, "us_per_launch": pe_us, "algorithmic_bytes": pe_bytes},
             "roofline_attention": {"kernel": "attn_prefill_kernel (causal GQA, S=%d, 28q/4kv, hd128)" % S, "bound": "mfma",
                                    "achieved": attn_flops / attn_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
                                    "frac": attn_flops / attn_us / 1e6 / 2500.0, "traffic": None, "us_per_launch": attn_us,
                                    "mfma_busy_frac_pmc": attn_busy},
         }
-        if fp8_extra is not None:
-            line["fp8_config3"] = fp8_extra
+        line.update(extras)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
         print(json.dumps(line))

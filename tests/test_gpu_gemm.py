@@ -108,3 +108,34 @@ def test_gemm_rejects_bad_shapes(ops):
     w = torch.zeros(128, 100, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(V3DError, match="multiple"):
         ops.gemm(a, w)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 128, "none"), (300, 512, 192, "bias"), (1000, 768, 1152, "res"), (513, 256, 640, "gelu"),
+                                       (6794, 4608, 3584, "bias"), (2000, 1024, 256, "swiglu"), (6794, 3584, 3584, "res")])
+def test_gemm_pingpong_tile_equals_v3_tile_bitwise(ops, kind, M, N, K, epi, monkeypatch):
+    """The ping-pong schedule of the 256 x 256 tile (gemm256pp_kernel: half-tile ring, counted vmcnt, staggered wave rows)
+    accumulates every output element in the same k order as the v3 kernel, so the two must agree BIT FOR BIT on every shape
+    (a stale or early LDS read shows up as a difference); the v3 kernel itself is checked against the f32 reference above.
+    K from 2 to 56 K-steps covers the prologue / second-last / last K-step code paths."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dt = DT[kind]
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    r = torch.randn(M, N, generator=g).to(dt).cuda()
+    kw = {"none": dict(), "bias": dict(bias=b, epilogue=ops.EPI_BIAS), "res": dict(res=r, epilogue=ops.EPI_RES),
+          "gelu": dict(bias=b, epilogue=ops.EPI_BIAS_GELU_TANH), "swiglu": dict(epilogue=ops.EPI_SWIGLU)}[epi]
+    monkeypatch.setenv("V3D_GEMM_VARIANT", "3")          # force the 256 x 256 tile whatever the cost model would pick
+    outs = {}
+    for pp in ("0", "1"):
+        monkeypatch.setenv("V3D_GEMM_PP", pp)
+        for rep in range(3):                              # repeated launches: a race would not be stable
+            out = ops.gemm(a, w, **kw)
+            torch.cuda.synchronize()
+            if pp in outs:
+                assert torch.equal(out, outs[pp]), f"pp={pp}: launch {rep} differs from launch 0"
+            outs[pp] = out
+    assert torch.equal(outs["0"], outs["1"])
+    if epi in ("none", "bias"):
+        close(outs["1"], ref_linear(a.cpu(), w.cpu(), b.cpu() if epi == "bias" else None, dt), kind)

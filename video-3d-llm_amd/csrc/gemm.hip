@@ -40,6 +40,8 @@ template <> struct Mfma16<f16_t> {
   }
 };
 
+template <int N> struct IntC { static constexpr int value = N; };
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_A_BYTES = BM * BK * 2;            // 16 KiB
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;      // 32 KiB
@@ -509,6 +511,224 @@ __global__ __launch_bounds__(512, 2) void gemm256x256_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// v4: the same 256 x 256 x 64 macro tile and 128 x 64 wave tile, scheduled as a PING-PONG between the two waves that
+// share a SIMD (waves w and w + 4, i.e. the wave rows wm = 0 / 1): a K-step is four phases of 16 MFMAs (one 64 x 32
+// quadrant of the wave tile x both k-halves); every phase is { load segment: the quadrant's new fragments by ds_read_b128 +
+// two LDS-DMA pieces of a later half-tile | barrier | lgkmcnt(0) | 16 MFMAs | barrier }, and the wm = 1 waves run ONE barrier
+// behind the wm = 0 waves, so that on every SIMD one wave is inside its MFMA cluster while its partner issues its loads:
+// fragment-read latency and DMA issue cost (60-185 cycles per piece) sit in the shadow of the partner's 256 MFMA cycles
+// instead of in front of the wave's own MFMAs (v3 keeps ~30 % of its wave cycles at the K-step rendezvous).
+//
+// Operand tiles are staged in HALF-tiles of 128 rows (16 KiB = 2 pieces per wave), ordered as they are consumed:
+//   H(4t+0) = A rows {128 wm + r}, r < 64   (quadrants with hm = 0)      H(4t+1) = W rows {64 wn + r}, r < 32  (hn = 0)
+//   H(4t+2) = W rows {64 wn + 32 + r}                      (hn = 1)      H(4t+3) = A rows {128 wm + 64 + r}    (hm = 1)
+// phases of K-step t: (hm, hn) = (0,0) (0,1) (1,1) (1,0) - each needs at most one new half of each operand; W(hn = 0) stays in
+// registers for the fourth.  Ring: 8 half-tile slots (2 K-steps, 128 KiB); phase P issues H(P + 5) and waits vmcnt(6), i.e.
+// until everything up to H(P + 2) - what phase P + 1 reads - has landed (its own pieces; the barriers publish the others').
+// Hazards, with B(k) the k-th workgroup barrier, phase P of the wm = 0 waves between B(2P) and B(2P+2), of the wm = 1
+// waves between B(2P+1) and B(2P+3):
+//   RAW  H(j) is read in phase c(j) >= j - 1 >= (its wait's phase) + 1, i.e. after a barrier every wave passed after its wait;
+//   WAR  H(P + 5) overwrites the slot of H(P - 3), last read in phase <= P - 3: those reads were retired (lgkmcnt(0)) before
+//        B(2P - 3) by both wave rows, and the earliest overwrite is issued after B(2P).
+// ------------------------------------------------------------------------------------------
+constexpr int PP_HALF = 128 * BK * 2;                   // 16 KiB per half-tile
+constexpr int PP_BUF = 4 * PP_HALF;                     // one K-step: A0 | W0 | W1 | A1
+constexpr int PP_LDS_BYTES = 256 * (B3N * 2 + 16);      // 132 KiB: the C tile of the epilogue (the 128 KiB ring fits inside)
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using M16 = Mfma16<T>;
+  using frag = typename M16::frag;
+  using v4i = __attribute__((ext_vector_type(4))) int;
+  constexpr int MT = 8, WROWS = 128, BM = 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * B3N;
+
+  // ---- staging: wave w moves local rows [16w, 16w + 16) of every half-tile, two 8-row pieces ----
+  unsigned a_off[2][2], w_off[2][2];        // [half][piece] byte offsets of this lane's 16-byte source chunk
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = wave * 16 + i * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int gm = m0 + 128 * (lr >> 6) + 64 * h + (lr & 63);
+      gm = gm < p.M ? gm : p.M - 1;                            // M tail: re-read the last row, never stored
+      a_off[h][i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
+      const int gn = n0 + 64 * (lr >> 5) + 32 * h + (lr & 31);
+      w_off[h][i] = (unsigned)(gn * (int)p.ldw + chunk * 8) * 2u;
+    }
+  }
+  // half-tile kinds in stream order: 0 = A(hm 0), 1 = W(hn 0), 2 = W(hn 1), 3 = A(hm 1)
+  auto stage = [&](auto kind_c, int kt) {
+    constexpr int KIND = decltype(kind_c)::value;
+    char* dst = smem + (kt & 1) * PP_BUF + KIND * PP_HALF + (wave * 16) * (BK * 2);
+    const char* src = (KIND == 0 || KIND == 3) ? (const char*)p.A : (const char*)p.W;
+    src += (size_t)kt * (BK * 2);
+    const unsigned* off = KIND == 0 ? a_off[0] : KIND == 3 ? a_off[1] : KIND == 1 ? w_off[0] : w_off[1];
+    glds16(src + off[0], dst);
+    glds16(src + off[1], dst + 8 * (BK * 2));
+  };
+
+  const int sw = (lane >> 1) & 7;
+  const unsigned frow = (lane & 15) * (BK * 2);
+  const unsigned fo0 = frow + (((0 + (lane >> 4)) ^ sw) << 4);
+  const unsigned fo1 = frow + (((4 + (lane >> 4)) ^ sw) << 4);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned aA = lds0 + (wm * 64) * (BK * 2);        // + buf * PP_BUF + {0 | 3 * PP_HALF} + fo{0,1}; m-tile: + 2048 each
+  const unsigned aW = lds0 + PP_HALF + (wn * 32) * (BK * 2);   // + buf * PP_BUF + {0 | PP_HALF}
+
+  f32x4 acc[4][MT];   // [n-tile][m-tile] of the transposed product
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  v4i FA[8], W0[4], W1[4];     // FA[2 * mt + kh], W[2 * nt2 + kh]
+#define V3D_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define V3D_RDA8(b0, b1) { V3D_DSR(FA[0], b0, 0); V3D_DSR(FA[1], b1, 0); V3D_DSR(FA[2], b0, 2048); V3D_DSR(FA[3], b1, 2048); \
+                           V3D_DSR(FA[4], b0, 4096); V3D_DSR(FA[5], b1, 4096); V3D_DSR(FA[6], b0, 6144); V3D_DSR(FA[7], b1, 6144); }
+#define V3D_RDW4(f, b0, b1) { V3D_DSR(f[0], b0, 0); V3D_DSR(f[1], b1, 0); V3D_DSR(f[2], b0, 2048); V3D_DSR(f[3], b1, 2048); }
+#define V3D_LG0_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FA[4]), "+v"(FA[5]), "+v"(FA[6]), "+v"(FA[7]) : : "memory")
+#define V3D_LG0_W(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+#define V3D_PPMMA(HM, HN, WF)                                                                          \
+  {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                     \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                   \
+    _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2)                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
+        acc[2 * (HN) + n2][4 * (HM) + mt] = M16::run(__builtin_bit_cast(frag, WF[2 * n2 + kh]), __builtin_bit_cast(frag, FA[2 * mt + kh]), \
+                                                     acc[2 * (HN) + n2][4 * (HM) + mt]);               \
+    __builtin_amdgcn_s_setprio(0);                                                                     \
+  }
+#define V3D_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define V3D_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+  const int nt = p.K / BK;       // >= 2 (the launcher sends shorter K to the v3 kernel)
+  // MODE 0: steady state; 1: second-last K-step (its fourth phase has nothing left to issue); 2: last K-step
+  auto kstep = [&](auto mode_c, int t) {
+    constexpr int MODE = decltype(mode_c)::value;
+    const unsigned bo = (unsigned)(t & 1) * PP_BUF;
+    // phase 0: quadrant (hm 0, hn 0)
+    { const unsigned w0 = aW + bo + fo0, w1 = aW + bo + fo1, a0 = aA + bo + fo0, a1 = aA + bo + fo1;
+      V3D_RDW4(W0, w0, w1); V3D_RDA8(a0, a1); }
+    if constexpr (MODE < 2) { stage(IntC<1>{}, t + 1); V3D_VM(6); } else { V3D_VM(2); }
+    V3D_BAR(); V3D_LG0_W(W0); V3D_LG0_A();
+    V3D_PPMMA(0, 0, W0);
+    V3D_BAR();
+    // phase 1: quadrant (hm 0, hn 1)
+    { const unsigned w0 = aW + bo + PP_HALF + fo0, w1 = aW + bo + PP_HALF + fo1;
+      V3D_RDW4(W1, w0, w1); }
+    if constexpr (MODE < 2) { stage(IntC<2>{}, t + 1); V3D_VM(6); } else { V3D_VM(0); }
+    V3D_BAR(); V3D_LG0_W(W1);
+    V3D_PPMMA(0, 1, W1);
+    V3D_BAR();
+    // phase 2: quadrant (hm 1, hn 1)
+    { const unsigned a0 = aA + bo + 3 * PP_HALF + fo0, a1 = aA + bo + 3 * PP_HALF + fo1;
+      V3D_RDA8(a0, a1); }
+    if constexpr (MODE < 2) { stage(IntC<3>{}, t + 1); V3D_VM(6); }
+    V3D_BAR(); V3D_LG0_A();
+    V3D_PPMMA(1, 1, W1);
+    V3D_BAR();
+    // phase 3: quadrant (hm 1, hn 0): no new fragments
+    if constexpr (MODE == 0) { stage(IntC<0>{}, t + 2); V3D_VM(6); } else if constexpr (MODE == 1) { V3D_VM(4); }
+    V3D_BAR();
+    V3D_PPMMA(1, 0, W0);
+    V3D_BAR();
+  };
+
+  stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0); stage(IntC<0>{}, 1);
+  V3D_VM(6);
+  V3D_BAR();
+  if (wm == 1) V3D_BAR();                      // the wm = 1 waves run one barrier behind
+  {
+    int t = 0;
+    for (; t < nt - 2; ++t) kstep(IntC<0>{}, t);
+    kstep(IntC<1>{}, t);
+    kstep(IntC<2>{}, t + 1);
+  }
+  if (wm == 0) V3D_BAR();
+#undef V3D_DSR
+#undef V3D_RDA8
+#undef V3D_RDW4
+#undef V3D_LG0_A
+#undef V3D_LG0_W
+#undef V3D_PPMMA
+#undef V3D_VM
+#undef V3D_BAR
+  __syncthreads();
+
+  // epilogue: the whole 256 x 256 C tile goes through LDS at once (256 rows x 528 B = 132 KiB of the CU's 160: one rendezvous
+  // instead of the v3 kernel's two half-tile passes), then leaves as whole 512-byte row segments
+  constexpr int C3_ROW = B3N * 2 + 16;
+  const T* bias = (const T*)p.bias;
+  T* out = (T*)p.out;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi_has_bias(EPI)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int ml = wm * WROWS + mi * 16 + (lane & 15);
+      uint2 pk;
+      pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
+      pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
+      *reinterpret_cast<uint2*>(smem + ml * C3_ROW + nl * 2) = pk;
+    }
+  }
+  __syncthreads();
+  if (EPI == EPI_SWIGLU) {
+    // tile columns: per 128-column group [gate64 | up64]; two groups per tile -> 128 output columns
+#pragma unroll 2
+    for (int row = tid >> 4; row < BM; row += 32) {
+      const int c16 = tid & 15, grp = c16 >> 3, ch = c16 & 7;
+      const int gm = m0 + row;
+      const uint4 g = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + ch * 16);
+      const uint4 u = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + 128 + ch * 16);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu(vec_get<T>(g, j))) * vec_get<T>(u, j);
+      if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + tn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
+    }
+  } else {
+#pragma unroll 2
+    for (int row = tid >> 5; row < BM; row += 16) {
+      const int ch = tid & 31;
+      const int gm = m0 + row;
+      if (gm < p.M) {
+        uint4 c = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + ch * 16);
+        if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES || EPI == EPI_BIAS_RELU) {
+          float v[8];
+          uint4 rr = make_uint4(0, 0, 0, 0);
+          if (EPI == EPI_BIAS_RES || EPI == EPI_RES) {
+            const int64_t rm = p.res_mod > 0 ? (gm % p.res_mod) : gm;
+            rr = *reinterpret_cast<const uint4*>((const T*)p.res + rm * p.ldr + n0 + ch * 8);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x = vec_get<T>(c, j);
+            v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + vec_get<T>(rr, j);
+          }
+          c = vec_pack<T>(v);
+        }
+        *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + n0 + ch * 8) = c;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Skinny GEMM for decode (M <= 8): out[m, n] = A[m,:] . W[n,:] (+bias)(+res).  Pure weight
 // streaming: one wave per output column group, 16-byte loads, f32 accumulate, shuffle reduce.
 // ------------------------------------------------------------------------------------------
@@ -601,10 +821,9 @@ __global__ __launch_bounds__(256) void gemv_swiglu_kernel(const T* __restrict__ 
   }
 }
 
-static int gemm_variant() {   // 0 = auto, 1 = force 128x128, 3 = force 256x256 (where N allows); for A/B runs
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("V3D_GEMM_VARIANT"); v = e ? atoi(e) : 0; }
-  return v;
+static int gemm_variant() {   // 0 = auto, 1 = force 128x128, 3 = force 256x256 (where N allows), 4 = force 192x256; read per call (A/B runs)
+  const char* e = getenv("V3D_GEMM_VARIANT");
+  return e ? atoi(e) : 0;
 }
 
 static int gemm_dma_mode() {   // -1 = auto, 0 / 1 = force (A/B runs)
@@ -646,21 +865,61 @@ static int launch_gemm256x256(GemmArgs p, int epi, hipStream_t st) {
   return check_launch("v3d_gemm (256-wide)");
 }
 
+static int gemm_pp_mode() {   // 1 (default) = ping-pong v4 for the 256 x 256 tile, 0 = the v3 kernel; read per call so that a
+  const char* e = getenv("V3D_GEMM_PP");     // test can A/B the two in one process
+  return e ? atoi(e) : 1;
+}
+
+template <typename T>
+static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = p.N / B3N;
+#define V3D_GEMM4_CASE(E)                                                                                 \
+  case E: {                                                                                               \
+    auto k = gemm256pp_kernel<T, E>;                                                                      \
+    static bool attr_done = false;                                                                        \
+    if (!attr_done) {                                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES); \
+      if (e != hipSuccess) { set_error("v3d_gemm: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
+      attr_done = true;                                                                                   \
+    }                                                                                                     \
+    hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), PP_LDS_BYTES, st, p);                   \
+  } break;
+  switch (epi) {
+    V3D_GEMM4_CASE(EPI_NONE)
+    V3D_GEMM4_CASE(EPI_BIAS)
+    V3D_GEMM4_CASE(EPI_BIAS_GELU_ERF)
+    V3D_GEMM4_CASE(EPI_BIAS_GELU_TANH)
+    V3D_GEMM4_CASE(EPI_BIAS_RES)
+    V3D_GEMM4_CASE(EPI_RES)
+    V3D_GEMM4_CASE(EPI_SWIGLU)
+    V3D_GEMM4_CASE(EPI_BIAS_RELU)
+    default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
+  }
+#undef V3D_GEMM4_CASE
+  return check_launch("v3d_gemm (256-wide, ping-pong)");
+}
+
 template <typename T>
 static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
-  // Tile choice (speed only): 256x256 runs ~1.27x the MFMA rate of 128x128 per tile but one workgroup per CU,
-  // so it loses when its tile count quantises badly against 256 CUs (e.g. 27 x 14 = 378 tiles).
+  // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
+  //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
+  //   256 x 256 ping-pong (256 slots): fixed 9 (prologue DMA latency + epilogue), 1.26 per K-step
+  //   192 x 256 v3        (256 slots): fixed 2, 1.32 per K-step  (3/4 of the tile: wins when 256-row tiles quantise badly
+  //                                    against the 256 CUs, e.g. M = 6794, N = 3584: 378 tiles = 1.48 rounds vs 504 = 1.97)
+  //   128 x 128           (512 slots): fixed 1, 0.98 per K-step  (many small tiles: small M, or N % 256 != 0)
   const int var = gemm_variant();
   if (p.N % B3N == 0 && var != 1) {
-    // cost in units of "one 128x128 tile on a whole CU at the 128x128 kernel's rate"
+    const double ks = (double)(p.K / BK);
     const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
-    const double t256 = (double)((tiles256 + 255) / 256) * 4.0 / 1.27;
-    const double t192 = (double)((tiles192 + 255) / 256) * 3.0 / 1.22;
-    const double t1 = (double)p.tiles_m * p.tiles_n / 256.0;
+    const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
+    const double t256 = (double)((tiles256 + 255) / 256) * (pp ? 9.0 + 1.2625 * ks : 9.0 + 1.36 * ks);
+    const double t192 = (double)((tiles192 + 255) / 256) * (2.0 + 1.32 * ks);
+    const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
     if (var == 4) return launch_gemm256x256<T, 6>(p, epi, st);
-    if (var == 3) return launch_gemm256x256<T, 8>(p, epi, st);
+    if (var == 3) return pp ? launch_gemm256pp<T>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
     if (t192 < t256 && t192 < t1) return launch_gemm256x256<T, 6>(p, epi, st);
-    if (t256 < t1) return launch_gemm256x256<T, 8>(p, epi, st);
+    if (t256 < t1) return pp ? launch_gemm256pp<T>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
   }
 #define V3D_GEMM_CASE(E)                                                                                  \
   case E: {                                                                                               \
