@@ -126,16 +126,18 @@ def test_gemm_pingpong_tile_equals_v3_tile_bitwise(ops, kind, M, N, K, epi, monk
     r = torch.randn(M, N, generator=g).to(dt).cuda()
     kw = {"none": dict(), "bias": dict(bias=b, epilogue=ops.EPI_BIAS), "res": dict(res=r, epilogue=ops.EPI_RES),
           "gelu": dict(bias=b, epilogue=ops.EPI_BIAS_GELU_TANH), "swiglu": dict(epilogue=ops.EPI_SWIGLU)}[epi]
-    monkeypatch.setenv("V3D_GEMM_VARIANT", "3")          # force the 256 x 256 tile whatever the cost model would pick
     outs = {}
-    for pp in ("0", "1"):
-        monkeypatch.setenv("V3D_GEMM_PP", pp)
-        for rep in range(3):                              # repeated launches: a race would not be stable
-            out = ops.gemm(a, w, **kw)
-            torch.cuda.synchronize()
-            if pp in outs:
-                assert torch.equal(out, outs[pp]), f"pp={pp}: launch {rep} differs from launch 0"
-            outs[pp] = out
-    assert torch.equal(outs["0"], outs["1"])
+    for var in ("3", "4"):                                # force the 256 x 256 / 192 x 256 tile whatever the cost model would pick
+        monkeypatch.setenv("V3D_GEMM_VARIANT", var)
+        for pp in ("0", "1"):
+            monkeypatch.setenv("V3D_GEMM_PP", pp)
+            for rep in range(3):                          # repeated launches: a race would not be stable
+                out = ops.gemm(a, w, **kw)
+                torch.cuda.synchronize()
+                if (var, pp) in outs:
+                    assert torch.equal(out, outs[var, pp]), f"variant {var} pp={pp}: launch {rep} differs from launch 0"
+                outs[var, pp] = out
+    assert torch.equal(outs["3", "0"], outs["3", "1"]) and torch.equal(outs["4", "0"], outs["4", "1"])
+    assert torch.equal(outs["3", "1"], outs["4", "1"])    # every tile shape sums k in the same order
     if epi in ("none", "bias"):
-        close(outs["1"], ref_linear(a.cpu(), w.cpu(), b.cpu() if epi == "bias" else None, dt), kind)
+        close(outs["4", "1"], ref_linear(a.cpu(), w.cpu(), b.cpu() if epi == "bias" else None, dt), kind)

@@ -535,13 +535,18 @@ constexpr int PP_HALF = 128 * BK * 2;                   // 16 KiB per half-tile
 constexpr int PP_BUF = 4 * PP_HALF;                     // one K-step: A0 | W0 | W1 | A1
 constexpr int PP_LDS_BYTES = 256 * (B3N * 2 + 16);      // 132 KiB: the C tile of the epilogue (the 128 KiB ring fits inside)
 
-template <typename T, int EPI>
+template <typename T, int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using M16 = Mfma16<T>;
   using frag = typename M16::frag;
   using v4i = __attribute__((ext_vector_type(4))) int;
-  constexpr int MT = 8, WROWS = 128, BM = 256;
+  // MT = 16-row accumulator tiles per wave along M: 8 -> BM = 256; 6 -> BM = 192 (A half-tiles of 96 rows = 12 pieces: the
+  // wm = 0 waves move two of them, the wm = 1 waves one, so the counted waits differ between the wave rows)
+  constexpr int MH = MT / 2;                // m-tiles per quadrant
+  constexpr int HR = MH * 16;               // A rows per wave row and half
+  constexpr int WROWS = MT * 16, BM = 2 * WROWS;
+  constexpr int NPA = 2 * HR / 8;           // pieces of an A half-tile: 16 or 12
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -551,30 +556,33 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * B3N;
 
-  // ---- staging: wave w moves local rows [16w, 16w + 16) of every half-tile, two 8-row pieces ----
+  // ---- staging: piece q = wave + 8 i (8 rows, 1 KiB) of every half-tile; W halves have 16 pieces, A halves NPA ----
   unsigned a_off[2][2], w_off[2][2];        // [half][piece] byte offsets of this lane's 16-byte source chunk
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int lr = wave * 16 + i * 8 + (lane >> 3);
+    const int lr = (wave + 8 * i) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+    const int awm = lr / HR, ar = lr - awm * HR;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int gm = m0 + 128 * (lr >> 6) + 64 * h + (lr & 63);
+      int gm = m0 + WROWS * awm + HR * h + ar;
       gm = gm < p.M ? gm : p.M - 1;                            // M tail: re-read the last row, never stored
       a_off[h][i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
       const int gn = n0 + 64 * (lr >> 5) + 32 * h + (lr & 31);
       w_off[h][i] = (unsigned)(gn * (int)p.ldw + chunk * 8) * 2u;
     }
   }
+  const bool a_two = wave + 8 < NPA;        // this wave moves a second A piece (always for MT = 8; the wm = 0 waves for MT = 6)
   // half-tile kinds in stream order: 0 = A(hm 0), 1 = W(hn 0), 2 = W(hn 1), 3 = A(hm 1)
   auto stage = [&](auto kind_c, int kt) {
     constexpr int KIND = decltype(kind_c)::value;
-    char* dst = smem + (kt & 1) * PP_BUF + KIND * PP_HALF + (wave * 16) * (BK * 2);
-    const char* src = (KIND == 0 || KIND == 3) ? (const char*)p.A : (const char*)p.W;
+    constexpr bool IS_A = KIND == 0 || KIND == 3;
+    char* dst = smem + (kt & 1) * PP_BUF + KIND * PP_HALF + (wave * 8) * (BK * 2);
+    const char* src = IS_A ? (const char*)p.A : (const char*)p.W;
     src += (size_t)kt * (BK * 2);
     const unsigned* off = KIND == 0 ? a_off[0] : KIND == 3 ? a_off[1] : KIND == 1 ? w_off[0] : w_off[1];
     glds16(src + off[0], dst);
-    glds16(src + off[1], dst + 8 * (BK * 2));
+    if (!IS_A || NPA == 16 || a_two) glds16(src + off[1], dst + 64 * (BK * 2));
   };
 
   const int sw = (lane >> 1) & 7;
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   const unsigned fo0 = frow + (((0 + (lane >> 4)) ^ sw) << 4);
   const unsigned fo1 = frow + (((4 + (lane >> 4)) ^ sw) << 4);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned aA = lds0 + (wm * 64) * (BK * 2);        // + buf * PP_BUF + {0 | 3 * PP_HALF} + fo{0,1}; m-tile: + 2048 each
+  const unsigned aA = lds0 + (wm * HR) * (BK * 2);        // + buf * PP_BUF + {0 | 3 * PP_HALF} + fo{0,1}; m-tile: + 2048 each
   const unsigned aW = lds0 + PP_HALF + (wn * 32) * (BK * 2);   // + buf * PP_BUF + {0 | PP_HALF}
 
   f32x4 acc[4][MT];   // [n-tile][m-tile] of the transposed product
@@ -591,61 +599,66 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  v4i FA[8], W0[4], W1[4];     // FA[2 * mt + kh], W[2 * nt2 + kh]
+  v4i FA[2 * MH], W0[4], W1[4];     // FA[2 * mt + kh], W[2 * nt2 + kh]
 #define V3D_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
-#define V3D_RDA8(b0, b1) { V3D_DSR(FA[0], b0, 0); V3D_DSR(FA[1], b1, 0); V3D_DSR(FA[2], b0, 2048); V3D_DSR(FA[3], b1, 2048); \
-                           V3D_DSR(FA[4], b0, 4096); V3D_DSR(FA[5], b1, 4096); V3D_DSR(FA[6], b0, 6144); V3D_DSR(FA[7], b1, 6144); }
+#define V3D_RDA(b0, b1) { V3D_DSR(FA[0], b0, 0); V3D_DSR(FA[1], b1, 0); V3D_DSR(FA[2], b0, 2048); V3D_DSR(FA[3], b1, 2048); \
+                          V3D_DSR(FA[4], b0, 4096); V3D_DSR(FA[5], b1, 4096);                                                 \
+                          if constexpr (MH == 4) { V3D_DSR(FA[6], b0, 6144); V3D_DSR(FA[7], b1, 6144); } }
 #define V3D_RDW4(f, b0, b1) { V3D_DSR(f[0], b0, 0); V3D_DSR(f[1], b1, 0); V3D_DSR(f[2], b0, 2048); V3D_DSR(f[3], b1, 2048); }
-#define V3D_LG0_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FA[4]), "+v"(FA[5]), "+v"(FA[6]), "+v"(FA[7]) : : "memory")
+#define V3D_LG0_A() { if constexpr (MH == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FA[4]), "+v"(FA[5]), "+v"(FA[6]), "+v"(FA[7]) : : "memory"); \
+                      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FA[4]), "+v"(FA[5]) : : "memory"); }
 #define V3D_LG0_W(f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
 #define V3D_PPMMA(HM, HN, WF)                                                                          \
   {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                     \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                   \
     _Pragma("unroll") for (int n2 = 0; n2 < 2; ++n2)                                                   \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                   \
-        acc[2 * (HN) + n2][4 * (HM) + mt] = M16::run(__builtin_bit_cast(frag, WF[2 * n2 + kh]), __builtin_bit_cast(frag, FA[2 * mt + kh]), \
-                                                     acc[2 * (HN) + n2][4 * (HM) + mt]);               \
+    _Pragma("unroll") for (int mt = 0; mt < MH; ++mt)                                                  \
+        acc[2 * (HN) + n2][MH * (HM) + mt] = M16::run(__builtin_bit_cast(frag, WF[2 * n2 + kh]), __builtin_bit_cast(frag, FA[2 * mt + kh]), \
+                                                      acc[2 * (HN) + n2][MH * (HM) + mt]);             \
     __builtin_amdgcn_s_setprio(0);                                                                     \
   }
-#define V3D_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  // counted wait: n0 for the waves that move two pieces of every half-tile, n1 for those with a single A piece (MT = 6, wm = 1)
+#define V3D_VM(n0, n1) { if (NPA == 16 || a_two) asm volatile("s_waitcnt vmcnt(" #n0 ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n1 ")" ::: "memory"); }
 #define V3D_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 
   const int nt = p.K / BK;       // >= 2 (the launcher sends shorter K to the v3 kernel)
-  // MODE 0: steady state; 1: second-last K-step (its fourth phase has nothing left to issue); 2: last K-step
+  // MODE 0: steady state; 1: second-last K-step (its fourth phase has nothing left to issue); 2: last K-step.
+  // After phase P's issue everything up to H(P + 2) must have landed: H(P+3..P+5) may stay in flight - kinds (A A W), (A W W),
+  // (W W A), (W A A) for P mod 4 = 0..3, i.e. 6 pieces, or 4 / 5 / 5 / 4 for a wave with single A pieces.
   auto kstep = [&](auto mode_c, int t) {
     constexpr int MODE = decltype(mode_c)::value;
     const unsigned bo = (unsigned)(t & 1) * PP_BUF;
     // phase 0: quadrant (hm 0, hn 0)
     { const unsigned w0 = aW + bo + fo0, w1 = aW + bo + fo1, a0 = aA + bo + fo0, a1 = aA + bo + fo1;
-      V3D_RDW4(W0, w0, w1); V3D_RDA8(a0, a1); }
-    if constexpr (MODE < 2) { stage(IntC<1>{}, t + 1); V3D_VM(6); } else { V3D_VM(2); }
+      V3D_RDW4(W0, w0, w1); V3D_RDA(a0, a1); }
+    if constexpr (MODE < 2) { stage(IntC<1>{}, t + 1); V3D_VM(6, 4); } else { V3D_VM(2, 1); }
     V3D_BAR(); V3D_LG0_W(W0); V3D_LG0_A();
     V3D_PPMMA(0, 0, W0);
     V3D_BAR();
     // phase 1: quadrant (hm 0, hn 1)
     { const unsigned w0 = aW + bo + PP_HALF + fo0, w1 = aW + bo + PP_HALF + fo1;
       V3D_RDW4(W1, w0, w1); }
-    if constexpr (MODE < 2) { stage(IntC<2>{}, t + 1); V3D_VM(6); } else { V3D_VM(0); }
+    if constexpr (MODE < 2) { stage(IntC<2>{}, t + 1); V3D_VM(6, 5); } else { V3D_VM(0, 0); }
     V3D_BAR(); V3D_LG0_W(W1);
     V3D_PPMMA(0, 1, W1);
     V3D_BAR();
     // phase 2: quadrant (hm 1, hn 1)
     { const unsigned a0 = aA + bo + 3 * PP_HALF + fo0, a1 = aA + bo + 3 * PP_HALF + fo1;
-      V3D_RDA8(a0, a1); }
-    if constexpr (MODE < 2) { stage(IntC<3>{}, t + 1); V3D_VM(6); }
+      V3D_RDA(a0, a1); }
+    if constexpr (MODE < 2) { stage(IntC<3>{}, t + 1); V3D_VM(6, 5); }
     V3D_BAR(); V3D_LG0_A();
     V3D_PPMMA(1, 1, W1);
     V3D_BAR();
     // phase 3: quadrant (hm 1, hn 0): no new fragments
-    if constexpr (MODE == 0) { stage(IntC<0>{}, t + 2); V3D_VM(6); } else if constexpr (MODE == 1) { V3D_VM(4); }
+    if constexpr (MODE == 0) { stage(IntC<0>{}, t + 2); V3D_VM(6, 4); } else if constexpr (MODE == 1) { V3D_VM(4, 3); }
     V3D_BAR();
     V3D_PPMMA(1, 0, W0);
     V3D_BAR();
   };
 
   stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0); stage(IntC<0>{}, 1);
-  V3D_VM(6);
+  V3D_VM(6, 4);                                 // H0, H1 landed; (W A A) in flight
   V3D_BAR();
   if (wm == 1) V3D_BAR();                      // the wm = 1 waves run one barrier behind
   {
@@ -656,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   }
   if (wm == 0) V3D_BAR();
 #undef V3D_DSR
-#undef V3D_RDA8
+#undef V3D_RDA
 #undef V3D_RDW4
 #undef V3D_LG0_A
 #undef V3D_LG0_W
@@ -870,13 +883,13 @@ static int gemm_pp_mode() {   // 1 (default) = ping-pong v4 for the 256 x 256 ti
   return e ? atoi(e) : 1;
 }
 
-template <typename T>
+template <typename T, int MT>
 static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
-  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_m = (p.M + MT * 32 - 1) / (MT * 32);
   p.tiles_n = p.N / B3N;
 #define V3D_GEMM4_CASE(E)                                                                                 \
   case E: {                                                                                               \
-    auto k = gemm256pp_kernel<T, E>;                                                                      \
+    auto k = gemm256pp_kernel<T, E, MT>;                                                                    \
     static bool attr_done = false;                                                                        \
     if (!attr_done) {                                                                                     \
       hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES); \
@@ -905,7 +918,7 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
   // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
   //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
   //   256 x 256 ping-pong (256 slots): fixed 9 (prologue DMA latency + epilogue), 1.26 per K-step
-  //   192 x 256 v3        (256 slots): fixed 2, 1.32 per K-step  (3/4 of the tile: wins when 256-row tiles quantise badly
+  //   192 x 256 ping-pong (256 slots): fixed 8, 1.0 per K-step   (3/4 of the tile: wins when 256-row tiles quantise badly
   //                                    against the 256 CUs, e.g. M = 6794, N = 3584: 378 tiles = 1.48 rounds vs 504 = 1.97)
   //   128 x 128           (512 slots): fixed 1, 0.98 per K-step  (many small tiles: small M, or N % 256 != 0)
   const int var = gemm_variant();
@@ -914,12 +927,12 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
     const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
     const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
     const double t256 = (double)((tiles256 + 255) / 256) * (pp ? 9.0 + 1.2625 * ks : 9.0 + 1.36 * ks);
-    const double t192 = (double)((tiles192 + 255) / 256) * (2.0 + 1.32 * ks);
+    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 8.0 + 1.0 * ks : 2.0 + 1.32 * ks);
     const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
-    if (var == 4) return launch_gemm256x256<T, 6>(p, epi, st);
-    if (var == 3) return pp ? launch_gemm256pp<T>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
-    if (t192 < t256 && t192 < t1) return launch_gemm256x256<T, 6>(p, epi, st);
-    if (t256 < t1) return pp ? launch_gemm256pp<T>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
+    if (var == 4) return pp ? launch_gemm256pp<T, 6>(p, epi, st) : launch_gemm256x256<T, 6>(p, epi, st);
+    if (var == 3) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
+    if (t192 < t256 && t192 < t1) return pp ? launch_gemm256pp<T, 6>(p, epi, st) : launch_gemm256x256<T, 6>(p, epi, st);
+    if (t256 < t1) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
   }
 #define V3D_GEMM_CASE(E)                                                                                  \
   case E: {                                                                                               \
