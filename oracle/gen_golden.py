@@ -518,7 +518,7 @@ def g_tiny_model():
     for k, v in dict(world_position_embedding_type="avg-discrete-sin3d", mm_spatial_pool_mode="bilinear", mm_spatial_pool_stride=2,
                      voxel_size=0.1, min_xyz_range=[-15, -15, -5], max_xyz_range=[15, 15, 5], mm_patch_merge_type="spatial_unpad",
                      mm_newline_position="grid", ground_head_type="infonce", ground_head_temperature=0.07,
-                     object_feature_type="patch14-pe", ground_token_ids=[318]).items():
+                     object_feature_type="patch14-pe", ground_token_ids=[318], coord_token_ids=[317]).items():
         setattr(cfg, k, v)
     torch.manual_seed(71)
     m = lq.LlavaQwenForCausalLM(cfg)
@@ -568,9 +568,12 @@ def g_tiny_model():
         gids = torch.cat([text[:5], torch.tensor([-200]), text[5:9], torch.tensor([318]), text[9:]])[None]      # one <ground> label
         glabels = torch.full_like(gids, -100)
         glabels[0, 10] = 318
+        cids = torch.cat([text[:5], torch.tensor([-200]), text[5:7], torch.tensor([317]), text[7:9], torch.tensor([317]), text[9:]])[None]   # two <coord> tokens
+        box_in = torch.tensor([[1.23, -2.5, 0.71]]).half().float()
         images = up8(img_lo, (2, 3))[None]
         wc = up8(wc_lo, (1, 2))[None]
-        out.update({f"{case}_img_lo": img_lo.numpy(), f"{case}_wc_lo": wc_lo.numpy(), f"{case}_boxes": boxes.numpy(),
+        out.update({f"{case}_cids": cids[0].numpy(), f"{case}_box_in": box_in.numpy(),
+                    f"{case}_img_lo": img_lo.numpy(), f"{case}_wc_lo": wc_lo.numpy(), f"{case}_boxes": boxes.numpy(),
                     f"{case}_ids": ids[0].numpy(), f"{case}_gids": gids[0].numpy(), f"{case}_glabels": glabels[0].numpy()})
         for kind in kinds:
             dt = DT[kind]
@@ -578,6 +581,7 @@ def g_tiny_model():
             for mod_name, b in inv.items():                       # from_pretrained(torch_dtype=...) keeps inv_freq f32 (see g_llm)
                 mod = m.get_submodule(mod_name.rsplit(".", 1)[0])
                 mod.inv_freq = b.float().clone()
+            raw = (lambda t: t2n(t)) if dt == torch.bfloat16 else (lambda t: t.numpy())
             vd = {"world_coords": wc.to(dt), "box_input": [], "objects": boxes.to(dt)[None]}
             _, _, _, _, emb, _, _, _ = m.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, images.to(dt), ["video"], None, vd)
             logits = m(input_ids=ids, images=images.to(dt), modalities=["video"], video_dict=vd, use_cache=False).logits
@@ -592,7 +596,11 @@ def g_tiny_model():
                 steps.append(lg)
             _, scores = m(input_ids=gids, images=images.to(dt), modalities=["video"], video_dict=vd, labels=glabels,
                           use_object_proposals=True, use_cache=False)
-            raw = (lambda t: t2n(t)) if dt == torch.bfloat16 else (lambda t: t.numpy())
+            if case == "F2":     # Scan2Cap-style prompt: a <coord> token whose row gets the PE of the (discretised) input box centre
+                vdc = dict(vd, box_input=box_in.to(dt))                      # llava_arch.py:416-417, 697-700; model_scan2cap.py:137-167
+                _, _, _, _, emb_c, _, _, _ = m.prepare_inputs_labels_for_multimodal(cids, None, None, None, None, images.to(dt), ["video"], None, vdc)
+                out[f"{case}_coord_rows_{kind}"] = raw(emb_c[0, [8 + Fr * 210 - 1, 11 + Fr * 210 - 1]])
+                out[f"{case}_coord_logits_{kind}"] = m(input_ids=cids, images=images.to(dt), modalities=["video"], video_dict=vdc, use_cache=False).logits[0, -1].numpy()
             out[f"{case}_embeds_{kind}"] = raw(emb[0])
             out[f"{case}_logits_{kind}"] = logits[0, -1].numpy()          # lm_head(...).float(): f32 in every dtype
             out[f"{case}_tokens_{kind}"] = np.array(toks, np.int64)

@@ -29,14 +29,24 @@ def visual_sequence(sd, world_coords, feats, dtype):
     return ids, torch.from_numpy(seq).to(dtype)
 
 
-def inputs_embeds(sd, input_ids, vis, dtype):
-    """llava_arch.py:684-745 for one sample with one <image> token."""
+def inputs_embeds(sd, input_ids, vis, dtype, box_input=None, coord_token_id=None):
+    """llava_arch.py:684-745 for one sample with one <image> token.  box_input [1,3] + coord_token_id: the 3-D PE of the
+    discretised box centre is added to the embedding of every <coord> text token (llava_arch.py:416-417, 697-700)."""
     ids = input_ids.tolist()
     at = ids.index(IMAGE_TOKEN_INDEX)
     emb = sd["model.embed_tokens.weight"].to(dtype)
-    pre = emb[input_ids[:at]]
-    post = emb[input_ids[at + 1:]]
-    return torch.cat([pre, vis, post], 0)
+    text = torch.cat([input_ids[:at], input_ids[at + 1:]])
+    e = emb[text]
+    if box_input is not None and coord_token_id is not None and bool((text == coord_token_id).any()):
+        kind = KIND[dtype]
+        C = emb.shape[1]
+        centre = torch.from_numpy(O.discrete_coords(_np(box_input.to(dtype).reshape(-1, 3)[:1]), kind)).to(dtype)
+        d = torch.arange(C // 3, dtype=torch.float32)
+        dim_t = (10000 ** (2 * (d // 2) / (C // 3))).numpy()
+        pe = torch.from_numpy(O.sin3d_pe(_np(centre)[None], C, kind, dim_t=dim_t)[0]).to(dtype)        # [1, C]
+        e = e.clone()
+        e[text == coord_token_id] += pe[0]
+    return torch.cat([e[:at], vis, e[at:]], 0)
 
 
 def scene_forward(sd, cfg, input_ids, images, world_coords, dtype, max_new_tokens=4):

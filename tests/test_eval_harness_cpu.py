@@ -1,0 +1,84 @@
+"""Host side of the ScanQA eval runner (v3d/eval_scanqa.py) against the I/O contract of llava/eval/model_scanqa.py:
+prompt-id structure of preprocess_qwen (:29-80), record schema (:196-204), answer clean-up (:188-192), stride sharding
+(:245) + the single gather that replaces Ray + the file lock - the last through a world-size-2 gloo run of `evaluate`
+(the same code path the GPU ranks take with RCCL)."""
+import json
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import tiny_model_fixture as TM
+from v3d import eval_scanqa as E
+
+
+def _questions(n, scenes=3):
+    return [{"id": f"q{i}", "video": f"scannet/scene{i * scenes // n:04d}_00",
+             "conversations": [{"from": "human", "value": f"<image>\nt{i + 1} t{i + 2} t{i + 3}"}, {"from": "gpt", "value": f"t{i + 10}"}],
+             "metadata": {"dataset": "scanqa", "question_type": "what", "answers": [f"t{i + 10}"]}} for i in range(n)]
+
+
+def test_chatml_ids_structure(tmp_path):
+    from transformers import AutoTokenizer
+    tok = AutoTokenizer.from_pretrained(TM.write_checkpoint(str(tmp_path / "ckpt"), TM.load()))
+    IM_S, IM_E, NL, SYS, USER, ASSIST = 309, 310, 303, 300, 301, 302
+    ids = E.build_prompt_ids(_questions(1)[0], tok)[0].tolist()
+    system = [IM_S, SYS, NL, 304, 305, 306, 307, 308, IM_E, NL]                       # <|im_start|>system\nYou are a helpful assistant.<|im_end|>\n
+    user = [IM_S, USER, NL, E.IMAGE_TOKEN_INDEX, NL, NL, 1, 2, 3, IM_E, NL]           # the value's own "\n" follows the placeholder's
+    assert ids == system + user + [IM_S, ASSIST, NL]                                   # open assistant turn = the generation prompt
+    assert ids.count(E.IMAGE_TOKEN_INDEX) == 1
+    # a closed assistant turn and a leading non-human turn (dropped, model_scanqa.py:43-44)
+    full = E.chatml_ids([{"from": "gpt", "value": "t9"}, {"from": "human", "value": "t4"}, {"from": "gpt", "value": "t5 t6"}], tok)[0].tolist()
+    assert full == system + [IM_S, USER, NL, 4, IM_E, NL] + [IM_S, ASSIST, NL, 5, 6, IM_E, NL]
+
+
+def test_record_schema_and_answer_cleanup():
+    line = _questions(1)[0]
+    rec = E.make_record(line, "t7", "llava_qwen_tiny")
+    assert list(rec) == ["dataset", "sample_id", "prompt", "pred_response", "gt_response", "model_id", "question_type"]
+    assert rec["prompt"] == E.EXTRA_PROMPT + line["conversations"][0]["value"] and rec["gt_response"] == "t10" and rec["sample_id"] == "q0"
+    assert E.clean_answer("  the chair <|im_end|>\n") == "the chair"
+    assert E.clean_answer("the chair") == "the chair"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    qs = _questions(11)
+
+    def answer_fn(lines):                      # stands in for the model: what matters here is who answers what, and the order
+        return [E.make_record(l, f"rank{rank}:{l['id']}", "stub") for l in lines]
+
+    recs = E.evaluate(qs, answer_fn, rank, world, torch.device("cpu"))
+    if rank == 0:
+        with open(out_path, "w") as f:
+            for r in recs:
+                f.write(json.dumps(r) + "\n")
+    else:
+        assert recs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_shards_by_stride_and_collates_in_question_order(tmp_path):
+    ctx = mp.get_context("spawn")
+    port, out = _free_port(), str(tmp_path / "answers.jsonl")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    recs = [json.loads(l) for l in open(out)]
+    assert [r["sample_id"] for r in recs] == [f"q{i}" for i in range(11)]
+    assert [r["pred_response"] for r in recs] == [f"rank{i % 2}:q{i}" for i in range(11)]        # questions[rank::world]

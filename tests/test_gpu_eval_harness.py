@@ -1,0 +1,92 @@
+"""The ScanQA eval runner end to end on a tiny synthetic dataset the test writes itself in the dataset's own on-disk form
+(EmbodiedScan-style scene index pickles, 16-bit depth PNGs, pose txt, JPEG frames, box JSONs, a question file) with the tiny
+random checkpoint of tests/golden/tiny_model.npz: loader -> VideoProcessor -> ChatML ids -> generate -> record -> answer file
+(model_scanqa.py:83-206), and the scene-reuse mode (one prefill per scene, questions answered in batches) giving the same
+records.  Every answer is also checked against Engine.generate called directly on the same inputs."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import tiny_model_fixture as TM
+from scene_files import write_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(root):
+    rng = np.random.default_rng(7)
+    scenes = {}
+    data_list = []
+    for s in range(2):
+        sid = f"scannet/scene{s:04d}_00"
+        V, H, W = 5, 48, 64
+        depth = rng.integers(500, 4000, size=(V, H, W)).astype(np.uint16)
+        poses = np.tile(np.eye(4), (V, 1, 1))
+        for v in range(V):
+            a = 0.5 * v + s
+            poses[v, :3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+            poses[v, :3, 3] = rng.normal(size=3)
+        rgb = rng.integers(0, 256, size=(V, H, W, 3), dtype=np.uint8)
+        files = write_frames(os.path.join(root, "posed_images", f"scene{s:04d}_00"), depth, poses, rgb=rgb)
+        item = {"sample_idx": sid, "axis_align_matrix": np.eye(4).tolist(),
+                "depth_cam2img": [[57.8, 0, 31.5, 0], [0, 57.8, 23.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                "images": [{"img_path": os.path.relpath(f, root)} for f in files]}
+        data_list.append(item)
+        scenes[sid] = item
+    os.makedirs(os.path.join(root, "embodiedscan"), exist_ok=True)
+    os.makedirs(os.path.join(root, "metadata"), exist_ok=True)
+    for split in ("train", "val", "test"):
+        with open(os.path.join(root, "embodiedscan", f"embodiedscan_infos_{split}.pkl"), "wb") as f:
+            pickle.dump({"data_list": data_list if split == "val" else []}, f)
+    for name in ("scannet_train_gt_box.json", "scannet_val_pred_box.json"):
+        with open(os.path.join(root, "metadata", name), "w") as f:
+            json.dump({sid: [[0, 0, 0, 1, 1, 1]] for sid in scenes}, f)
+    qs = []
+    for i in range(7):                                 # 4 questions on scene 0, 3 on scene 1, of different lengths
+        words = " ".join(f"t{(11 * i + k) % 290 + 1}" for k in range(3 + 2 * (i % 3)))
+        qs.append({"id": f"q{i}", "video": f"scannet/scene{0 if i < 4 else 1:04d}_00",
+                   "conversations": [{"from": "human", "value": "<image>\n" + words}, {"from": "gpt", "value": "t42"}],
+                   "metadata": {"dataset": "scanqa", "question_type": "what", "answers": ["t42"]}})
+    with open(os.path.join(root, "questions.json"), "w") as f:
+        json.dump(qs, f)
+    return qs
+
+
+def test_eval_runner_end_to_end(tmp_path):
+    from v3d import eval_scanqa as E
+    root = str(tmp_path)
+    qs = _dataset(root)
+    ckpt = TM.write_checkpoint(os.path.join(root, "llava_qwen_tiny"), TM.load())
+    argv = ["--model-path", ckpt, "--video-folder", root, "--embodiedscan-folder", os.path.join(root, "embodiedscan"),
+            "--metadata-folder", os.path.join(root, "metadata"), "--question-file", os.path.join(root, "questions.json"),
+            "--max_frame_num", "4", "--max-new-tokens", "5"]
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl")]) == 0
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "reuse.jsonl"), "--reuse-scenes"]) == 0
+    plain = [json.loads(l) for l in open(os.path.join(root, "out", "plain.jsonl"))]
+    reuse = [json.loads(l) for l in open(os.path.join(root, "out", "reuse.jsonl"))]
+    for recs in (plain, reuse):
+        assert [r["sample_id"] for r in recs] == [q["id"] for q in qs]
+        assert all(list(r) == ["dataset", "sample_id", "prompt", "pred_response", "gt_response", "model_id", "question_type"] for r in recs)
+        assert all(r["model_id"] == "llava_qwen_tiny" and r["gt_response"] == "t42" and r["prompt"].startswith(E.EXTRA_PROMPT) for r in recs)
+        assert all(len(r["pred_response"].split()) <= 5 and "<|im_end|>" not in r["pred_response"] for r in recs)
+    # the plain path = model.generate on the same inputs (checked directly), the reuse path = the same answers unless a
+    # near-tie flips a token (one-row decode linears sum in another f32 order): most must agree
+    tokenizer, model, image_processor, name = E.load_model(ckpt)
+    from llava.video_utils import VideoProcessor
+    vp = VideoProcessor(video_folder=root, annotation_dir=os.path.join(root, "embodiedscan"), metadata_dir=os.path.join(root, "metadata"))
+    for q, r in zip(qs, plain):
+        ids = E.build_prompt_ids(q, tokenizer)
+        images, vd = E._video_inputs(vp, image_processor, q["video"], model, 4)
+        assert tuple(images.shape) == (1, 4, 3, 384, 384) and tuple(vd["world_coords"].shape) == (1, 4, 384, 384, 3)
+        toks = model.engine.generate(ids[0], images[0], vd["world_coords"][0], max_new_tokens=5, eos_token_id=model._eos())
+        assert E.clean_answer(tokenizer.batch_decode(toks.view(1, -1), skip_special_tokens=True)[0]) == r["pred_response"]
+    same = sum(a["pred_response"] == b["pred_response"] for a, b in zip(plain, reuse))
+    assert same >= len(qs) - 2, (plain, reuse)
+    # an existing answer file is never overwritten (model_scanqa.py:238-240)
+    before = open(os.path.join(root, "out", "plain.jsonl")).read()
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl")]) == 0
+    assert open(os.path.join(root, "out", "plain.jsonl")).read() == before

@@ -8,6 +8,7 @@ per-layer shape).  The CPU oracle cannot run these sizes in test time, so the ch
   * causality: changing the LAST prompt token leaves every K/V cache row before it bit-identical;
   * the e4m3 path (configs[3]) stays within its re-stated tolerance of the bf16 path at full size (noise grows ~sqrt(#GEMMs)).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -177,3 +178,36 @@ def test_engine_capacity_errors(full):
     long = torch.cat([full["ids"], torch.zeros(8192 - 6794 + 1, dtype=torch.int64)])
     with pytest.raises(V3DError, match="exceeds engine capacity"):
         eng.build_inputs_embeds(long, feats, vox)
+
+
+def test_object_patch_masks_50_proposals_vs_oracle():
+    """K19 at the proposal count of configs[2] (50 boxes, extract_pred_box.py:30) on 2 full-size frames, f16 (the eval dtype):
+    masks bit-exact against the oracle's restatement of llava_arch.py:351-376 (itself pinned to the reference's own lines by
+    tests/golden/objects.npz), masked-mean features + box-centre PE within 16-bit rounding of the oracle."""
+    from oracle import llm_oracle as L
+    from oracle import v3d_oracle as O
+    from v3d import ops
+    dt = torch.float16
+    g = torch.Generator().manual_seed(91)
+    Fr, C, n = 2, 3584, 50
+    # piecewise-smooth coordinates (8 x 8 pixel blocks share a point) so that boxes of 0.5 - 2.5 m select whole patches
+    coords = (torch.rand(Fr, 48, 1, 48, 1, 3, generator=g) - 0.5).expand(Fr, 48, 8, 48, 8, 3).reshape(Fr, 384, 384, 3) * torch.tensor([9.0, 9.0, 3.0])
+    coords = (coords + 0.02 * torch.randn(Fr, 384, 384, 3, generator=g)).to(dt)
+    boxes = torch.cat([(torch.rand(n, 3, generator=g) - 0.5) * torch.tensor([8.0, 8.0, 2.5]), torch.rand(n, 3, generator=g) * 2.0 + 0.5], 1).to(dt)
+    boxes[7] = torch.tensor([30.0, 30.0, 30.0, 0.2, 0.2, 0.2]).to(dt)                 # selects nothing
+    feats = torch.randn(Fr, 729, C, generator=g).to(dt)
+    want = L.object_patch_mask(coords, boxes)
+    mask = ops.object_patch_mask(coords.cuda(), boxes.cuda())
+    assert tuple(mask.shape) == (n, Fr, 27, 27)
+    assert np.array_equal(mask.cpu().numpy().astype(bool), want.numpy())
+    assert 5 < int(want.any(dim=(1, 2, 3)).sum()) <= n and not bool(want[7].any())
+    centres = ops.discrete_coords(boxes[:, :3].contiguous().cuda())
+    assert np.array_equal(centres.float().cpu().numpy(), O.discrete_coords(boxes[:, :3].float().numpy(), "f16"))
+    d = torch.arange(C // 3, dtype=torch.float32)
+    dim_t = 10000 ** (2 * (d // 2) / (C // 3))
+    pe = ops.sin3d_pe(centres[None], C, dim_t=dim_t)[0]
+    got = ops.masked_mean(feats.cuda().view(-1, C), mask.view(n, -1), add=pe)
+    pe_ref = torch.from_numpy(O.sin3d_pe(centres.float().cpu().numpy()[None], C, "f16", dim_t=dim_t.numpy())[0]).to(dt)
+    ref = L.object_features(feats, want, pe_ref)
+    err = (got.float().cpu() - ref.float()).abs()
+    assert bool((err <= 2.0 ** -10 * (ref.float().abs() + 1.0) + 2e-3).all()), err.max()

@@ -65,3 +65,21 @@ def test_engine_grounding_scores_match_reference_model(g, kind, tol):
     got = eng.ground_scores(inp["gids"], gi, inp["images"].cuda(), inp["world_coords"].cuda(), inp["boxes"])
     assert got.shape == (6,)
     assert float((got.float().cpu() - want["scores"]).abs().max()) < tol         # cosine scores: absolute tolerance
+
+
+@pytest.mark.parametrize("kind,tol", [("bf16", 2e-2), ("f16", 3e-3)])
+def test_engine_coord_token_rows_match_reference_model(g, kind, tol):
+    """Scan2Cap prompt: <coord> token rows = embedding + PE(discretised box_input centre) (llava_arch.py:416-417, 697-700)."""
+    dt = TM.DT[kind]
+    inp = TM.case_inputs(g, "F2")
+    cids, box = torch.from_numpy(g["F2_cids"]), torch.from_numpy(g["F2_box_in"])
+    eng = _engine(g, dt, 2)
+    feats = eng.encode_images(inp["images"].cuda())
+    vox = eng.voxel_ids(inp["world_coords"].to(dt).cuda())
+    x = eng.build_inputs_embeds(cids, feats, vox, box_input=box, coord_token_id=317)
+    want = TM.bits_to_f32(g["F2_coord_rows_bf16"]) if kind == "bf16" else torch.from_numpy(g[f"F2_coord_rows_{kind}"]).float()
+    got = x[[8 + 420 - 1, 11 + 420 - 1]].float().cpu()
+    ulp = 2.0 ** (-7 if kind == "bf16" else -10)
+    assert bool(((got - want).abs() <= ulp * (want.abs() + 1.0)).all())          # table PE within 1 ulp16, one rounded add
+    logits = eng.llm_forward(x, 0)
+    assert rel_err(logits, torch.from_numpy(g[f"F2_coord_logits_{kind}"])) < 3 * tol

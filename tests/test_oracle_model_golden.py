@@ -60,3 +60,25 @@ def test_scene_ground_matches_reference_model(g, kind):
     tol = dict(f32=1e-4, bf16=4e-2, f16=5e-3)[kind]           # cosine scores in [-1, 1]: absolute tolerance
     assert float((got["scores"].float() - want["scores"]).abs().max()) < tol
     assert not bool(got["masks"][4].any())                       # the far-away box selects no patch
+
+
+@pytest.mark.parametrize("kind", ["f32", "bf16", "f16"])
+def test_coord_token_rows_match_reference_model(g, kind):
+    """Scan2Cap-style prompt (model_scan2cap.py:137-167): the rows of the two <coord> tokens carry embed + PE(discretised box
+    centre) (llava_arch.py:416-417, 697-700); pinned to the reference's prepare_inputs_labels_for_multimodal."""
+    sd, inp = TM.state_dict(g), TM.case_inputs(g, "F2")
+    dt = TM.DT[kind]
+    cids, box = torch.from_numpy(g["F2_cids"]), torch.from_numpy(g["F2_box_in"])
+    w = {k: v.to(dt) for k, v in sd.items()}
+    from oracle import llm_oracle as L
+    feats = L.projector(L.siglip_tower(inp["images"].to(dt), w, 2, 2), w)
+    _, vis = PO.visual_sequence(w, inp["world_coords"].to(dt), feats, dt)
+    x = PO.inputs_embeds(w, cids, vis, dt, box_input=box, coord_token_id=317)
+    want = TM.bits_to_f32(g["F2_coord_rows_bf16"]) if kind == "bf16" else torch.from_numpy(g[f"F2_coord_rows_{kind}"]).float()
+    got = x[[8 + 420 - 1, 11 + 420 - 1]].float()
+    if kind == "f32":
+        assert torch.allclose(got, want, rtol=0, atol=5e-7)         # numpy's and torch's f32 sin / cos differ in the last bit
+    else:
+        assert torch.equal(got, want)                               # gather + PE rounded to 16 bits + one rounded add: bit-exact
+    plain = PO.inputs_embeds(w, cids, vis, dt)
+    assert not torch.equal(plain[8 + 420 - 1].float(), want[0])     # the PE really was added

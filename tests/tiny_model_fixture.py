@@ -49,7 +49,7 @@ def expected(g, case, kind):
 HF_CONFIG = dict(
     architectures=["LlavaQwenForCausalLM"], model_type="llava_qwen", vocab_size=320, hidden_size=256, intermediate_size=384,
     num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, max_position_embeddings=4096, rms_norm_eps=1e-6,
-    rope_theta=1000000.0, use_sliding_window=False, attention_dropout=0.0, tie_word_embeddings=False, eos_token_id=319,
+    rope_theta=1000000.0, use_sliding_window=False, attention_dropout=0.0, tie_word_embeddings=False, eos_token_id=310,
     mm_vision_tower="google/siglip-so400m-patch14-384", mm_projector_type="mlp2x_gelu", mm_hidden_size=144,
     mm_use_im_start_end=False, mm_use_im_patch_token=False, mm_patch_merge_type="spatial_unpad", mm_newline_position="grid",
     mm_spatial_pool_mode="bilinear", mm_spatial_pool_stride=2, world_position_embedding_type="avg-discrete-sin3d",
@@ -79,8 +79,12 @@ def write_checkpoint(path, g, shards=2):
         json.dump({"metadata": {}, "weight_map": weight_map}, f)
     from tokenizers import Tokenizer, models, pre_tokenizers
     from transformers import PreTrainedTokenizerFast
-    vocab = {f"t{i}": i for i in range(320)}
+    # 320 ids: words t0..t299, the ChatML words and specials the eval harness needs, the rest of the table as t3xx
+    names = {300: "system", 301: "user", 302: "assistant", 303: "\n", 304: "You", 305: "are", 306: "a", 307: "helpful",
+             308: "assistant.", 309: "<|im_start|>", 310: "<|im_end|>"}
+    vocab = {names.get(i, f"t{i}"): i for i in range(320)}
     tok = Tokenizer(models.WordLevel(vocab, unk_token="t0"))
-    tok.pre_tokenizer = pre_tokenizers.Whitespace()
-    PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="t319", pad_token="t0", unk_token="t0").save_pretrained(path)
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split("\n", "isolated"), pre_tokenizers.Split(" ", "removed")])
+    PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="t0", unk_token="t0",
+                            additional_special_tokens=["<|im_start|>", "<|im_end|>"]).save_pretrained(path)
     return path

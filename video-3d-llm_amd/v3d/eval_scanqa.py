@@ -1,0 +1,224 @@
+"""ScanQA evaluation runner with the I/O contract of the reference's driver (llava/eval/model_scanqa.py), one process per
+GPU instead of Ray actors + a file lock:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m v3d.eval_scanqa \\
+        --model-path <ckpt> --video-folder data --embodiedscan-folder data/embodiedscan \\
+        --question-file data/processed/scanqa_val_llava_style.json --answer-file out/scanqa.jsonl --max_frame_num 32
+
+* prompt ids: `chatml_ids` restates preprocess_qwen (model_scanqa.py:29-80): ChatML turns with IMAGE_TOKEN_INDEX (-200) where the
+  "<image>" placeholder stood (the tokenizer-dependent ids themselves are parity-unpinned: no Qwen2 tokenizer ships with the
+  reference; the STRUCTURE is what tests/test_gpu_eval_harness.py checks);
+* sharding: `questions[rank::world]` (model_scanqa.py:245);
+* per question: VideoProcessor.process_3d_video -> merge_video_dict -> cast to the model dtype on the device (:156-165) ->
+  model.generate(..., modalities="video", max_new_tokens=512, use_cache=True, video_dict=...) (:173-185) -> decode, strip the
+  stop string (:188-192) -> the record {dataset, sample_id, prompt, pred_response, gt_response, model_id, question_type} (:196-204);
+* collation: ONE variable-length gather of the records to rank 0 (v3d.distributed.gather_records over RCCL), which writes
+  the JSONL answer file in the original question order (the reference appends under fasteners.InterProcessLock in arrival order).
+`--reuse-scenes` (not in the reference): consecutive questions of one scene share the scene's prefill
+(Engine.prefill_scene) and are answered in batches of up to 16 (Engine.answer_group); records and order are unchanged.
+"""
+import argparse
+import json
+import os
+import re
+import time
+
+import torch
+
+from . import distributed as D
+from .token_ids import IMAGE_TOKEN_INDEX
+
+EXTRA_PROMPT = ("The video captures 3D spatial information of a scene. Please focus on the spatial relationships in the video and "
+                "answer the following questions.\n")
+STOP_STR = "<|im_end|>"          # conv_templates["qwen_1_5"].sep (llava/conversation.py:443-452): the ChatML turn terminator
+
+
+def chatml_ids(turns, tokenizer, has_image=True, system_message="You are a helpful assistant."):
+    """Ids of a ChatML conversation as preprocess_qwen builds them (model_scanqa.py:29-80): <|im_start|>system\\n{system}<|im_end|>\\n,
+    then per turn <|im_start|>{user|assistant}\\n{text}<|im_end|>\\n; an "<image>" placeholder in a user turn becomes
+    IMAGE_TOKEN_INDEX followed by a newline (:53-59); a turn whose value is None is left open (the generation prompt, :62-63).
+    turns: [{"from": "human" | "gpt", "value": str | None}, ...].  Returns LongTensor [1, n]."""
+    tok = lambda s: tokenizer(s).input_ids       # noqa: E731
+    ids_attr = getattr(tokenizer, "additional_special_tokens_ids", None)     # :32; newer transformers dropped the attribute
+    im_start, im_end = (ids_attr[:2] if ids_attr else tokenizer.convert_tokens_to_ids(["<|im_start|>", "<|im_end|>"]))
+    nl = tok("\n")
+    role_ids = {"human": tok("<|im_start|>user"), "gpt": tok("<|im_start|>assistant")}
+    if turns and turns[0]["from"] != "human":
+        turns = turns[1:]
+    ids = [im_start] + tok("system") + nl + tok(system_message) + [im_end] + nl
+    for turn in turns:
+        head = role_ids[turn["from"]] + nl
+        text = turn["value"]
+        if text is None:
+            ids += head
+        elif has_image and "<image>" in text:
+            n_img = len(re.findall("<image>", text))
+            parts = text.split("<image>")
+            cur = list(head)
+            for i, part in enumerate(parts):
+                cur += tok(part)
+                if i < len(parts) - 1:
+                    cur += [IMAGE_TOKEN_INDEX] + nl
+            cur += [im_end] + nl
+            assert cur.count(IMAGE_TOKEN_INDEX) == n_img
+            ids += cur
+        else:
+            ids += head + tok(text) + [im_end] + nl
+    return torch.tensor([ids], dtype=torch.long)
+
+
+def build_prompt_ids(line, tokenizer, mm_use_im_start_end=False):
+    """model_scanqa.py:139-154: "<image>\\n" is put in front of the question of the first turn; the ids come from the record's own
+    first conversation turn plus an open assistant turn."""
+    return chatml_ids([line["conversations"][0], {"from": "gpt", "value": None}], tokenizer, has_image=True)
+
+
+def make_record(line, pred_text, model_name, extra_prompt=EXTRA_PROMPT):
+    """The JSONL record of model_scanqa.py:196-204."""
+    return {"dataset": line["metadata"]["dataset"], "sample_id": line["id"], "prompt": extra_prompt + line["conversations"][0]["value"],
+            "pred_response": pred_text, "gt_response": line["conversations"][1]["value"], "model_id": model_name,
+            "question_type": line["metadata"]["question_type"]}
+
+
+def clean_answer(text, stop_str=STOP_STR):
+    """model_scanqa.py:188-192."""
+    text = text.strip()
+    if text.endswith(stop_str):
+        text = text[: -len(stop_str)]
+    return text.strip()
+
+
+def _video_inputs(video_processor, image_processor, video_id, model, max_frame_num, force_sample=True):
+    from llava.video_utils import merge_video_dict
+    vd = merge_video_dict([video_processor.process_3d_video(video_id, image_processor, force_sample=force_sample, frames_upbound=max_frame_num)])
+    images = vd.pop("images").to(device=model.device, dtype=model.dtype)                      # :163
+    for k in vd:
+        vd[k] = vd[k].to(device=model.device, dtype=model.dtype)                              # :164-165
+    return images, vd
+
+
+def evaluate(questions, answer_fn, rank, world, device):
+    """Shard, answer, collate.  answer_fn(list of question records of ONE rank) -> list of output records in the same order.
+    Returns on rank 0 every record in the original question order, on the other ranks None."""
+    mine = D.shard(questions, rank, world)
+    recs = answer_fn(mine)
+    if len(recs) != len(mine):
+        raise RuntimeError("answer_fn must return one record per question")
+    if world == 1:
+        return recs
+    return D.gather_records(recs, device)
+
+
+def model_answer_fn(model, tokenizer, image_processor, video_processor, model_name, max_frame_num=32, max_new_tokens=512,
+                    reuse_scenes=False, times=None):
+    """The per-rank loop of model_scanqa.py:130-206 around `model` (the loader-produced LlavaQwenForCausalLM)."""
+
+    def decode(ids):
+        return clean_answer(tokenizer.batch_decode(ids.view(1, -1), skip_special_tokens=True)[0])
+
+    def one_by_one(lines):
+        out = []
+        for line in lines:
+            ids = build_prompt_ids(line, tokenizer).to(model.device)
+            if int((ids == IMAGE_TOKEN_INDEX).sum()) != 1:
+                raise ValueError("exactly one <image> placeholder per prompt (model_scanqa.py:61)")
+            images, vd = _video_inputs(video_processor, image_processor, line["video"], model, max_frame_num)
+            t0 = time.time()
+            with torch.inference_mode():
+                toks = model.generate(ids, images=images, modalities="video", do_sample=False, temperature=0.0, top_p=None, num_beams=1,
+                                      max_new_tokens=max_new_tokens, use_cache=True, video_dict=vd)
+            if times is not None:
+                torch.cuda.synchronize()
+                times.append(time.time() - t0)
+            out.append(make_record(line, decode(toks[0]), model_name))
+        return out
+
+    def scene_batches(lines):
+        """Consecutive questions of one scene: ONE scene prefill, answers in batches of up to 16 (Engine.answer_group)."""
+        eng, out, i = model.engine, [], 0
+        eos = model._eos()
+        while i < len(lines):
+            j = i
+            while j < len(lines) and lines[j]["video"] == lines[i]["video"]:
+                j += 1
+            ids = [build_prompt_ids(l, tokenizer)[0] for l in lines[i:j]]
+            at = int((ids[0] == IMAGE_TOKEN_INDEX).nonzero()[0])
+            prefix = ids[0][: at + 1]
+            if any(not torch.equal(x[: at + 1], prefix) for x in ids):
+                raise ValueError("questions of one scene must share the prompt prefix up to <image>")
+            images, vd = _video_inputs(video_processor, image_processor, lines[i]["video"], model, max_frame_num)
+            with torch.inference_mode():
+                P = eng.prefill_scene(prefix, images[0], vd["world_coords"][0])
+                for b in range(i, j, 16):
+                    qs = [x[at + 1:] for x in ids[b - i: min(j, b + 16) - i]]
+                    room = eng.cfg.llm.max_pos - P - max(len(q) for q in qs) + 1
+                    answers = eng.answer_group(qs, max_new_tokens=min(max_new_tokens, room), eos_token_id=eos)
+                    out += [make_record(l, decode(a), model_name) for l, a in zip(lines[b: b + len(qs)], answers)]
+            i = j
+        return out
+
+    return scene_batches if reuse_scenes else one_by_one
+
+
+def load_model(model_path, overwrite_cfg=False):
+    """load_pretrained_model (llava/model/builder.py) - the reference's own loader when its checkout is importable behind the
+    overlay, else the same call sequence from v3d.loader."""
+    from llava.mm_utils import get_model_name_from_path
+    name = get_model_name_from_path(model_path)
+    overwrite = {"tie_word_embeddings": False, "use_cache": True, "vocab_size": 151649} if overwrite_cfg else {}     # model_scanqa.py:94-99
+    try:
+        from llava.model.builder import load_pretrained_model
+    except ImportError:
+        from .loader import load_pretrained_model
+    tokenizer, model, image_processor, _ = load_pretrained_model(model_path, None, name, overwrite_config=overwrite)
+    return tokenizer, model, image_processor, name
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--model-path", required=True)
+    ap.add_argument("--video-folder", default="data")
+    ap.add_argument("--embodiedscan-folder", default="data/embodiedscan")
+    ap.add_argument("--metadata-folder", default="data/metadata")
+    ap.add_argument("--question-file", required=True)
+    ap.add_argument("--answer-file", default="answer.jsonl")
+    ap.add_argument("--test_size", type=int, default=10000000)
+    ap.add_argument("--max_frame_num", type=int, default=32)
+    ap.add_argument("--max-new-tokens", type=int, default=512)
+    ap.add_argument("--frame_sampling_strategy", default="uniform")
+    ap.add_argument("--overwrite_cfg", action="store_true")
+    ap.add_argument("--reuse-scenes", action="store_true", help="share one scene prefill between consecutive questions of a scene")
+    a = ap.parse_args(argv)
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    with open(os.path.expanduser(a.question_file)) as f:
+        questions = json.load(f)[: a.test_size]
+    if os.path.exists(a.answer_file):                                                         # model_scanqa.py:238-240
+        print(f"The {a.answer_file} already exists!!!")
+        return 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from llava.video_utils import VideoProcessor
+    tokenizer, model, image_processor, name = load_model(os.path.expanduser(a.model_path), a.overwrite_cfg)
+    vp = VideoProcessor(video_folder=a.video_folder, annotation_dir=a.embodiedscan_folder, frame_sampling_strategy=a.frame_sampling_strategy,
+                        metadata_dir=a.metadata_folder)
+    times = []
+    fn = model_answer_fn(model, tokenizer, image_processor, vp, name, a.max_frame_num, a.max_new_tokens, a.reuse_scenes, times)
+    records = evaluate(questions, fn, rank, world, dev)
+    if rank == 0:
+        os.makedirs(os.path.dirname(os.path.abspath(a.answer_file)), exist_ok=True)
+        with open(a.answer_file, "w") as f:
+            for r in records:
+                f.write(json.dumps(r) + "\n")
+        if times:
+            print(f"time: {sum(times) / len(times)}")                                        # model_scanqa.py:252
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

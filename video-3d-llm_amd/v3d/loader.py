@@ -98,3 +98,32 @@ def drop_deleted_tower_layer(sd, tower_from_raw_siglip):
     pfx = VIT_PREFIX + "encoder.layers."
     last = max(int(k[len(pfx):].split(".")[0]) for k in sd if k.startswith(pfx))
     return {k: v for k, v in sd.items() if not k.startswith(f"{pfx}{last}.")}
+
+
+def load_pretrained_model(model_path, model_base=None, model_name=None, device_map="auto", torch_dtype="float16",
+                          attn_implementation="flash_attention_2", overwrite_config=None, **kwargs):
+    """The LLaVA-Qwen branch of llava.model.builder.load_pretrained_model (builder.py:26-36, 206-228, 266-292) for callers that
+    run without the reference checkout on the path: tokenizer, LlavaQwenForCausalLM.from_pretrained with the same keyword
+    arguments, resize_token_embeddings, the tower's image processor, the context length.  Same return tuple."""
+    from transformers import AutoTokenizer
+
+    from llava.model import LlavaQwenConfig, LlavaQwenForCausalLM
+    if model_base is not None or kwargs:
+        raise NotImplementedError(f"only a full LLaVA-Qwen checkpoint directory is supported here (model_base / {sorted(kwargs)} given)")
+    dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}[torch_dtype] if isinstance(torch_dtype, str) else torch_dtype
+    tokenizer = AutoTokenizer.from_pretrained(model_path)
+    cfg = None
+    if overwrite_config:
+        cfg = LlavaQwenConfig.from_pretrained(model_path)
+        for k, v in overwrite_config.items():
+            setattr(cfg, k, v)
+    model = LlavaQwenForCausalLM.from_pretrained(model_path, low_cpu_mem_usage=True, attn_implementation=attn_implementation, config=cfg,
+                                                 device_map=device_map, torch_dtype=dt)
+    model.resize_token_embeddings(len(tokenizer))
+    tower = model.get_vision_tower()
+    if not tower.is_loaded:
+        tower.load_model(device_map=device_map)
+    for key in ("max_sequence_length", "max_position_embeddings", "tokenizer_model_max_length"):
+        if hasattr(model.config, key):
+            return tokenizer, model, tower.image_processor, getattr(model.config, key)
+    return tokenizer, model, tower.image_processor, 2048
