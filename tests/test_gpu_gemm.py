@@ -137,6 +137,14 @@ def test_gemm_pingpong_tile_equals_v3_tile_bitwise(ops, kind, M, N, K, epi, monk
                 if (var, pp) in outs:
                     assert torch.equal(out, outs[var, pp]), f"variant {var} pp={pp}: launch {rep} differs from launch 0"
                 outs[var, pp] = out
+    # the persistent tile loop: a grid of 3 workgroups makes every workgroup walk several tiles (next-tile prefetch under the
+    # epilogue, ring / C-staging reuse, counted waits restarted per tile)
+    monkeypatch.setenv("V3D_GEMM_PP_GRID", "3")
+    for var in ("3", "4"):
+        monkeypatch.setenv("V3D_GEMM_VARIANT", var)
+        for rep in range(2):
+            assert torch.equal(ops.gemm(a, w, **kw), outs[var, "1"]), f"variant {var}: persistent grid of 3 differs (launch {rep})"
+    monkeypatch.delenv("V3D_GEMM_PP_GRID")
     assert torch.equal(outs["3", "0"], outs["3", "1"]) and torch.equal(outs["4", "0"], outs["4", "1"])
     assert torch.equal(outs["3", "1"], outs["4", "1"])    # every tile shape sums k in the same order
     if epi in ("none", "bias"):

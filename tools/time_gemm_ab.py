@@ -28,8 +28,8 @@ shapes = [("llm qkv", S, 4608, 3584, 1), ("llm o_proj", S, 3584, 3584, 5), ("llm
           ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0)]
 for name, M, N, K, epi in shapes:
     row = []
-    for var, pp in (("1", "0"), ("4", "0"), ("4", "1"), ("3", "1"), ("0", "1")):
-        os.environ["V3D_GEMM_VARIANT"], os.environ["V3D_GEMM_PP"] = var, pp
+    for var, skew in (("3", "0"), ("3", "8"), ("3", "16"), ("3", "32"), ("3", "64"), ("4", "0"), ("4", "16"), ("4", "32")):
+        os.environ["V3D_GEMM_VARIANT"], os.environ["V3D_GEMM_PP"], os.environ["V3D_GEMM_SKEW"] = var, "1", skew
         ms = run(M, N, K, epi)
-        row.append(f"{ms*1e3:7.1f} us {2.0*M*N*K/ms/1e9:6.0f} TF")
-    print(f"{name:18s} {M:5d}x{N:5d}x{K:5d} | 128 {row[0]} | v3-192 {row[1]} | pp-192 {row[2]} | pp-256 {row[3]} | auto {row[4]}", flush=True)
+        row.append(f"{ms*1e3:7.1f}")
+    print(f"{name:18s} {M:5d}x{N:5d}x{K:5d} | pp-256 skew 0/8/16/32/64: {' '.join(row[:5])} | pp-192 skew 0/16/32: {' '.join(row[5:])}", flush=True)

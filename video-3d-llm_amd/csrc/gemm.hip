@@ -55,6 +55,7 @@ struct GemmArgs {
   int res_mod;        // >0: residual row = m % res_mod (ViT position embedding)
   int tiles_m, tiles_n;
   int dma_late;       // 256-wide kernel: restage after (1) or before (0) the last phase's MFMAs of a K-step
+  int skew;           // ping-pong kernel: largest start delay of a workgroup, in units of 1024 shader cycles (0 = none)
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -552,26 +553,42 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * B3N;
+  const int n_tiles = p.tiles_m * p.tiles_n;
 
+  // PERSISTENT: the grid is one workgroup per CU (or per tile when there are fewer); workgroup b walks the logical tiles
+  // b, b + grid, b + 2 grid, ... (the XCD-aware grouped order of tile_of_block: the stride is a multiple of 8, so a workgroup
+  // stays in its XCD's column of the order).  After a tile's K loop the K-step-0 half-tiles of the NEXT tile are issued
+  // before the epilogue, so their HBM latency (and the launch / dispatch gap between rounds) hides under the C-tile stores.
+  int bid = blockIdx.x;
+  // Start skew: with one tile per CU per round and equal tile times every CU reaches its epilogue at the same moment, and the
+  // chip alternates between "all CUs on the matrix cores, HBM nearly idle" and "all CUs storing C tiles, matrix cores idle"
+  // (the burst is HBM-bound: 256 x 128 KiB at once).  Delaying workgroup b by ((5 b) mod 16) / 16 of `skew` spreads the
+  // epilogues of later rounds over the K loops of the other CUs; equal tile times keep the offsets for the whole launch.
+  if (p.skew > 0) {
+    const int units = (((int)blockIdx.x * 5) & 15) * p.skew / 16;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  int tm, tn, m0, n0;
   // ---- staging: piece q = wave + 8 i (8 rows, 1 KiB) of every half-tile; W halves have 16 pieces, A halves NPA ----
   unsigned a_off[2][2], w_off[2][2];        // [half][piece] byte offsets of this lane's 16-byte source chunk
+  auto setup = [&](int b) {
+    tile_of_block(b, n_tiles, p.tiles_m, p.tiles_n, tm, tn);
+    m0 = tm * BM; n0 = tn * B3N;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int lr = (wave + 8 * i) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
-    const int awm = lr / HR, ar = lr - awm * HR;
+    for (int i = 0; i < 2; ++i) {
+      const int lr = (wave + 8 * i) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+      const int awm = lr / HR, ar = lr - awm * HR;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int gm = m0 + WROWS * awm + HR * h + ar;
-      gm = gm < p.M ? gm : p.M - 1;                            // M tail: re-read the last row, never stored
-      a_off[h][i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
-      const int gn = n0 + 64 * (lr >> 5) + 32 * h + (lr & 31);
-      w_off[h][i] = (unsigned)(gn * (int)p.ldw + chunk * 8) * 2u;
+      for (int h = 0; h < 2; ++h) {
+        int gm = m0 + WROWS * awm + HR * h + ar;
+        gm = gm < p.M ? gm : p.M - 1;                            // M tail: re-read the last row, never stored
+        a_off[h][i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
+        const int gn = n0 + 64 * (lr >> 5) + 32 * h + (lr & 31);
+        w_off[h][i] = (unsigned)(gn * (int)p.ldw + chunk * 8) * 2u;
+      }
     }
-  }
+  };
   const bool a_two = wave + 8 < NPA;        // this wave moves a second A piece (always for MT = 8; the wm = 0 waves for MT = 6)
   // half-tile kinds in stream order: 0 = A(hm 0), 1 = W(hn 0), 2 = W(hn 1), 3 = A(hm 1)
   auto stage = [&](auto kind_c, int kt) {
@@ -594,11 +611,6 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   const unsigned aW = lds0 + PP_HALF + (wn * 32) * (BK * 2);   // + buf * PP_BUF + {0 | PP_HALF}
 
   f32x4 acc[4][MT];   // [n-tile][m-tile] of the transposed product
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   v4i FA[2 * MH], W0[4], W1[4];     // FA[2 * mt + kh], W[2 * nt2 + kh]
 #define V3D_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 #define V3D_RDA(b0, b1) { V3D_DSR(FA[0], b0, 0); V3D_DSR(FA[1], b1, 0); V3D_DSR(FA[2], b0, 2048); V3D_DSR(FA[3], b1, 2048); \
@@ -657,17 +669,129 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     V3D_BAR();
   };
 
-  stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0); stage(IntC<0>{}, 1);
-  V3D_VM(6, 4);                                 // H0, H1 landed; (W A A) in flight
-  V3D_BAR();
-  if (wm == 1) V3D_BAR();                      // the wm = 1 waves run one barrier behind
-  {
-    int t = 0;
-    for (; t < nt - 2; ++t) kstep(IntC<0>{}, t);
-    kstep(IntC<1>{}, t);
-    kstep(IntC<2>{}, t + 1);
+  constexpr int C3_ROW = B3N * 2 + 16;
+  char* const cst = smem + PP_BUF;            // C staging of the epilogue: K-step buffer 1 onwards (buffer 0 receives the next tile)
+  const T* bias = (const T*)p.bias;
+  T* out = (T*)p.out;
+
+  setup(bid);
+  stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0);
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage(IntC<0>{}, 1);                          // H4 (slot 4: free - the previous tile's epilogue has left it)
+    V3D_VM(6, 4);                                 // H0, H1 landed; (W A A) in flight (later tiles: everything but H4 landed long ago)
+    V3D_BAR();
+    if (wm == 1) V3D_BAR();                      // the wm = 1 waves run one barrier behind
+    {
+      int t = 0;
+      for (; t < nt - 2; ++t) kstep(IntC<0>{}, t);
+      kstep(IntC<1>{}, t);
+      kstep(IntC<2>{}, t + 1);
+    }
+    if (wm == 0) V3D_BAR();
+    __syncthreads();                              // every fragment read of this tile is done: the whole ring is free
+
+    const int cm0 = m0, cn0 = n0, ctn = tn;
+    const int next = bid + (int)gridDim.x;
+    const bool has_next = next < n_tiles;         // workgroup-uniform
+    if (has_next) {                               // next tile's K-step 0 -> buffer 0, in flight under the epilogue
+      setup(next);
+      stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0);
+    }
+
+    // epilogue in two halves of WROWS rows (the wave row wm = half writes, everyone stores): accumulators -> LDS (16-bit, bias
+    // added in f32 first) -> whole 512-byte row segments
+#ifdef V3D_PP_PROBE   // tools/probes/gemm_pp_probe.hip only (WRONG RESULTS): 1 = K loop alone, the accumulators folded into one store
+    if (V3D_PP_PROBE == 1) {
+      float sacc = 0.f;
+      for (int i = 0; i < 4; ++i) for (int j = 0; j < MT; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (sacc == 12345.678f) out[tid] = from_f32<T>(sacc);
+    } else
+#endif
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // residual rows of this half: all loads in flight BEFORE the staging pass (issued one by one inside the store loop, each
+      // exposed its HBM round trip: 20 us per tile on the SigLIP fc2 shape)
+      constexpr bool HAS_RES = EPI == EPI_BIAS_RES || EPI == EPI_RES;
+      constexpr int RIT = WROWS / 16;                 // store-loop iterations per thread
+      uint4 rres[HAS_RES ? RIT : 1];
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int it = 0; it < RIT; ++it) {
+          const int gm = cm0 + half * WROWS + (tid >> 5) + 16 * it;
+          const int64_t rm = p.res_mod > 0 ? ((gm < p.M ? gm : p.M - 1) % p.res_mod) : (gm < p.M ? gm : p.M - 1);
+          rres[it] = *reinterpret_cast<const uint4*>((const T*)p.res + rm * p.ldr + cn0 + (tid & 31) * 8);
+        }
+      }
+      if (wm == half) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (epi_has_bias(EPI)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[cn0 + nl + r]);
+          }
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi) {
+            const int ml = mi * 16 + (lane & 15);
+            uint2 pk;
+            pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
+            pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
+            *reinterpret_cast<uint2*>(cst + ml * C3_ROW + nl * 2) = pk;
+          }
+        }
+      }
+      __syncthreads();
+      if (EPI == EPI_SWIGLU) {
+        // tile columns: per 128-column group [gate64 | up64]; two groups per tile -> 128 output columns
+#pragma unroll
+        for (int row = tid >> 4; row < WROWS; row += 32) {
+          const int c16 = tid & 15, grp = c16 >> 3, ch = c16 & 7;
+          const int gm = cm0 + half * WROWS + row;
+          const uint4 g = *reinterpret_cast<const uint4*>(cst + row * C3_ROW + grp * 256 + ch * 16);
+          const uint4 u = *reinterpret_cast<const uint4*>(cst + row * C3_ROW + grp * 256 + 128 + ch * 16);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu(vec_get<T>(g, j))) * vec_get<T>(u, j);
+          if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + ctn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < RIT; ++it) {
+          const int row = (tid >> 5) + 16 * it;
+          const int ch = tid & 31;
+          const int gm = cm0 + half * WROWS + row;
+          if (gm < p.M) {
+            uint4 c = *reinterpret_cast<const uint4*>(cst + row * C3_ROW + ch * 16);
+            if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES || EPI == EPI_BIAS_RELU) {
+              float v[8];
+              const uint4 rr = HAS_RES ? rres[it] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float x = vec_get<T>(c, j);
+                v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + vec_get<T>(rr, j);
+              }
+              c = vec_pack<T>(v);
+            }
+            *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + cn0 + ch * 8) = c;
+          }
+        }
+      }
+      __syncthreads();
+    }
+#ifdef V3D_PP_PROBE
+    if (V3D_PP_PROBE == 2) { if (!has_next) break; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bid = next; continue; }
+#endif
+    if (!has_next) break;
+    // the counted waits of the K loop assume that only this wave's staging DMAs are outstanding, in issue order: retire the
+    // epilogue's stores / residual loads (and with them the prefetch, long since landed) before the next tile starts counting
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bid = next;
   }
-  if (wm == 0) V3D_BAR();
 #undef V3D_DSR
 #undef V3D_RDA
 #undef V3D_RDW4
@@ -676,69 +800,6 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
 #undef V3D_PPMMA
 #undef V3D_VM
 #undef V3D_BAR
-  __syncthreads();
-
-  // epilogue: the whole 256 x 256 C tile goes through LDS at once (256 rows x 528 B = 132 KiB of the CU's 160: one rendezvous
-  // instead of the v3 kernel's two half-tile passes), then leaves as whole 512-byte row segments
-  constexpr int C3_ROW = B3N * 2 + 16;
-  const T* bias = (const T*)p.bias;
-  T* out = (T*)p.out;
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (epi_has_bias(EPI)) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
-    }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int ml = wm * WROWS + mi * 16 + (lane & 15);
-      uint2 pk;
-      pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
-      pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
-      *reinterpret_cast<uint2*>(smem + ml * C3_ROW + nl * 2) = pk;
-    }
-  }
-  __syncthreads();
-  if (EPI == EPI_SWIGLU) {
-    // tile columns: per 128-column group [gate64 | up64]; two groups per tile -> 128 output columns
-#pragma unroll 2
-    for (int row = tid >> 4; row < BM; row += 32) {
-      const int c16 = tid & 15, grp = c16 >> 3, ch = c16 & 7;
-      const int gm = m0 + row;
-      const uint4 g = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + ch * 16);
-      const uint4 u = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + grp * 256 + 128 + ch * 16);
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu(vec_get<T>(g, j))) * vec_get<T>(u, j);
-      if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + tn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
-    }
-  } else {
-#pragma unroll 2
-    for (int row = tid >> 5; row < BM; row += 16) {
-      const int ch = tid & 31;
-      const int gm = m0 + row;
-      if (gm < p.M) {
-        uint4 c = *reinterpret_cast<const uint4*>(smem + row * C3_ROW + ch * 16);
-        if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES || EPI == EPI_BIAS_RELU) {
-          float v[8];
-          uint4 rr = make_uint4(0, 0, 0, 0);
-          if (EPI == EPI_BIAS_RES || EPI == EPI_RES) {
-            const int64_t rm = p.res_mod > 0 ? (gm % p.res_mod) : gm;
-            rr = *reinterpret_cast<const uint4*>((const T*)p.res + rm * p.ldr + n0 + ch * 8);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float x = vec_get<T>(c, j);
-            v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + vec_get<T>(rr, j);
-          }
-          c = vec_pack<T>(v);
-        }
-        *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + n0 + ch * 8) = c;
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -883,10 +944,27 @@ static int gemm_pp_mode() {   // 1 (default) = ping-pong v4 for the 256 x 256 ti
   return e ? atoi(e) : 1;
 }
 
+static int pp_slots() {       // workgroups the chip holds at once (one per CU: 132 KiB of LDS each); V3D_GEMM_PP_GRID overrides (tests)
+  const char* e = getenv("V3D_GEMM_PP_GRID");
+  if (e && atoi(e) > 0) return atoi(e);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 template <typename T, int MT>
 static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
   p.tiles_m = (p.M + MT * 32 - 1) / (MT * 32);
   p.tiles_n = p.N / B3N;
+  const int n_tiles = p.tiles_m * p.tiles_n;
+  const int grid = n_tiles < pp_slots() ? n_tiles : pp_slots();     // persistent: one workgroup per CU walks its tiles
+  { const char* e = getenv("V3D_GEMM_SKEW"); p.skew = e ? atoi(e) : 0; }
+  if (n_tiles <= grid) p.skew = 0;                                  // a single round: nothing to spread
 #define V3D_GEMM4_CASE(E)                                                                                 \
   case E: {                                                                                               \
     auto k = gemm256pp_kernel<T, E, MT>;                                                                    \
@@ -896,7 +974,7 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
       if (e != hipSuccess) { set_error("v3d_gemm: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
       attr_done = true;                                                                                   \
     }                                                                                                     \
-    hipLaunchKernelGGL(k, dim3(p.tiles_m * p.tiles_n), dim3(512), PP_LDS_BYTES, st, p);                   \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), PP_LDS_BYTES, st, p);                                    \
   } break;
   switch (epi) {
     V3D_GEMM4_CASE(EPI_NONE)
@@ -1000,7 +1078,7 @@ extern "C" int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   GemmArgs p;
   p.A = A; p.W = W; p.bias = need_bias ? bias : nullptr; p.res = need_res ? res : nullptr; p.out = out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldo = ldo; p.res_mod = res_mod;
-  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = N / BN;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = N / BN; p.skew = 0; p.dma_late = 0;
   hipStream_t st = (hipStream_t)stream;
   if (M <= 8) return dtype == V3D_BF16 ? launch_gemv<bf16_t>(p, epilogue, st) : launch_gemv<f16_t>(p, epilogue, st);
   return dtype == V3D_BF16 ? launch_gemm<bf16_t>(p, epilogue, st) : launch_gemm<f16_t>(p, epilogue, st);
