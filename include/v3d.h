@@ -209,7 +209,9 @@ int v3d_add_row(void* x, int64_t ldx, const int64_t* rows, int n_rows, int C, co
 /* K16 / K11  softmax(Q K^T * scale [+ causal mask]) V without materialising the scores.
  * Prefill: Qwen2 causal GQA (spec: eager Qwen2Attention, modeling_qwen2.py:289-311; runtime:
  * flash-attn-2 :567-574) with D = 128; SigLIP attention (siglip_encoder.py:213-239) non-causal with
- * D = 96 (head dim 72 zero-padded by the QKV weight layout; d_out = 72 columns are written).
+ * D = 96 = the kernel's tile width for head dim 72: d_out = 72 is the number of valid dims - columns >= d_out of q are
+ * treated as zero and only d_out columns of o are written, so heads may be packed at their true stride (hsq = hsk = 72:
+ * the 24 extra columns a tile row covers then belong to the next head or to row padding; they must be readable).
  * Element (b, token s, head h, dim d) of q is at q + b*bsq + s*ldq + h*hsq + d (likewise k, v with
  * bsk/ldk|ldv/hsk and o with bso/ldo/hso); kv head = h / (Hq/Hkv).  With causal != 0 query i sits at
  * key position q_pos0 + i (q_pos0 = number of cached tokens).  Sq <= 8 with B == 1 takes the

@@ -159,6 +159,33 @@ def test_attention_vit_noncausal_padded_heads(ops, kind):
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_attention_vit_heads_packed_at_true_stride(ops, kind):
+    """SigLIP as the engine lays it out: q | k | v blocks of 16 heads x 72 packed with head stride 72 in one row (the QKV GEMM
+    computes no padding columns); the kernel's 96-wide tile reaches 24 columns into the NEXT head (or the row padding), which
+    d_out = 72 makes it ignore - the result must equal attention over the 72 true dims, and the layout with zero-padded heads."""
+    import math
+    dt = DT[kind]
+    B, S, H, D, DP = 3, 729, 16, 72, 96
+    g = torch.Generator().manual_seed(16)
+    ld = 3584                                                     # 3 * 1152 + 24 readable columns, rounded up to 256
+    row = torch.randn(B * S, ld, generator=g).to(dt)              # the pad columns hold (finite) garbage on purpose
+    q = row[:, : H * D].view(B, S, H, D)
+    k = row[:, H * D: 2 * H * D].view(B, S, H, D)
+    v = row[:, 2 * H * D: 3 * H * D].view(B, S, H, D)
+    dev = row.cuda()
+    out = torch.empty(B * S, H * D, dtype=dt, device="cuda")
+    ops.attention(dev, dev[:, H * D:], dev[:, 2 * H * D:], out, B, S, S, H, H, DP, D, ld, ld, ld, out.stride(0), S * ld, S * ld,
+                  S * out.stride(0), D, D, D, False, 0, 1 / math.sqrt(D))
+    want = ref_attention(q, k, v, False, D ** -0.5)
+    close(out.view(B, S, H, D), want, kind, ulps=3.0, floor=0.1)
+    padded = torch.zeros(B, S, 3, H, DP)
+    padded[:, :, 0, :, :D], padded[:, :, 1, :, :D], padded[:, :, 2, :, :D] = q.float(), k.float(), v.float()
+    pd = padded.to(dt).cuda()
+    ref2 = ops.attention_bshd(pd[:, :, 0], pd[:, :, 1], pd[:, :, 2], causal=False, scale=D ** -0.5, d_out=D)
+    assert torch.equal(ref2.reshape(B * S, H * D), out)           # same arithmetic on the same values: bit for bit
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
 @pytest.mark.parametrize("past", [0, 5, 700])
 def test_attention_decode(ops, kind, past):
     dt = DT[kind]

@@ -139,6 +139,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     float f[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = vec_get<T>(raw, j) * p.scale_log2;
+    if (D > 72 && ks * 16 + 8 >= 72) {     // only tiles that can reach past d_out (the SigLIP head: 72 of the 96-wide tile)
+      // dims >= d_out do not belong to this head: with heads packed at their true stride (72) they hold the NEXT head's values.
+      // Zeroing them in Q removes their products from Q.K^T whatever the K tile carries there (finite activations).
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (ks * 16 + h * 8 + j) < p.d_out ? f[j] : 0.f;
+    }
     qf[ks].u = vec_pack<T>(f);
   }
 

@@ -135,7 +135,7 @@ class SceneContext:
 
 
 class Engine:
-    VIT_DP = 96      # SigLIP head dim 72, zero padded to the attention kernel's 96
+    VIT_DP = 96      # the attention kernel's tile width for SigLIP's head dim 72
 
     def __init__(self, cfg: EngineConfig, state_dict, dtype=torch.bfloat16, device="cuda", max_frames=32, llm_fp8=False):
         """llm_fp8 (BASELINE configs[3]): the decoder linears and the LM head use OCP e4m3 weights, quantised once per
@@ -178,7 +178,10 @@ class Engine:
         # fc2 (K = 4352) runs on the 256-wide GEMM tile (234 vs 265 us); the pad columns are zero weights -> stay exactly zero
         Hx = _up(Hp, 256)
         self.v_Hx = Hx if Hx <= 1.15 * Hp else Hp
-        self.v_nqkv = _up(3 * nh * DP, 128)
+        # Q | K | V heads packed at their TRUE stride (72): the attention kernel works on 96-wide tiles but treats dims >= 72 as
+        # not belonging to the head (v3d_attention's d_out), so the GEMM does not compute 25 % padding columns; rows padded to a
+        # multiple of 256 for the 256-wide GEMM tile (3456 -> 3584); + DP - hd readable columns behind the last head
+        self.v_nqkv = _up(3 * nh * hd + (DP - hd), 256)
         self.v_kpatch = _up(3 * v.patch * v.patch, 64)
         vp = "model.vision_tower.vision_tower.vision_model."
         self.v_pe_w = _pad2(sd[vp + "embeddings.patch_embedding.weight"].reshape(H, -1), Hp, self.v_kpatch)
@@ -190,11 +193,8 @@ class Engine:
             wqkv = torch.zeros((self.v_nqkv, Hk), dtype=self.dtype, device=self.device)
             bqkv = torch.zeros(self.v_nqkv, dtype=self.dtype, device=self.device)
             for part, nme in enumerate(("q_proj", "k_proj", "v_proj")):
-                w = sd[p + f"self_attn.{nme}.weight"].view(nh, hd, H)
-                b = sd[p + f"self_attn.{nme}.bias"].view(nh, hd)
-                dst = wqkv[part * nh * DP:(part + 1) * nh * DP].view(nh, DP, Hk)
-                dst[:, :hd, :H] = w
-                bqkv[part * nh * DP:(part + 1) * nh * DP].view(nh, DP)[:, :hd] = b
+                wqkv[part * H:(part + 1) * H, :H] = sd[p + f"self_attn.{nme}.weight"]
+                bqkv[part * H:(part + 1) * H] = sd[p + f"self_attn.{nme}.bias"]
             self.v_layers.append(dict(
                 ln1_w=sd[p + "layer_norm1.weight"].contiguous(), ln1_b=sd[p + "layer_norm1.bias"].contiguous(),
                 ln2_w=sd[p + "layer_norm2.weight"].contiguous(), ln2_b=sd[p + "layer_norm2.bias"].contiguous(),
@@ -303,8 +303,8 @@ class Engine:
             ops.layernorm(x[:, :H], L["ln1_w"], L["ln1_b"], v.eps, out=h[:, :H])
             ops.gemm(h[:, :Hk], L["wqkv"], bias=L["bqkv"], epilogue=ops.EPI_BIAS, out=qkv)
             ld = qkv.stride(0)
-            ops.attention(qkv, qkv[:, nh * DP:], qkv[:, 2 * nh * DP:], att, F_, n, n, nh, nh, DP, self.vhd,
-                          ld, ld, ld, att.stride(0), n * ld, n * ld, n * att.stride(0), DP, DP, self.vhd, False, 0, scale)
+            ops.attention(qkv, qkv[:, H:], qkv[:, 2 * H:], att, F_, n, n, nh, nh, DP, self.vhd,
+                          ld, ld, ld, att.stride(0), n * ld, n * ld, n * att.stride(0), self.vhd, self.vhd, self.vhd, False, 0, scale)
             ops.gemm(att[:, :Hk], L["wo"], bias=L["bo"], res=x, epilogue=ops.EPI_BIAS_RES, out=x)
             ops.layernorm(x[:, :H], L["ln2_w"], L["ln2_b"], v.eps, out=h[:, :H])
             ops.gemm(h[:, :Hk], L["w1"], bias=L["b1"], epilogue=ops.EPI_BIAS_GELU_TANH, out=mlp)
