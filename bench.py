@@ -266,11 +266,19 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}: launch N > 1 with "
                          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus}`")
+    # V3D_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend - exercises the N > 1 code path (sharding, record gather,
+    # max-over-ranks timing) on a one-GPU box; its numbers mean nothing (the ranks share one GPU) and the line says so
+    rehearsal = os.environ.get("V3D_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from v3d import distributed as v3dist
     from v3d import ops
@@ -318,11 +326,11 @@ def main():
         merged = None
         if world > 1:   # eval collation: ONE variable-length gather of the answer records to rank 0 (replaces Ray + file lock)
             recs = [{"sample_id": sid, "pred_token_ids": row} for sid, row in zip(my_ids, answers.tolist())]
-            merged = v3dist.gather_records(recs, dev)
+            merged = v3dist.gather_records(recs, torch.device("cpu") if rehearsal else dev)
         barrier()
         dt_s = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt_s], device="cpu" if rehearsal else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_s = tt.item()
             if rank == 0:
@@ -381,7 +389,8 @@ def main():
         line = {
             "metric": "scenes/sec ScanQA @32 frames", "value": world * a.steps / dt_s, "unit": "scenes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_s / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16",
+            "data": "synthetic" + (" (REHEARSAL: all ranks share cuda:0 over gloo - not a measurement)" if rehearsal else ""),
             "config": {"workload": "ScanQA val, uniform 32 frames, %s, 1xMI355X per rank: 32x(480x640 u16 depth + 384x384 RGB) -> "
                                    "SigLIP-so400m(26L) + mlp2x_gelu + 3D-PE fusion -> Qwen2-7B prefill S=%d + %d greedy tokens (%d decode passes "
                                    "over the weights); random-init weights at true widths; %d distinct synthetic scenes cycled"
