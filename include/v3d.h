@@ -319,6 +319,30 @@ int v3d_preprocess_rgb_u8(const uint8_t* frames, int F, int H, int W, const floa
  * GEMM: gathers images [B,3,S,S] into rows [B*(S/patch)^2, kpad], columns (c, ky, kx) zero padded. */
 int v3d_patchify(const void* images, void* out, int B, int S, int patch, int kpad, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ training step (configs[4], first kernels) --- */
+
+/* The loss of Qwen2ForCausalLM.forward, llava/model/language_model/qwen2/modeling_qwen2.py:1195-1205: logits [positions, vocab]
+ * (dtype: f32 as the reference's `.float()`, or 16-bit; row stride ld), labels [positions] int64 (device); position t predicts
+ * label t + 1 (the shift), rows whose label is ignore_index (-100) do not count.  Outputs (device, f32): loss_rows[positions-1]
+ * (0 for ignored rows), lse_rows[positions-1] (log-sum-exp per row, reused by the gradient), mean_count[2] = {mean loss over the
+ * valid rows (CrossEntropyLoss reduction 'mean'; NaN if none), number of valid rows}. */
+int v3d_cross_entropy(const void* logits, int64_t ld, int dtype, int64_t positions, int vocab, const int64_t* labels,
+                      int64_t ignore_index, float* loss_rows, float* lse_rows, float* mean_count, void* stream);
+/* d loss / d logits: dlogits[t, :] = (softmax(logits[t, :]) - onehot(labels[t + 1])) * upstream / #valid, zero rows for ignored
+ * labels and for the last position; written in grad_dtype (the logits' dtype or f32), row stride ldg. */
+int v3d_cross_entropy_grad(const void* logits, int64_t ld, int dtype, int64_t positions, int vocab, const int64_t* labels,
+                           int64_t ignore_index, const float* lse_rows, const float* mean_count, float upstream, void* dlogits,
+                           int64_t ldg, int grad_dtype, void* stream);
+
+/* Backward of v3d_visual_tokens (flags POOL [| PE] [| NEWLINE]) with respect to its parameter-free inputs: the PE add passes the
+ * gradient through (llava_arch.py:515: coords are detached), get_2dPool's bilinear 27 -> 14 (llava_arch.py:191-210) scatters
+ * it back onto the projector features with the forward's own tap weights (gather form, f32 accumulation in a fixed order), and
+ * image_newline (llava_arch.py:307-328) collects the sum of its V * n rows.
+ * dout rows as the forward wrote them (V*n*(n+1) with NEWLINE else V*n*n; row stride dout_stride), dfeat [V, side*side, C] dtype,
+ * dnewline [C] f32 (NEWLINE only). */
+int v3d_visual_tokens_grad(const void* dout, int64_t dout_stride, void* dfeat, float* dnewline, int dtype, int V, int side, int n,
+                           int C, int flags, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* a1  llava/video_utils.py:187  np.linspace(0, total-1, n, dtype=int).  out_host[n]. */

@@ -125,6 +125,13 @@ def test_plain_and_grounding_forward_match_the_reference(loaded, g):
     out = model(inp["ids"][None].cuda(), images=images, modalities="video", video_dict=video_dict)
     assert tuple(out.logits.shape) == (1, 431, 320) and out.logits.dtype == torch.float32
     assert rel_err(out.logits[0, -1], want["logits"]) < 9e-3
+    # labels -> the shifted cross-entropy of Qwen2ForCausalLM.forward over the re-aligned labels, against torch on the returned logits
+    lab = torch.full_like(inp["ids"], -100)
+    lab[-4:] = inp["ids"][-4:]
+    out2 = model(inp["ids"][None].cuda(), images=images, modalities="video", video_dict=video_dict, labels=lab[None].cuda())
+    full = torch.cat([lab[:5], torch.full((420,), -100), lab[6:]])
+    ref_loss = torch.nn.functional.cross_entropy(out2.logits[0, :-1].float().cpu(), full[1:], ignore_index=-100)
+    assert abs(out2.loss.item() - ref_loss.item()) < 1e-5 * max(1.0, ref_loss.item())
     tup = model.prepare_inputs_labels_for_multimodal(inp["ids"][None].cuda(), None, None, None, None, images, ["video"], None, video_dict)
     assert tup[0] is None and tup[1] is None and tup[2] is None and tup[5] is None and tup[6] is None
     assert tuple(tup[4].shape) == (1, 431, 256) and rel_err(tup[4][0], want["embeds"]) < 3e-3

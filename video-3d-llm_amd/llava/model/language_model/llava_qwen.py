@@ -13,8 +13,8 @@ v3d.engine.Engine's HBM layouts.  Call contracts mirrored (3-D eval drivers):
                    max_new_tokens=N, use_cache=True)                                     -> LongTensor [1, n_new]
     model(input_ids, images=..., modalities="video", video_dict=..., labels=labels, use_object_proposals=True)
                                                                                          -> (None, scores [n_obj + 1])
-    model(input_ids, images=..., modalities="video", video_dict=...)                     -> CausalLMOutputWithPast(logits [1,S,V] f32)
-Greedy decoding only; sampling / beams / training losses raise NotImplementedError, unknown keyword arguments raise
+    model(input_ids, images=..., modalities="video", video_dict=..., [labels=...])       -> CausalLMOutputWithPast(loss, logits [1,S,V] f32)
+Greedy decoding only, no autograd (the loss is a forward value); sampling / beams / box_labels raise NotImplementedError, unknown keyword arguments raise
 TypeError - nothing is silently dropped.
 """
 import json
@@ -171,8 +171,8 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
         position (modeling_qwen2.py:1188-1192)."""
         if output_attentions or output_hidden_states or dpo_forward:
             raise NotImplementedError("output_attentions / output_hidden_states / dpo_forward are not on the accelerated path")
-        if box_labels is not None or (labels is not None and not use_object_proposals):
-            raise NotImplementedError("losses (labels / box_labels) belong to training, outside the accelerated inference path")
+        if box_labels is not None:
+            raise NotImplementedError("the grounding loss (box_labels) belongs to training, outside the accelerated inference path")
         if past_key_values is not None:
             raise NotImplementedError("external KV caches are not supported; use generate() (the engine owns the cache)")
         eng = self.engine
@@ -200,7 +200,12 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
             if loc.numel() != 1:
                 raise ValueError("exactly one <ground> label token expected")
             return None, eng.predict_box(x, int(loc[0]), object_features)
-        return CausalLMOutputWithPast(loss=None, logits=eng.logits_all_rows(x)[None], past_key_values=None)
+        logits = eng.logits_all_rows(x)
+        loss = None
+        if labels is not None:        # the shifted cross-entropy of modeling_qwen2.py:1195-1205 over the re-aligned labels (forward value only)
+            from v3d import ops
+            loss, _ = ops.cross_entropy(logits, new_labels[0].to(eng.device))
+        return CausalLMOutputWithPast(loss=loss, logits=logits[None], past_key_values=None)
 
     # ------------------------------------------------------------------ generate (llava_qwen.py:208-226)
     @torch.no_grad()

@@ -623,3 +623,47 @@ def patchify(images, patch=14, kpad=640):
     out = torch.empty((B * g * g, kpad), dtype=im.dtype, device=im.device)
     check(lib().v3d_patchify(_p(im), _p(out), B, S, patch, kpad, _code(im), _stream()), "v3d_patchify")
     return out
+
+
+# ------------------------------------------------------------------------------ training step (configs[4], first kernels)
+
+
+def cross_entropy(logits, labels, ignore_index=-100):
+    """Qwen2ForCausalLM's loss (modeling_qwen2.py:1195-1205): logits [S, vocab] (f32 / f16 / bf16), labels [S] int64 on the device;
+    position t predicts label t + 1.  Returns (mean loss f32 scalar tensor, state for cross_entropy_grad)."""
+    lg = _dev(logits, "logits")
+    lb = _dev(labels, "labels").to(torch.int64).reshape(-1)
+    S, V = lg.shape
+    if lb.numel() != S or S < 2:
+        raise V3DError("cross_entropy: labels must have one entry per position (>= 2 positions)")
+    loss_rows = torch.empty(S - 1, dtype=torch.float32, device=lg.device)
+    lse_rows = torch.empty(S - 1, dtype=torch.float32, device=lg.device)
+    mean_count = torch.empty(2, dtype=torch.float32, device=lg.device)
+    check(lib().v3d_cross_entropy(_p(lg), lg.stride(0), _code(lg), S, V, _p(lb), ignore_index, _p(loss_rows), _p(lse_rows), _p(mean_count),
+                                  _stream()), "v3d_cross_entropy")
+    return mean_count[0], (lg, lb, lse_rows, mean_count, ignore_index, loss_rows)
+
+
+def cross_entropy_grad(state, upstream=1.0, dtype=None):
+    """d loss / d logits for the state cross_entropy returned, [S, vocab] in `dtype` (default: the logits' dtype)."""
+    lg, lb, lse_rows, mean_count, ignore_index, _ = state
+    S, V = lg.shape
+    dtype = dtype or lg.dtype
+    out = torch.empty((S, V), dtype=dtype, device=lg.device)
+    check(lib().v3d_cross_entropy_grad(_p(lg), lg.stride(0), _code(lg), S, V, _p(lb), ignore_index, _p(lse_rows), _p(mean_count),
+                                       float(upstream), _p(out), out.stride(0), _DT[dtype], _stream()), "v3d_cross_entropy_grad")
+    return out
+
+
+def visual_tokens_grad(dout, V, side=27, n=14, newline=True):
+    """Backward of visual_tokens(pool=True [, table] [, newline]) for dout [rows, C] (16-bit): returns (dfeat [V, side*side, C],
+    dnewline f32 [C] or None)."""
+    g = _dev(dout, "dout")
+    rows, C = g.shape
+    if rows != V * n * ((n + 1) if newline else n):
+        raise V3DError(f"visual_tokens_grad: dout has {rows} rows, expected {V * n * ((n + 1) if newline else n)}")
+    dfeat = torch.empty((V, side * side, C), dtype=g.dtype, device=g.device)
+    dnl = torch.empty(C, dtype=torch.float32, device=g.device) if newline else None
+    flags = VT_POOL | VT_PE | (VT_NEWLINE if newline else 0)
+    check(lib().v3d_visual_tokens_grad(_p(g), g.stride(0), _p(dfeat), _p(dnl), _code(g), V, side, n, C, flags, _stream()), "v3d_visual_tokens_grad")
+    return dfeat, dnl
