@@ -76,3 +76,16 @@ def test_greedy_cover_edge_cases():
     assert sel.tolist() == [0, 1, 2] and gains.tolist() == [1, 1, 0] and n_all == 2 and n_sel == 2
     with pytest.raises(_native.V3DError):
         ops.greedy_cover(np.full((1, 1, 3), 1 << 22, np.int32), np.zeros((1, 3), np.int32))
+
+
+def test_host_half_under_asan_ubsan():
+    """csrc/host.cpp + its self-test driver built with g++ -fsanitize=address,undefined (sanitizers on the CPU
+    build): frame-index and greedy-cover helpers on ragged sizes against a brute-force set implementation, and every
+    argument-validation branch."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this machine")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "video-3d-llm_amd", "csrc"), "sanitize"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "host_selftest ok" in r.stdout

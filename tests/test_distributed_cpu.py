@@ -52,3 +52,44 @@ def test_shard_and_gather_world2():
 def test_shard_is_the_reference_stride():
     items = list(range(10))
     assert D.shard(items, 1, 4) == items[1::4]
+
+
+def _zero2_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    numel = 1003                                   # not a multiple of the world size: the tail partition is padded
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(numel, generator=g)
+    part = D.reduce_scatter_grads(grad, bucket_elems=128)          # several buckets
+    part_one = D.reduce_scatter_grads(grad, bucket_elems=10 ** 9)  # one bucket: same result
+    bounds, per = D.partition_bounds(numel, world)
+    params = torch.arange(numel, dtype=torch.float32)
+    mine = torch.zeros(per)
+    b, e = bounds[rank]
+    mine[: e - b] = params[b:e] - 0.1 * part[: e - b]              # an SGD step on the rank's own partition
+    full = D.all_gather_params(mine, numel, bucket_elems=200)
+    q.put((rank, part, part_one, full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_reduce_scatter_and_all_gather_world2():
+    """ZeRO-2's two exchanges (scripts/zero2.json:22-34) over gloo, world 2: the partitions of the averaged gradient and the
+    re-assembled parameters equal the single-process computation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_zero2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    grads = [torch.randn(1003, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)]
+    mean = (grads[0] + grads[1]) / 2
+    bounds, per = D.partition_bounds(1003, 2)
+    for rank, part, part_one, full in res:
+        b, e = bounds[rank]
+        assert torch.allclose(part[: e - b], mean[b:e]) and torch.equal(part, part_one) and not bool(part[e - b:].any())
+        assert torch.allclose(full, torch.arange(1003, dtype=torch.float32) - 0.1 * mean)

@@ -59,8 +59,8 @@ static inline uint64_t pack_key(const int32_t* k) {
 extern "C" int v3d_greedy_cover_host(const int32_t* keys_host, int n_frames, int64_t pts_per_frame,
                                      const int32_t* scene_host, int64_t m, int max_frames, int32_t* sel_host,
                                      int64_t* gain_host, int64_t* num_all_host, int64_t* num_sel_host) {
-  if (!keys_host || !scene_host || !sel_host || !gain_host || n_frames <= 0 || pts_per_frame <= 0 || m < 0 ||
-      max_frames <= 0) {
+  if (!keys_host || (!scene_host && m > 0) || !sel_host || !gain_host || n_frames <= 0 || pts_per_frame <= 0 || m < 0 ||
+      max_frames <= 0) {      // (an empty scene - m == 0, scene pointer unused - is legal, as for the device entry)
     v3d::set_error("v3d_greedy_cover_host: bad arguments");
     return V3D_E_INVALID;
   }

@@ -44,3 +44,64 @@ def gather_records(records, device, dst=0):
                 merged.append(p[i])
         i += 1
     return merged
+
+
+# ------------------------------------------------------------------------------ training collectives (configs[4])
+# ZeRO-2 as scripts/zero2.json:22-34 configures DeepSpeed: gradients leave by reduce-scatter in buckets of 2e8 elements
+# (`reduce_scatter: true`, `reduce_bucket_size: 2e8`), the updated parameter partitions come back by all-gather in buckets of the
+# same size (`allgather_bucket_size: 2e8`).  On the 8-GPU xGMI mesh a 2e8-element bf16 bucket is 400 MB = 50 MB per peer; RCCL's
+# reduce_scatter over a fully connected mesh can use all 7 links, a ring is bound by one.
+
+ZERO2_BUCKET_ELEMS = int(2e8)
+
+
+def partition_bounds(numel, world):
+    """Equal contiguous partitions of a flat buffer (padded to a multiple of world): [(begin, end)] per rank."""
+    per = (numel + world - 1) // world
+    return [(min(r * per, numel), min((r + 1) * per, numel)) for r in range(world)], per
+
+
+def reduce_scatter_grads(flat_grad, bucket_elems=ZERO2_BUCKET_ELEMS, average=True):
+    """flat_grad: this rank's flat gradient buffer [numel] (any float dtype).  Returns this rank's partition of the SUM (or
+    mean) over ranks, [per] (zero-padded at the tail), exchanged bucket by bucket so that no more than `bucket_elems` elements are
+    in flight: per bucket ONE reduce-scatter (RCCL) - or, where the backend has none (gloo), an all-reduce of the bucket followed
+    by the local slice (same result, CPU tests only)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    numel = flat_grad.numel()
+    bounds, per = partition_bounds(numel, world)
+    out = torch.zeros(per, dtype=flat_grad.dtype, device=flat_grad.device)
+    has_rs = dist.get_backend() != "gloo"
+    # a bucket covers the same sub-range [o, o + chunk) of every rank's partition, so each bucket is a complete reduce-scatter
+    chunk = max(1, min(per, bucket_elems // world))
+    for o in range(0, per, chunk):
+        n = min(chunk, per - o)
+        send = torch.zeros(world * n, dtype=flat_grad.dtype, device=flat_grad.device)
+        for r in range(world):
+            b = r * per + o
+            e = min(b + n, numel)
+            if e > b:
+                send[r * n: r * n + (e - b)] = flat_grad[b:e]
+        if has_rs:
+            dist.reduce_scatter_tensor(out[o: o + n], send, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(send, op=dist.ReduceOp.SUM)
+            out[o: o + n] = send[rank * n: (rank + 1) * n]
+    if average:
+        out /= world
+    return out
+
+
+def all_gather_params(partition, numel, bucket_elems=ZERO2_BUCKET_ELEMS):
+    """Inverse exchange after the optimizer step: every rank contributes its updated partition [per]; returns the flat
+    parameter buffer [numel], gathered in buckets of at most `bucket_elems` elements."""
+    world = dist.get_world_size()
+    per = partition.numel()
+    full = torch.empty(world * per, dtype=partition.dtype, device=partition.device)
+    chunk = max(1, min(per, bucket_elems // world))
+    for o in range(0, per, chunk):
+        n = min(chunk, per - o)
+        parts = [torch.empty(n, dtype=partition.dtype, device=partition.device) for _ in range(world)]
+        dist.all_gather(parts, partition[o: o + n].contiguous())
+        for r in range(world):
+            full[r * per + o: r * per + o + n] = parts[r]
+    return full[:numel]
