@@ -126,6 +126,30 @@ def test_attention_matches_reference_eager_rounding(ops, kind):
     close(got, want, kind, ulps=4.0, floor=0.3)
 
 
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("Sq,Sk", [(64, 64), (300, 300), (1000, 1000), (2100, 2100), (130, 900), (517, 2048)])
+def test_attention_prefill64_optin_kernel_equals_default_kernel_bitwise(ops, kind, Sq, Sk, monkeypatch):
+    """V3D_ATTN64=1 selects attn_prefill64_kernel (64 queries per wave, 3-deep K/V ring, softmax pieces in the MFMA gaps): same
+    arithmetic in the same order as attn_prefill_kernel, so the outputs are equal bit for bit - causal, GQA, ragged tails,
+    question rows at q_pos0 > 0 over a longer K/V prefix (scene reuse), and the rare max-raise branch (spiked key)."""
+    dt = DT[kind]
+    H, KV, D = 28, 4, 128
+    g = torch.Generator().manual_seed(Sq * 7 + Sk)
+    q = torch.randn(1, Sq, H, D, generator=g) * 0.5
+    k = torch.randn(1, Sk, KV, D, generator=g) * 0.5
+    v = torch.randn(1, Sk, KV, D, generator=g)
+    if Sk >= 300:
+        k[0, Sk - 90, 1] = q[0, Sq - 10, 9] * 30          # a late spike: the running maximum of one query jumps
+    q, k, v = q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("V3D_ATTN64", mode)
+        outs[mode] = ops.attention_bshd(q, k, v, causal=True, q_pos0=Sk - Sq)
+    assert torch.equal(outs["0"], outs["1"])
+    want = ref_attention(q.cpu(), k.cpu(), v.cpu(), True, 1 / math.sqrt(D), q_pos0=Sk - Sq)
+    close(outs["1"], want, kind, ulps=4.0, floor=0.3)      # (the spiked row's P is one 16-bit rounding away from one-hot)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """Force the running max to jump at a late KV tile (rule: rare branches need their own test)."""
     dt = torch.bfloat16

@@ -80,7 +80,7 @@ struct AttnArgs {
 };
 
 #ifdef V3D_ATTN_PROF   // tools/probes/attn_prof.hip only: per-wave cycle split of the tile loop (never in the product build)
-__device__ unsigned long long g_attn_prof[8 * 64];
+__device__ unsigned long long g_attn_prof[4 * 4096];
 __device__ unsigned long long g_attn_blocks[4 * 4096];   // per workgroup: realtime start, end, shader-clock delta, HW_ID
 // per-phase shader-clock stamps of the pipeline step (one asm statement each, so the wait stays with the stamp)
 #define V3D_STAMP(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
@@ -459,6 +459,645 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     if (row < 32 && q < p.Sq && ch * 8 < p.d_out)
       *reinterpret_cast<uint4*>(O + (int64_t)q * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(so + row * OROW + ch * 16);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Prefill, head dim 128, 64 queries per wave (r02): workgroup = 4 waves = 256 queries of one (batch, head), ONE workgroup per CU,
+// each wave alone on its SIMD with the whole 512-entry register file (O^T of its two 32-query blocks: 128 accumulator
+// registers).  The same LDS image, staging, swizzle, S^T = K.Q^T / O^T += V^T.P^T operand trick and max-deferred softmax as
+// attn_prefill_kernel; what changes is who hides whom.  With two independent 4-wave workgroups per CU the two waves of a SIMD
+// competed for its single vector-issue port and the younger one ran 3670 cycles per tile against the older one's 2566
+// (profiles/r01_attn_probe.txt): 68 % of the matrix pipe inside the loop.  Here one wave carries BOTH chains of two query
+// blocks and interleaves them itself:
+//   phase 1  S'^T(t+1) of block 0 (16 MFMAs), then of block 1 (16 MFMAs) with the first half of block 0's softmax (mask, max,
+//            16 exp2 in place) in their shadow;
+//   phase 2  O^T += V^T . P^T(t) of both blocks (32 MFMAs; every V^T fragment feeds two MFMAs) with the rest of the softmax of
+//            tile t+1 in their shadow (block 0: 16 exp2 + packs; block 1: everything).
+// K and V fragments are read once per tile and wave for 64 queries (half the LDS fragment traffic per flop), the K/V tiles are
+// staged once per 256 queries (half the DMA pieces per flop), and one barrier per tile serves twice the work.
+// ------------------------------------------------------------------------------------------
+constexpr int A2_BQ = 256;
+constexpr int A2_LDS = 6 * AT_TILE;     // 3-deep ring of {K, V} tile pairs: 96 KiB
+
+#ifndef V3D_A64_ABL
+#define V3D_A64_ABL 0     // tools/probes/attn64_probe.hip: bit 0 no softmax pieces, 1 no score MFMAs, 2 no P.V MFMAs, 3 no K reads, 4 no V reads, 5 no DMA
+#endif
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_prefill64_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma32<T>;
+  constexpr int D = 128, KS = 8, DT = 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, h = lane >> 5;
+  const int qt = (int)gridDim.y - 1 - (int)blockIdx.y;      // heaviest (last, causal) query tiles first, as attn_prefill_kernel
+  const int head = blockIdx.x, b = blockIdx.z;
+  const int hk = head / p.group;
+  const int q0 = qt * A2_BQ;
+
+  const uint16_t* Q = (const uint16_t*)p.q + b * p.bsq + (int64_t)head * p.hsq;
+  const uint16_t* K = (const uint16_t*)p.k + b * p.bsk + (int64_t)hk * p.hsk;
+  const uint16_t* V = (const uint16_t*)p.v + b * p.bsk + (int64_t)hk * p.hsk;
+
+  // ---- Q fragments of the wave's two 32-query blocks: B operand, lane (q, h) holds c * Q[q][16ks + 8h .. +8) ----
+  int qi[2];
+  Frag16 qf[2][KS];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    qi[blk] = q0 + wave * 64 + blk * 32 + ql;
+    const int qi_ld = qi[blk] < p.Sq ? qi[blk] : p.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(Q + (int64_t)qi_ld * p.ldq + ks * 16 + h * 8);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = vec_get<T>(raw, j) * p.scale_log2;
+      qf[blk][ks].u = vec_pack<T>(f);
+      asm volatile("" : "+a"(qf[blk][ks].i4));       // from here on the fragment LIVES in the accumulator half (64 registers)
+    }
+  }
+
+  auto qk_mfma = [&](f32x16& acc, const v4i& a, const v4i& b_) {
+    if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t))
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_));
+    else
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b_));
+  };
+  auto pv_mfma = [&](f32x16& acc, const v4i& a, const v4i& b_) {
+    if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t))
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b_));
+    else
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b_));
+  };
+  // ---- tile counts ----
+  const int n_tiles_all = (p.Sk + AT_BKV - 1) / AT_BKV;
+  int n_tiles = n_tiles_all;           // tiles the workgroup stages
+  int n_wave = n_tiles_all;            // tiles THIS wave computes (a causal wave stops at its last query's tile)
+  if (CAUSAL) {
+    const int last_q = q0 + A2_BQ - 1 < p.Sq ? q0 + A2_BQ - 1 : p.Sq - 1;
+    const int t = (p.q_pos0 + last_q) / AT_BKV + 1;
+    n_tiles = t < n_tiles_all ? t : n_tiles_all;
+    const int tw = (p.q_pos0 + q0 + wave * 64 + 63) / AT_BKV + 1;
+    n_wave = tw < n_tiles ? tw : n_tiles;
+  }
+
+  // ---- KV staging by LDS-DMA (as attn_prefill_kernel): wave w stages rows [16w, 16w+16) of a tile ----
+  const int srow = lane >> 4;
+  const int st_row0 = wave * 16 + srow;
+  const int st_chunk0 = (lane & 15) ^ (srow << 2);
+  const unsigned ldk_b = (unsigned)p.ldk * 2u, ldv_b = (unsigned)p.ldv * 2u;
+  auto stage = [&](const uint16_t* src, unsigned ld_b, char* dst, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = t * AT_BKV + st_row0 + 4 * i;
+      key = key < p.Sk ? key : p.Sk - 1;        // tail keys are masked in the scores
+      const int chunk = st_chunk0 ^ i;
+      glds16a((const char*)src + ((unsigned)key * ld_b + (unsigned)chunk * 16u), dst + i * 4 * AT_ROW);
+    }
+  };
+  auto stage_k = [&](int buf, int t) { stage(K, ldk_b, smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW, t); };
+  auto stage_v = [&](int buf, int t) { stage(V, ldv_b, smem + buf * 2 * AT_TILE + AT_TILE + (wave * 16) * AT_ROW, t); };
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int k_sw = kv_swz(ql);
+  const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int v_chunk_lo = 2 * (g & 1) + (pp >> 1);
+  const int v_byte = 8 * (pp & 1);
+  const int v_row0 = 4 * h + qq;
+  const int v_sw0 = kv_swz(v_row0), v_sw1 = kv_swz(v_row0 + 8);
+  const unsigned kaddr0_ = lds_base + ql * AT_ROW + ((h ^ k_sw) << 4);
+  const unsigned vaddr0_ = lds_base + AT_TILE + v_row0 * AT_ROW + v_byte + ((v_chunk_lo ^ v_sw0) << 4);
+  const unsigned vaddr1_ = lds_base + AT_TILE + (v_row0 + 8) * AT_ROW + v_byte + ((v_chunk_lo ^ v_sw1) << 4);
+
+  f32x16 o[2][DT];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[blk][i][r] = 0.f;
+  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+  const int q_pos[2] = {p.q_pos0 + qi[0], p.q_pos0 + qi[1]};
+  const int blk_first_pos[2] = {p.q_pos0 + q0 + wave * 64, p.q_pos0 + q0 + wave * 64 + 32};
+
+  // 3-deep ring of {K tile, V tile} pairs (96 KiB): tile t lives in buffer t % 3.  One wave per SIMD has no partner to hide a
+  // DMA wait, so K is staged THREE tiles ahead and V two, and the step-end wait is counted (vmcnt(8): what was issued this step
+  // stays in flight across the barrier).  Buffer offsets are run-time values added to the per-lane fragment addresses.
+#define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((kaddr0 ^ ((ks) << 5)) + kb), "i"(imm))
+#define V3D_KW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+  // Every MFMA of this kernel is inline asm with explicit register classes: the scores S'^T in VGPRs (the softmax reads them), the Q
+  // fragments and O^T in the accumulator half.  hipcc does not see an MFMA in an asm statement, so the hazards it would pad are
+  // padded by hand: V3D_MFMA_TO_VALU before VALU reads of MFMA results, V3D_VALU_TO_MFMA after VALU writes of MFMA operands.
+#define V3D_KM(B, f, i, kt, ks) qk_mfma(s[B][kt], f[i], qf[B][ks].i4)
+#define V3D_MFMA_TO_VALU() asm volatile("s_nop 15\n\ts_nop 7" ::: "memory")
+#define V3D_VALU_TO_MFMA() asm volatile("s_nop 3" ::: "memory")
+  v4i ka_[4], kc_[4];
+  auto qk_fill = [&](unsigned kb) {
+    constexpr int KB = 0;
+    auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+    V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
+    V3D_KR(kc[0], 4, KB); V3D_KR(kc[1], 5, KB); V3D_KR(kc[2], 6, KB); V3D_KR(kc[3], 7, KB);
+  };
+  // S'^T = K . (cQ)^T - m_run of ONE block for the tile in ring buffer KB (16 MFMAs); `refill` re-issues the first ring-full
+  // of K fragments for the other block's pass over the same tile.
+  auto qk_run = [&](unsigned kb, auto blk_c, auto refill_c, f32x16 (&s)[2][2]) {
+    constexpr int KB = 0;
+    constexpr int B = decltype(blk_c)::value;
+    constexpr bool REFILL = decltype(refill_c)::value != 0;
+    auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+    const float init = -m_run[B];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[B][kt][r] = init;
+    asm volatile("" : "+v"(s[B][0]), "+v"(s[B][1]));      // the initialisation is complete before the first asm MFMA reads it
+    V3D_VALU_TO_MFMA();
+    V3D_KW(4, ka); V3D_KM(B, ka, 0, 0, 0); V3D_KM(B, ka, 1, 0, 1); V3D_KM(B, ka, 2, 0, 2); V3D_KM(B, ka, 3, 0, 3);
+    V3D_KR(ka[0], 0, KB + 8192); V3D_KR(ka[1], 1, KB + 8192); V3D_KR(ka[2], 2, KB + 8192); V3D_KR(ka[3], 3, KB + 8192);
+    V3D_KW(4, kc); V3D_KM(B, kc, 0, 0, 4); V3D_KM(B, kc, 1, 0, 5); V3D_KM(B, kc, 2, 0, 6); V3D_KM(B, kc, 3, 0, 7);
+    V3D_KR(kc[0], 4, KB + 8192); V3D_KR(kc[1], 5, KB + 8192); V3D_KR(kc[2], 6, KB + 8192); V3D_KR(kc[3], 7, KB + 8192);
+    V3D_KW(4, ka); V3D_KM(B, ka, 0, 1, 0); V3D_KM(B, ka, 1, 1, 1); V3D_KM(B, ka, 2, 1, 2); V3D_KM(B, ka, 3, 1, 3);
+    if constexpr (REFILL) { V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB); V3D_KW(4, kc); }
+    else { V3D_KW(0, kc); }
+    V3D_KM(B, kc, 0, 1, 4); V3D_KM(B, kc, 1, 1, 5); V3D_KM(B, kc, 2, 1, 6); V3D_KM(B, kc, 3, 1, 7);
+    if constexpr (REFILL) { V3D_KR(kc[0], 4, KB); V3D_KR(kc[1], 5, KB); V3D_KR(kc[2], 6, KB); V3D_KR(kc[3], 7, KB); }
+  };
+
+  // softmax part 1 of block B for tile t: mask (diagonal / tail tiles only), max, the (rare) raise of the running maximum.
+  auto softmax_prep = [&](auto blk_c, f32x16 (&s)[2][2], int t) -> float {
+    constexpr int B = decltype(blk_c)::value;
+    const int kv0 = t * AT_BKV;
+    const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > blk_first_pos[B]) || (kv0 + AT_BKV > p.Sk);
+    if (need_mask) {
+      int last = p.Sk - 1;
+      if (CAUSAL) last = q_pos[B] < last ? q_pos[B] : last;
+      const int limit = last - kv0 - 4 * h;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s[B][kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : s[B][kt][r];
+    }
+    float mx = fmaxf(s[B][0][0], s[B][1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[B][0][r]), s[B][1][r]);
+    float alpha = 1.0f;
+    if (t == 0 || __any(mx > AT_RAISE)) {
+      const float mp = fmaxf(mx, __shfl_xor(mx, 32));
+      float d = t == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);       // per-lane decision: see attn_prefill_kernel
+      d = mp == -INFINITY ? 0.f : d;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[B][kt][r] -= d;
+      m_run[B] += d;
+      alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+    }
+    return alpha;
+  };
+  // quarter i of block B: 8 scores -> exp2 -> one P^T fragment + row-sum share
+  auto softmax_quarter = [&](auto blk_c, const f32x16 (&s)[2][2], int i, Frag16& pf, float& ls0, float& ls1) {
+    constexpr int B = decltype(blk_c)::value;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(s[B][i >> 1][8 * (i & 1) + j]);
+    ls0 += (e[0] + e[1]) + (e[2] + e[3]);
+    ls1 += (e[4] + e[5]) + (e[6] + e[7]);
+    pf.u = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
+  };
+
+#define V3D_VR(f, dt, VB) { \
+  const unsigned a0 = (vaddr0 ^ ((dt) << 6)) + vb, a1 = (vaddr1 ^ ((dt) << 6)) + vb; \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[0]) : "v"(a0), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[1]) : "v"(a1), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[2]) : "v"(a0), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[3]) : "v"(a1), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[4]) : "v"(a0), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[5]) : "v"(a1), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[6]) : "v"(a0), "i"(VB + 12288)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[7]) : "v"(a1), "i"(VB + 12288)); }
+#define V3D_VW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory")
+
+  // COARSE step (the wave's first and last tiles, where some of {scores, P.V, staging} are absent): tile t's P.V of both blocks,
+  // tile t+1's scores and softmax, every part guarded.  PAR = t & 1: V(t) in ring buffer PAR,
+  // K(t+1) in buffer 1 - PAR.  pc = P^T fragments of tile t (both blocks), pn receives those of tile t+1.
+  auto cstep = [&](int t, Frag16 (&pc0)[4], Frag16 (&pc1)[4], Frag16 (&pn0)[4], Frag16 (&pn1)[4]) {
+    constexpr bool FULL = false;                               // the guarded form: first / last tiles of a wave only
+    constexpr int VB = 0;
+    const unsigned vb = (unsigned)(t % 3) * (2 * AT_TILE), kbn = (unsigned)((t + 1) % 3) * (2 * AT_TILE);
+    const unsigned vaddr0 = vaddr0_, vaddr1 = vaddr1_;
+    const bool do_qk = FULL || t + 1 < n_wave, do_pv = FULL || t < n_wave;          // wave-uniform
+    f32x16 s[2][2];
+    float alpha0 = 1.0f, alpha1 = 1.0f, ls00 = 0.f, ls01 = 0.f, ls10 = 0.f, ls11 = 0.f;
+    if (do_qk) qk_fill(kbn);
+    if (FULL || t + 3 < n_tiles) stage_k((t + 3) % 3, t + 3);  // K of tile t was consumed one step ago
+    if (FULL || t + 2 < n_tiles) stage_v((t + 2) % 3, t + 2);  // V of tile t - 1 was consumed one step ago
+    // ---- phase 1: scores of block 0, then of block 1 with the head of block 0's softmax in their shadow
+    if (do_qk) {
+      qk_run(kbn, IntC<0>{}, IntC<1>{}, s);
+      V3D_MFMA_TO_VALU();
+      alpha0 = softmax_prep(IntC<0>{}, s, t + 1);
+      softmax_quarter(IntC<0>{}, s, 0, pn0[0], ls00, ls01);
+      softmax_quarter(IntC<0>{}, s, 1, pn0[1], ls00, ls01);
+      qk_run(kbn, IntC<1>{}, IntC<0>{}, s);
+    }
+    // (block 1's scores are first read by VALU after the first two P.V groups: 16 MFMAs later)
+    // ---- phase 2: P.V of both blocks, the rest of the softmax between the MFMA groups
+    v2i va[8], vc[8];
+    if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    // O^T lives in the ACCUMULATOR half of the register file for the whole kernel: the P.V MFMAs are inline asm with "+a"
+    // operands (hipcc otherwise keeps every MFMA in the VGPR form and shuttles ~650 values per tile between the two halves)
+    auto mmav = [&](const v2i* f, int dt) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        v4i vf = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
+        asm volatile("s_nop 1" : "+v"(vf));           // the fragment is assembled (v_mov) before the asm MFMA reads it
+        pv_mfma(o[0][dt], vf, pc0[s4].i4);
+        pv_mfma(o[1][dt], vf, pc1[s4].i4);
+      }
+    };
+    if (do_pv) { V3D_VW(8, va); mmav(va, 0); V3D_VR(va, 2, VB) }
+    if (do_qk) {
+      softmax_quarter(IntC<0>{}, s, 2, pn0[2], ls00, ls01);
+      softmax_quarter(IntC<0>{}, s, 3, pn0[3], ls00, ls01);
+      asm volatile("" : "+v"(pn0[2].i4), "+v"(pn0[3].i4), "+v"(ls00), "+v"(ls01));
+    }
+    if (do_pv) { V3D_VW(8, vc); mmav(vc, 1); V3D_VR(vc, 3, VB) }
+    if (do_qk) {
+      alpha1 = softmax_prep(IntC<1>{}, s, t + 1);
+      softmax_quarter(IntC<1>{}, s, 0, pn1[0], ls10, ls11);
+      asm volatile("" : "+v"(pn1[0].i4), "+v"(ls10), "+v"(ls11));
+    }
+    if (do_pv) { V3D_VW(8, va); mmav(va, 2); }
+    if (do_qk) {
+      softmax_quarter(IntC<1>{}, s, 1, pn1[1], ls10, ls11);
+      softmax_quarter(IntC<1>{}, s, 2, pn1[2], ls10, ls11);
+      asm volatile("" : "+v"(pn1[1].i4), "+v"(pn1[2].i4), "+v"(ls10), "+v"(ls11));
+    }
+    if (do_pv) { V3D_VW(0, vc); mmav(vc, 3); }
+    if (do_qk) {
+      softmax_quarter(IntC<1>{}, s, 3, pn1[3], ls10, ls11);
+      // wave-uniform, rare: the maximum moved, bring O and l to the new reference.  O sits in the accumulator half: the asm pins
+      // keep its read-modify-write INSIDE the cold branch (hipcc otherwise hoists 128 v_accvgpr_read into every iteration)
+      if (__any(alpha0 != 1.0f)) {
+        V3D_MFMA_TO_VALU();
+#pragma unroll
+        for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[0][i]));
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[0][i][r] *= alpha0;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[0][i]));
+        V3D_VALU_TO_MFMA();
+        l_run[0] *= alpha0;
+      }
+      if (__any(alpha1 != 1.0f)) {
+        V3D_MFMA_TO_VALU();
+#pragma unroll
+        for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[1][i]));
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[1][i][r] *= alpha1;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[1][i]));
+        V3D_VALU_TO_MFMA();
+        l_run[1] *= alpha1;
+      }
+      l_run[0] += ls00 + ls01;
+      l_run[1] += ls10 + ls11;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // tiles t+1 (V) / t+2 (K) landed and visible; everyone is done with tile t
+  };
+
+
+  // ---- the steady-state step, hand-interleaved: 64 MFMAs, one softmax slice after every second MFMA ----
+  // MFMA order: S'^T(t+1) of block 0 (16), of block 1 (16), then O^T += V^T.P^T(t) for both blocks (32, a V^T fragment feeds two).
+  // Softmax of a block and tile = 16 slices: 0-1 mask / max / (rare) raise; 2-9 four exp2 each, in place; 10-13 pack one P^T
+  // fragment each; 14-15 idle.  Placement (MFMA pairs 0..31 of step t):
+  //   pairs  0.. 7 (scores of block 0)    block 1, tile t,   slices 8-15  -> P_1(t), consumed from pair 16 on
+  //   pairs  8..15 (scores of block 1)    block 0, tile t+1, slices 0-7
+  //   pairs 16..23 (P.V, d tiles 0-1)     block 0, tile t+1, slices 8-15  -> P_0(t+1) (second buffer: P_0(t) is being read)
+  //   pairs 24..31 (P.V, d tiles 2-3)     block 1, tile t+1, slices 0-7   (its scores stay in registers into the next step)
+  // so that every MFMA gap carries ~3 VALU instructions, one v_exp_f32 among them, and neither pipe waits for the other.
+  f32x16 s0[2], s1[2];                       // scores of block 0 / block 1 (block 1's live across the step boundary)
+  float a0_ = 1.0f, a1_ = 1.0f, ls0a = 0.f, ls0b = 0.f, ls1a = 0.f, ls1b = 0.f, mx0 = 0.f, mx1 = 0.f, cy0 = 0.f, cy1 = 0.f;
+  // One wave per SIMD issues in order: a dependent MFMA blocks everything behind it, so the softmax has to sit in EVERY MFMA gap in
+  // pieces of <= 24 issue cycles (an MFMA holds the vector issue for 8 of its 32; v_exp_f32 costs 8, plain VALU 4).  The softmax of a
+  // block and tile is 32 half-slices: 0-3 mask / max / (rare) raise; 4-19 two exp2 each, in place, + their row sum; 20-27 pack half
+  // a P^T fragment each; 28-31 re-arm eight score registers each with -m for the block's next tile.
+  auto sm = [&](auto blk_c, auto h_c, auto masked_c, f32x16 (&sc)[2], Frag16 (&dst)[4], int tt, float& alpha, float& lsa, float& lsb, float& mx,
+                float& carry) {
+    constexpr int B = decltype(blk_c)::value, HH = decltype(h_c)::value;
+    if constexpr ((V3D_A64_ABL & 1) != 0) { __builtin_amdgcn_sched_barrier(0); return; }
+    if constexpr (HH < 4) {
+      constexpr int kt = HH >> 1, base = 8 * (HH & 1);
+      if constexpr (HH == 0) {
+        const int kv0 = tt * AT_BKV;
+        const bool need_mask = decltype(masked_c)::value && ((CAUSAL && kv0 + AT_BKV - 1 > blk_first_pos[B]) || (kv0 + AT_BKV > p.Sk));
+        if (need_mask) {
+          int last = p.Sk - 1;
+          if (CAUSAL) last = q_pos[B] < last ? q_pos[B] : last;
+          const int limit = last - kv0 - 4 * h;
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[k2][r] = (k2 * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : sc[k2][r];
+        }
+        mx = sc[0][0];
+      }
+#pragma unroll
+      for (int r = (HH == 0 ? 1 : 0); r < 8; ++r) mx = fmaxf(mx, sc[kt][base + r]);
+      if constexpr (HH == 3) {
+        alpha = 1.0f;
+        if (tt == 0 || __any(mx > AT_RAISE)) {
+          const float mp = fmaxf(mx, __shfl_xor(mx, 32));
+          float d = tt == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);       // per-lane decision: see attn_prefill_kernel
+          d = mp == -INFINITY ? 0.f : d;
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[k2][r] -= d;
+          m_run[B] += d;
+          alpha = tt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+        }
+        asm volatile("" : "+v"(alpha), "+v"(mx));
+      } else {
+        asm volatile("" : "+v"(mx));              // (the pins materialise a piece's results HERE, in the order of the asm MFMAs:
+      }                                           //  IR-level sinking otherwise moves the arithmetic to its first use)
+    } else if constexpr (HH < 20) {
+      constexpr int e = HH - 4, q = e >> 2, hf = (e >> 1) & 1, half = e & 1, kt = q >> 1, base = 8 * (q & 1) + 4 * hf + 2 * half;
+      const float e0 = __builtin_amdgcn_exp2f(sc[kt][base]), e1 = __builtin_amdgcn_exp2f(sc[kt][base + 1]);
+      sc[kt][base] = e0; sc[kt][base + 1] = e1;
+      if constexpr (half == 0) {
+        carry = e0 + e1;
+        asm volatile("" : "+v"(sc[kt]), "+v"(carry));
+      } else {
+        if (hf == 0) lsa += carry + (e0 + e1); else lsb += carry + (e0 + e1);
+        asm volatile("" : "+v"(sc[kt]), "+v"(lsa), "+v"(lsb));
+      }
+    } else if constexpr (HH < 28) {
+      constexpr int c = HH - 20, q = c >> 1, half = c & 1, kt = q >> 1, base = 8 * (q & 1) + 4 * half;
+      const unsigned w0 = pack2<T>(sc[kt][base + 0], sc[kt][base + 1]), w1 = pack2<T>(sc[kt][base + 2], sc[kt][base + 3]);
+      if constexpr (half == 0) { dst[q].u.x = w0; dst[q].u.y = w1; } else { dst[q].u.z = w0; dst[q].u.w = w1; }
+      if constexpr (half == 1) asm volatile("" : "+v"(dst[q].i4));
+      else asm volatile("" : "+v"(dst[q].u.x), "+v"(dst[q].u.y));
+    } else {
+      constexpr int i = HH - 28, kt = i >> 1, base = 8 * (i & 1);
+      const float init = -m_run[B];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {              // asm moves: placed here, and written straight into the MFMA's accumulator tuple
+        float x;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(init));
+        sc[kt][base + r] = x;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);       // the piece stays in this MFMA gap
+  };
+#define V3D_H1(HH, TT) sm(IntC<1>{}, IntC<HH>{}, IntC<0>{}, s1, p1, TT, a1_, ls1a, ls1b, mx1, cy1)
+#define V3D_H0(HH, TT) sm(IntC<0>{}, IntC<HH>{}, IntC<0>{}, s0, pn0, TT, a0_, ls0a, ls0b, mx0, cy0)
+#define V3D_H1M(HH, TT) sm(IntC<1>{}, IntC<HH>{}, IntC<1>{}, s1, p1, TT, a1_, ls1a, ls1b, mx1, cy1)
+#define V3D_H0M(HH, TT) sm(IntC<0>{}, IntC<HH>{}, IntC<1>{}, s0, pn0, TT, a0_, ls0a, ls0b, mx0, cy0)
+#if (V3D_A64_ABL & 2)
+#define V3D_QM(S, f, i, kt, B, ks)
+#else
+#define V3D_QM(S, f, i, kt, B, ks) qk_mfma(S[kt], f[i], qf[B][ks].i4)
+#endif
+#if (V3D_A64_ABL & 4)
+#define V3D_PVM(acc, vf, pf)
+#else
+#define V3D_PVM(acc, vf, pf) pv_mfma(acc, vf, pf)
+#endif
+  // four score MFMAs of one K fragment group, a piece of block OB's softmax after each
+#define V3D_QM4(S, f, kt, B, ks0, HM, h0, TT) \
+    V3D_QM(S, f, 0, kt, B, ks0 + 0); HM(h0 + 0, TT); V3D_QM(S, f, 1, kt, B, ks0 + 1); HM(h0 + 1, TT); \
+    V3D_QM(S, f, 2, kt, B, ks0 + 2); HM(h0 + 2, TT); V3D_QM(S, f, 3, kt, B, ks0 + 3); HM(h0 + 3, TT);
+  // the two P.V MFMAs (q-blocks 0 / 1) that share one V^T fragment, a piece after each
+#define V3D_PV2(f, dt, s4, HM, h0, TT) { v4i vf = {f[2 * (s4)][0], f[2 * (s4)][1], f[2 * (s4) + 1][0], f[2 * (s4) + 1][1]}; \
+    asm volatile("s_nop 0" : "+v"(vf)); V3D_PVM(o[0][dt], vf, pc0[s4].i4); HM(h0 + 0, TT); V3D_PVM(o[1][dt], vf, p1[s4].i4); HM(h0 + 1, TT); }
+#define V3D_PV8(f, dt, HM, h0, TT) V3D_PV2(f, dt, 0, HM, h0, TT) V3D_PV2(f, dt, 1, HM, h0 + 2, TT) V3D_PV2(f, dt, 2, HM, h0 + 4, TT) V3D_PV2(f, dt, 3, HM, h0 + 6, TT)
+  Frag16 p1[4];                              // P^T of block 1 (single buffer: written in gaps 4..11, read from MFMA 32 on)
+  // ---- the steady-state step: 64 MFMAs, a softmax piece in every gap ----
+  //   MFMAs  0..15 (scores of block 0, tile t+1)   block 1, tile t,   pieces 16..31  -> P_1(t), consumed from MFMA 32 on
+  //   MFMAs 16..31 (scores of block 1, tile t+1)   block 0, tile t+1, pieces  0..15
+  //   MFMAs 32..47 (P.V of tile t, d tiles 0-1)    block 0, tile t+1, pieces 16..31  -> P_0(t+1) (second buffer: P_0(t) is being read)
+  //   MFMAs 48..63 (P.V of tile t, d tiles 2-3)    block 1, tile t+1, pieces  0..15  (its scores stay in registers into the next step)
+  auto fstep = [&](int t, unsigned kb, unsigned vb, int bk3, int bv2, Frag16 (&pc0)[4], Frag16 (&pn0)[4]) {
+    constexpr int VB = 0, KB = 0;             // kb / vb: byte offsets of the ring buffers of K(t+1) / V(t); bk3 / bv2: buffers of K(t+3) / V(t+2)
+    const unsigned vaddr0 = vaddr0_, vaddr1 = vaddr1_, kaddr0 = kaddr0_;
+    auto& ka = ka_; auto& kc = kc_;
+#if (V3D_A64_ABL & 8)
+#define V3D_FKR(dst, ks, imm)
+#else
+#define V3D_FKR(dst, ks, imm) V3D_KR(dst, ks, imm)
+    qk_fill(kb);
+#endif
+#if (V3D_A64_ABL & 16)
+#define V3D_FVR(f, dt, VB)
+#else
+#define V3D_FVR(f, dt, VB) V3D_VR(f, dt, VB)
+#endif
+#if !(V3D_A64_ABL & 32)
+    stage_k(bk3, t + 3);
+    stage_v(bv2, t + 2);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    V3D_KW(4, ka); V3D_QM4(s0, ka, 0, 0, 0, V3D_H1, 16, t)
+    V3D_FKR(ka[0], 0, KB + 8192); V3D_FKR(ka[1], 1, KB + 8192); V3D_FKR(ka[2], 2, KB + 8192); V3D_FKR(ka[3], 3, KB + 8192);
+    l_run[1] += ls1a + ls1b;                   // tile t's row sums of block 1 are complete (its rescale happened a step ago)
+    ls1a = 0.f; ls1b = 0.f;
+    V3D_KW(4, kc); V3D_QM4(s0, kc, 0, 0, 4, V3D_H1, 20, t)
+    V3D_FKR(kc[0], 4, KB + 8192); V3D_FKR(kc[1], 5, KB + 8192); V3D_FKR(kc[2], 6, KB + 8192); V3D_FKR(kc[3], 7, KB + 8192);
+    V3D_KW(4, ka); V3D_QM4(s0, ka, 1, 0, 0, V3D_H1, 24, t)
+    V3D_FKR(ka[0], 0, KB); V3D_FKR(ka[1], 1, KB); V3D_FKR(ka[2], 2, KB); V3D_FKR(ka[3], 3, KB);
+    V3D_KW(4, kc); V3D_QM4(s0, kc, 1, 0, 4, V3D_H1, 28, t)
+    V3D_FKR(kc[0], 4, KB); V3D_FKR(kc[1], 5, KB); V3D_FKR(kc[2], 6, KB); V3D_FKR(kc[3], 7, KB);
+    V3D_KW(4, ka); V3D_QM4(s1, ka, 0, 1, 0, V3D_H0, 0, t + 1)
+    V3D_FKR(ka[0], 0, KB + 8192); V3D_FKR(ka[1], 1, KB + 8192); V3D_FKR(ka[2], 2, KB + 8192); V3D_FKR(ka[3], 3, KB + 8192);
+    V3D_KW(4, kc); V3D_QM4(s1, kc, 0, 1, 4, V3D_H0, 4, t + 1)
+    V3D_FKR(kc[0], 4, KB + 8192); V3D_FKR(kc[1], 5, KB + 8192); V3D_FKR(kc[2], 6, KB + 8192); V3D_FKR(kc[3], 7, KB + 8192);
+    v2i va[8], vc[8];
+    V3D_KW(4, ka); V3D_QM4(s1, ka, 1, 1, 0, V3D_H0, 8, t + 1)
+    V3D_FVR(va, 0, VB)
+    V3D_KW(8, kc); V3D_QM4(s1, kc, 1, 1, 4, V3D_H0, 12, t + 1)
+    V3D_FVR(vc, 1, VB)
+    V3D_VW(8, va); V3D_PV8(va, 0, V3D_H0, 16, t + 1)
+    V3D_FVR(va, 2, VB)
+    V3D_VW(8, vc); V3D_PV8(vc, 1, V3D_H0, 24, t + 1)
+    V3D_FVR(vc, 3, VB)
+    V3D_VW(8, va); V3D_PV8(va, 2, V3D_H1, 0, t + 1)
+    V3D_VW(0, vc); V3D_PV8(vc, 3, V3D_H1, 8, t + 1)
+    // ---- rare: the maximum of a block moved - bring its O and l to the new reference (O sits in the accumulator half: the
+    //      asm pins keep the read-modify-write inside the cold branch)
+    if (__any(a0_ != 1.0f)) {
+      V3D_MFMA_TO_VALU();
+#pragma unroll
+      for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[0][i]));
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[0][i][r] *= a0_;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[0][i]));
+      V3D_VALU_TO_MFMA();
+      l_run[0] *= a0_;
+    }
+    if (__any(a1_ != 1.0f)) {
+      V3D_MFMA_TO_VALU();
+#pragma unroll
+      for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[1][i]));
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[1][i][r] *= a1_;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) asm volatile("" : "+a"(o[1][i]));
+      V3D_VALU_TO_MFMA();
+      l_run[1] *= a1_;
+    }
+    l_run[0] += ls0a + ls0b;
+    ls0a = 0.f; ls0b = 0.f;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // K(t+2), V(t+1) (issued a step ago) landed; K(t+3), V(t+2) stay in flight
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: tiles 0 (K, V) and 1 (K) in flight; scores of tile 0 for both blocks; block 0's softmax complete (P_0(0)),
+  //      block 1's slices 0..7 (the steady-state step finishes them) ----
+#ifdef V3D_ATTN_PROF
+  const unsigned long long blk_rt0 = __builtin_amdgcn_s_memrealtime(), blk_c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long blk_c1 = 0, blk_c2 = 0;
+#endif
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (n_tiles > 1) { stage_k(1, 1); stage_v(1, 1); }
+  if (n_tiles > 2) stage_k(2, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Frag16 pa0[4], pb0[4], p1b[4];
+  {
+    f32x16 sp[2][2];
+    qk_fill(0u);
+    qk_run(0u, IntC<0>{}, IntC<1>{}, sp);
+    qk_run(0u, IntC<1>{}, IntC<0>{}, sp);
+    V3D_MFMA_TO_VALU();
+    s0[0] = sp[0][0]; s0[1] = sp[0][1]; s1[0] = sp[1][0]; s1[1] = sp[1][1];
+  }
+  {
+    auto& pn0 = pa0;
+#define V3D_RUN4(HM, h0, TT) HM(h0, TT); HM(h0 + 1, TT); HM(h0 + 2, TT); HM(h0 + 3, TT);
+    V3D_H0M(0, 0); V3D_H0(1, 0); V3D_H0(2, 0); V3D_H0(3, 0);
+    V3D_RUN4(V3D_H0, 4, 0) V3D_RUN4(V3D_H0, 8, 0) V3D_RUN4(V3D_H0, 12, 0) V3D_RUN4(V3D_H0, 16, 0) V3D_RUN4(V3D_H0, 20, 0) V3D_RUN4(V3D_H0, 24, 0)
+    V3D_RUN4(V3D_H0, 28, 0)
+    l_run[0] = ls0a + ls0b;
+    ls0a = 0.f; ls0b = 0.f;
+    V3D_H1M(0, 0); V3D_H1(1, 0); V3D_H1(2, 0); V3D_H1(3, 0);
+    V3D_RUN4(V3D_H1, 4, 0) V3D_RUN4(V3D_H1, 8, 0) V3D_RUN4(V3D_H1, 12, 0)
+  }
+  {
+    // steady-state steps need tiles t+3 (K) and t+2 (V) to exist and the wave to compute tile t+1; in pairs (P_0 double buffer)
+    // ... and tile t + 1 to need no mask for either q-block of the wave (no diagonal, no Sk tail)
+    int n_plain = p.Sk / AT_BKV;
+    if (CAUSAL) { const int d = (blk_first_pos[0] + 1) / AT_BKV; n_plain = d < n_plain ? d : n_plain; }
+    int n_full = n_tiles - 3 < n_wave - 1 ? n_tiles - 3 : n_wave - 1;
+    n_full = (n_full < n_plain - 1 ? n_full : n_plain - 1);
+    n_full = n_full < 0 ? 0 : n_full & ~1;
+    int t = 0;
+    int bk = 1, bv = 0;                         // ring buffers of K(t+1), V(t)
+#ifdef V3D_ATTN_PROF
+    blk_c1 = __builtin_amdgcn_s_memtime();
+#endif
+    for (; t < n_full; t += 2) {
+      fstep(t, (unsigned)bk * (2 * AT_TILE), (unsigned)bv * (2 * AT_TILE), bv, bk == 2 ? 0 : bk + 1, pa0, pb0);       // K(t+3) -> buffer of tile t; V(t+2) -> bk + 1
+      bk = bk == 2 ? 0 : bk + 1; bv = bv == 2 ? 0 : bv + 1;
+      fstep(t + 1, (unsigned)bk * (2 * AT_TILE), (unsigned)bv * (2 * AT_TILE), bv, bk == 2 ? 0 : bk + 1, pb0, pa0);
+      bk = bk == 2 ? 0 : bk + 1; bv = bv == 2 ? 0 : bv + 1;
+    }
+#ifdef V3D_ATTN_PROF
+    blk_c2 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+      const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+      if (bid < 4096) { g_attn_prof[0 * 4096 + bid] = blk_c1 - blk_c0; g_attn_prof[1 * 4096 + bid] = blk_c2 - blk_c1; g_attn_prof[2 * 4096 + bid] = (unsigned long long)n_full; }
+    }
+#endif
+    // (a coarse step reads only K(t+1) / V(t), which the previous step's counted wait + barrier already made visible, and ends
+    //  with vmcnt(0): waves may leave the steady state at different t - every step, fine or coarse, has exactly one barrier)
+    // leave the pipeline: finish block 1's softmax of tile t, then the guarded coarse steps for the wave's last tiles
+    {
+      auto& pn0 = pb0;      // (unused by slices 8..15 of block 1)
+      (void)pn0;
+      V3D_RUN4(V3D_H1, 16, t) V3D_RUN4(V3D_H1, 20, t) V3D_RUN4(V3D_H1, 24, t)
+      l_run[1] += ls1a + ls1b;
+    }
+    for (; t < n_tiles; t += 2) {
+      cstep(t, pa0, p1, pb0, p1b);
+      if (t + 1 < n_tiles) cstep(t + 1, pb0, p1b, pa0, p1);
+    }
+  }
+#undef V3D_H0
+#undef V3D_H1
+#undef V3D_H0M
+#undef V3D_H1M
+#undef V3D_RUN4
+#undef V3D_QM4
+#undef V3D_PV8
+#undef V3D_QM
+#undef V3D_PV2
+  V3D_MFMA_TO_VALU();
+  __syncthreads();
+#undef V3D_MFMA_TO_VALU
+#undef V3D_VALU_TO_MFMA
+#undef V3D_KR
+#undef V3D_KW
+#undef V3D_KM
+#undef V3D_VR
+#undef V3D_VW
+
+  // ---- normalise, transpose through LDS, store whole rows (one 32-query block at a time per wave) ----
+  constexpr int OROW = D * 2 + 16;
+  char* so = smem + wave * 32 * OROW;
+  uint16_t* O = (uint16_t*)p.o + b * p.bso + (int64_t)head * p.hso;
+  constexpr int OCH = D / 8;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const float l_tot = l_run[blk] + __shfl_xor(l_run[blk], 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = 32 * dt + 8 * r4 + 4 * h;
+        uint2 pk;
+        pk.x = pack2<T>(o[blk][dt][4 * r4 + 0] * inv, o[blk][dt][4 * r4 + 1] * inv);
+        pk.y = pack2<T>(o[blk][dt][4 * r4 + 2] * inv, o[blk][dt][4 * r4 + 3] * inv);
+        *reinterpret_cast<uint2*>(so + ql * OROW + d * 2) = pk;
+      }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own LDS writes are done (its region is private)
+#pragma unroll
+    for (int i = 0; i < (32 * OCH + 63) / 64; ++i) {
+      const int idx = i * 64 + lane;
+      const int row = idx / OCH, ch = idx - row * OCH;
+      const int q = q0 + wave * 64 + blk * 32 + row;
+      if (row < 32 && q < p.Sq && ch * 8 < p.d_out)
+        *reinterpret_cast<uint4*>(O + (int64_t)q * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(so + row * OROW + ch * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next block overwrites the region
+    __builtin_amdgcn_wave_barrier();
+  }
+#ifdef V3D_ATTN_PROF
+  if (tid == 0) {
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (bid < 4096) {
+      g_attn_blocks[4 * bid + 0] = blk_rt0;
+      g_attn_blocks[4 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+      g_attn_blocks[4 * bid + 2] = __builtin_amdgcn_s_memtime() - blk_c0;
+      g_attn_blocks[4 * bid + 3] = (unsigned long long)n_tiles;
+    }
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -870,8 +1509,33 @@ __global__ __launch_bounds__(128) void attn_decode_merge_kernel(AttnArgs p, DecR
   O[d] = from_f32<T>(lt > 0.f ? ot / lt : 0.f);
 }
 
+// V3D_ATTN64=1 opts in to attn_prefill64_kernel (one wave per SIMD, 64 queries per wave) for head dim 128 prefill; default 0 =
+// attn_prefill_kernel.  Measured (S = 6794, 28/4 heads, same box): 374 us vs 328 us - halving the LDS traffic does not pay while a
+// single in-order wave has to issue the softmax, the LDS reads and the MFMAs (tools/probes/attn64_probe.hip).
+static int attn64_mode() {
+  const char* e = getenv("V3D_ATTN64");
+  return e ? atoi(e) : 0;
+}
+
 template <typename T>
 static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t st) {
+  if (D == 128 && p.Sq >= 64 && attn64_mode() != 0) {
+    const dim3 grid64(p.Hq, (p.Sq + A2_BQ - 1) / A2_BQ, B);
+#define V3D_ATTN64(CC)                                                                                            \
+    {                                                                                                             \
+      auto k = attn_prefill64_kernel<T, CC>;                                                                      \
+      static bool done = false;                                                                                   \
+      if (!done) {                                                                                                \
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, A2_LDS);   \
+        if (e != hipSuccess) { set_error("v3d_attention: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
+        done = true;                                                                                              \
+      }                                                                                                           \
+      hipLaunchKernelGGL(k, grid64, dim3(256), A2_LDS, st, p);                                                    \
+    }
+    if (causal) V3D_ATTN64(true) else V3D_ATTN64(false)
+#undef V3D_ATTN64
+    return check_launch("v3d_attention (64 queries per wave)");
+  }
   const dim3 grid(p.Hq, (p.Sq + AT_BQ - 1) / AT_BQ, B), block(256);
 #define V3D_ATTN(DD, CC)                                                                                          \
   {                                                                                                               \
