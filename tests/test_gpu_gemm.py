@@ -127,6 +127,7 @@ def test_gemm_pingpong_tile_equals_v3_tile_bitwise(ops, kind, M, N, K, epi, monk
     kw = {"none": dict(), "bias": dict(bias=b, epilogue=ops.EPI_BIAS), "res": dict(res=r, epilogue=ops.EPI_RES),
           "gelu": dict(bias=b, epilogue=ops.EPI_BIAS_GELU_TANH), "swiglu": dict(epilogue=ops.EPI_SWIGLU)}[epi]
     outs = {}
+    monkeypatch.setenv("V3D_GEMM_STREAMK", "0")           # (a tile cut in two sums k in two runs: its own test below)
     for var in ("3", "4"):                                # force the 256 x 256 / 192 x 256 tile whatever the cost model would pick
         monkeypatch.setenv("V3D_GEMM_VARIANT", var)
         for pp in ("0", "1"):
@@ -149,3 +150,48 @@ def test_gemm_pingpong_tile_equals_v3_tile_bitwise(ops, kind, M, N, K, epi, monk
     assert torch.equal(outs["3", "1"], outs["4", "1"])    # every tile shape sums k in the same order
     if epi in ("none", "bias"):
         close(outs["4", "1"], ref_linear(a.cpu(), w.cpu(), b.cpu() if epi == "bias" else None, dt), kind)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,epi,grid", [(6794, 3584, 3584, "res", None), (6794, 3584, 2048, "bias", None), (3000, 2560, 512, "none", "16"),
+                                            (1024, 2560, 512, "gelu", "16"), (2000, 4096, 768, "swiglu", "24"), (1500, 3072, 1024, "res", "32")])
+def test_gemm_stream_k_tail_matches_whole_tile_walk(ops, kind, M, N, K, epi, grid, monkeypatch):
+    """Split-K tail of the ping-pong kernel (V3D_GEMM_STREAMK=2: wherever legal): the tiles left after the whole-tile rounds are cut
+    into 2..4 K-chunks run side by side; chunk 0 adds the others' f32 accumulators.  A cut tile is the f32 sum of 2..4 runs of k
+    instead of one: an output may differ from the whole-tile walk by the f32 rounding of those partial sums, i.e. by one rounding
+    of the 16-bit result - never more - and repeated launches agree bit for bit (fixed cuts, fixed order).  Small grids
+    (V3D_GEMM_PP_GRID) put whole-tile rounds, 2- / 3- / 4-way cuts (first, middle, last chunks) and the flag exchange into small
+    shapes; the first two cases are the decoder's o_proj shape on the full chip."""
+    g = torch.Generator().manual_seed(M + N + K)
+    dt = DT[kind]
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    r = torch.randn(M, N, generator=g).to(dt).cuda()
+    kw = {"none": dict(), "bias": dict(bias=b, epilogue=ops.EPI_BIAS), "res": dict(res=r, epilogue=ops.EPI_RES),
+          "gelu": dict(bias=b, epilogue=ops.EPI_BIAS_GELU_TANH), "swiglu": dict(epilogue=ops.EPI_SWIGLU)}[epi]
+    monkeypatch.setenv("V3D_GEMM_VARIANT", "3")
+    if grid:
+        monkeypatch.setenv("V3D_GEMM_PP_GRID", grid)
+    monkeypatch.setenv("V3D_GEMM_STREAMK", "0")
+    whole = ops.gemm(a, w, **kw)
+    monkeypatch.setenv("V3D_GEMM_STREAMK", "2")
+    cut = [ops.gemm(a, w, **kw) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(cut[0], cut[1]) and torch.equal(cut[0], cut[2])
+    assert not torch.equal(cut[0], whole) or K <= 128, "stream-K did not engage (outputs identical to the whole-tile walk)"
+    ulp = 2.0 ** (-7 if kind == "bf16" else -10)
+    wf = whole.float()
+    d = (cut[0].float() - wf).abs()
+    tiny = 4e-6 * (a.float().abs().mean() * w.float().abs().mean() * K).item() ** 0.5 * K ** 0.25   # f32 rounding of the partial sums (~|sum| 2^-22)
+    tiny = max(tiny, 1e-5)
+    if epi in ("none", "bias"):
+        bound = 1.01 * ulp * wf.abs() + tiny                                 # one rounding of the 16-bit result
+    elif epi == "res":
+        bound = 1.01 * ulp * ((wf - r.float()).abs() + wf.abs()) + tiny      # the product is rounded, then product + residual
+    else:
+        bound = 4 * ulp * (wf.abs() + wf.abs().mean())                       # the activation sees a pre-activation one ulp away
+    assert bool((d <= bound + 1e-30).all()), f"max diff {d.max().item()}"
+    assert float((d > 0).float().mean()) < 0.2            # and only a minority of outputs moves at all
+    if epi in ("none", "bias"):
+        close(cut[0], ref_linear(a.cpu(), w.cpu(), b.cpu() if epi == "bias" else None, dt), kind)

@@ -1,4 +1,4 @@
-"""A/B timing of the 256-wide GEMM schedules (V3D_GEMM_PP=0 v3 one-barrier pipeline / 1 ping-pong) on the path's shapes."""
+"""A/B timing of the ping-pong GEMM on the path's shapes: tile choice and the stream-K tail (V3D_GEMM_STREAMK 0 / 1 / 2)."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "video-3d-llm_amd"))
@@ -13,7 +13,7 @@ def run(M, N, K, epi, iters=30):
     kw = {}
     if bias is not None: kw["bias"] = bias
     if res is not None: kw["res"] = res
-    for _ in range(3): ops.gemm(a, w, epilogue=epi, out=out, **kw)
+    for _ in range(10): ops.gemm(a, w, epilogue=epi, out=out, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -24,12 +24,18 @@ S = 6794
 shapes = [("llm qkv", S, 4608, 3584, 1), ("llm o_proj", S, 3584, 3584, 5), ("llm gate_up swiglu", S, 37888, 3584, 6), ("llm down", S, 3584, 18944, 5),
           ("vit qkv", 23328, 4608, 1152, 1), ("vit fc1 gelu", 23328, 4352, 1152, 3), ("vit fc2", 23328, 1280, 4352, 4 if False else 1), ("proj1 gelu", 23328, 3584, 1152, 2),
           ("proj2", 23328, 3584, 3584, 1), ("vit out 1152", 23328, 1152, 1152, 1), ("vit out 1280", 23328, 1280, 1152, 1), ("patch embed", 23328, 1152, 640, 1),
-          ("answer grp qkv", 960, 4608, 3584, 1), ("answer grp gate_up", 960, 37888, 3584, 6), ("answer grp down", 960, 3584, 18944, 5),
+          ("answer grp o", 960, 3584, 3584, 5), ("answer grp qkv", 960, 4608, 3584, 1), ("answer grp gate_up", 960, 37888, 3584, 6), ("answer grp down", 960, 3584, 18944, 5),
           ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0)]
+os.environ["V3D_GEMM_PP"] = "1"
+os.environ.pop("V3D_GEMM_SKEW", None)
 for name, M, N, K, epi in shapes:
     row = []
-    for var, skew in (("3", "0"), ("3", "8"), ("3", "16"), ("3", "32"), ("3", "64"), ("4", "0"), ("4", "16"), ("4", "32")):
-        os.environ["V3D_GEMM_VARIANT"], os.environ["V3D_GEMM_PP"], os.environ["V3D_GEMM_SKEW"] = var, "1", skew
+    # automatic tile choice without / with the stream-K tail, then the 256 x 256 tile forced without / with it
+    for var, sk in ((None, "0"), (None, "1"), ("3", "0"), ("3", "2"), ("4", "0")):
+        if var is None: os.environ.pop("V3D_GEMM_VARIANT", None)
+        else: os.environ["V3D_GEMM_VARIANT"] = var
+        os.environ["V3D_GEMM_STREAMK"] = sk
         ms = run(M, N, K, epi)
         row.append(f"{ms*1e3:7.1f}")
-    print(f"{name:18s} {M:5d}x{N:5d}x{K:5d} | pp-256 skew 0/8/16/32/64: {' '.join(row[:5])} | pp-192 skew 0/16/32: {' '.join(row[5:])}", flush=True)
+    tf = 2.0 * M * N * K / (float(row[1]) * 1e-6) / 1e12
+    print(f"{name:18s} {M:5d}x{N:5d}x{K:5d} | auto sk=0 / sk=1: {row[0]} {row[1]} ({tf:6.0f} TF/s) | pp-256 sk=0 / sk=2: {row[2]} {row[3]} | pp-192: {row[4]}", flush=True)

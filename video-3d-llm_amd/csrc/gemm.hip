@@ -19,6 +19,8 @@
 #include <stdlib.h>
 
 #include "v3d_common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace v3d {
 
@@ -56,6 +58,15 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int dma_late;       // 256-wide kernel: restage after (1) or before (0) the last phase's MFMAs of a K-step
   int skew;           // ping-pong kernel: largest start delay of a workgroup, in units of 1024 shader cycles (0 = none)
+  // ping-pong kernel, split-K tail (sk_dp >= 0): per XCD sk_dp rounds of whole tiles, then each remaining tile is cut into
+  // sk_split K-chunks run by neighbouring workgroups of the XCD AT THE SAME TIME (all chunk-c workgroups walk the same k range in
+  // lock step, so operand panels are still shared in L2 - a stream-K walk with staggered k offsets ran at half speed: HBM-bound);
+  // the chunk-0 workgroup adds the others' accumulator images and runs the epilogue
+  int sk_dp;          // -1: off
+  int sk_split;       // 2 .. 4
+  float* sk_ws;       // one accumulator image (32 x 512 x 16 bytes) per workgroup
+  unsigned* sk_flags; // one word per workgroup: == sk_epoch once its image is written
+  unsigned sk_epoch;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -77,9 +88,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 // XCD-aware logical block id (blocks b and b+8 share an XCD's L2), then grouped row-major tiles:
 // the ~64 workgroups resident on one XCD cover an 8 x 8 patch of tiles and share operand panels.
+__device__ __forceinline__ void tile_of_logical(int L, int tiles_m, int tiles_n, int& tm, int& tn);
+__device__ __forceinline__ int xcd_first_logical(int xcd, int nblocks) {     // first logical tile of an XCD's share, shares: q + (xcd < r)
+  const int q = nblocks >> 3, r = nblocks & 7;
+  return xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+}
 __device__ __forceinline__ void tile_of_block(int bid, int nblocks, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
-  const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  tile_of_logical(xcd_first_logical(bid & 7, nblocks) + (bid >> 3), tiles_m, tiles_n, tm, tn);
+}
+__device__ __forceinline__ void tile_of_logical(int L, int tiles_m, int tiles_n, int& tm, int& tn) {
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * tiles_n;
   const int g = L / per_group, in_g = L - g * per_group;
@@ -569,10 +586,37 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(16);
   }
   int tm, tn, m0, n0;
+  // ---- the work of this workgroup: a list of SEGMENTS (tile, K-step range).  Plain persistent walk: whole tiles b, b + grid, ...
+  // Split-K tail (p.sk_dp >= 0): with g = xcd wx + idx the XCD-major id of workgroup (xcd = b & 7, idx = b >> 3; wx = grid / 8), the
+  // first sk_dp grid tiles of the logical order are whole tiles - XCD x owns the block [x dp wx, (x + 1) dp wx), round r tile
+  // r wx + idx of it - and the T = n_tiles - dp grid tiles left go out as items (chunk c, tile j) = (g / T, g mod T), g < split T:
+  // an XCD's workgroups take neighbouring tiles of (mostly) ONE chunk, so they walk the same k range in lock step and share operand
+  // panels in L2 exactly as in a whole-tile round.  Chunk c covers the granules (2 K-steps) [c gpt / split, (c + 1) gpt / split).
+  // A chunk c > 0 ends by writing its accumulators to the workspace and raising its flag - it never waits - and chunk 0 adds the
+  // images of the workgroups that ran the tile's other chunks and runs the epilogue.
+  const int nt = p.K / BK;       // >= 2 (the launcher sends shorter K to the v3 kernel)
+  const bool sk = p.sk_dp >= 0;
+  const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, wx = (int)gridDim.x >> 3;
+  const int gpt = nt >> 1;                                                   // granules per tile
+  const int sk_g = xcd * wx + idx, sk_T = n_tiles - p.sk_dp * (int)gridDim.x;
+  int dp_round = 0;
+  bool sk_item = sk && sk_g < p.sk_split * sk_T;                             // this workgroup has a chunk of the tail
+  int k_begin = 0, k_end = nt;
+  // next segment -> (L, k range); false when the list is exhausted
+  auto next_segment = [&](int& L) -> bool {
+    if (!sk) { if (bid >= n_tiles) return false; L = xcd_first_logical(bid & 7, n_tiles) + (bid >> 3); bid += (int)gridDim.x; k_begin = 0; k_end = nt; return true; }
+    if (dp_round < p.sk_dp) { L = (xcd * p.sk_dp + dp_round) * wx + idx; ++dp_round; k_begin = 0; k_end = nt; return true; }
+    if (!sk_item) return false;
+    sk_item = false;
+    const int c = sk_g / sk_T;
+    L = p.sk_dp * (int)gridDim.x + (sk_g - c * sk_T);
+    k_begin = 2 * (c * gpt / p.sk_split); k_end = 2 * ((c + 1) * gpt / p.sk_split);
+    return true;
+  };
   // ---- staging: piece q = wave + 8 i (8 rows, 1 KiB) of every half-tile; W halves have 16 pieces, A halves NPA ----
   unsigned a_off[2][2], w_off[2][2];        // [half][piece] byte offsets of this lane's 16-byte source chunk
-  auto setup = [&](int b) {
-    tile_of_block(b, n_tiles, p.tiles_m, p.tiles_n, tm, tn);
+  auto setup = [&](int L) {
+    tile_of_logical(L, p.tiles_m, p.tiles_n, tm, tn);
     m0 = tm * BM; n0 = tn * B3N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -634,7 +678,6 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
 #define V3D_VM(n0, n1) { if (NPA == 16 || a_two) asm volatile("s_waitcnt vmcnt(" #n0 ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(" #n1 ")" ::: "memory"); }
 #define V3D_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
 
-  const int nt = p.K / BK;       // >= 2 (the launcher sends shorter K to the v3 kernel)
   // MODE 0: steady state; 1: second-last K-step (its fourth phase has nothing left to issue); 2: last K-step.
   // After phase P's issue everything up to H(P + 2) must have landed: H(P+3..P+5) may stay in flight - kinds (A A W), (A W W),
   // (W W A), (W A A) for P mod 4 = 0..3, i.e. 6 pieces, or 4 / 5 / 5 / 4 for a wave with single A pieces.
@@ -674,20 +717,24 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   const T* bias = (const T*)p.bias;
   T* out = (T*)p.out;
 
-  setup(bid);
-  stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0);
+  {
+    int L;
+    if (!next_segment(L)) return;               // (split tail with fewer items than workgroups: nothing to do)
+    setup(L);
+  }
+  stage(IntC<0>{}, k_begin); stage(IntC<1>{}, k_begin); stage(IntC<2>{}, k_begin); stage(IntC<3>{}, k_begin);
   while (true) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stage(IntC<0>{}, 1);                          // H4 (slot 4: free - the previous tile's epilogue has left it)
+    stage(IntC<0>{}, k_begin + 1);                // H4 (slot 4: free - the previous tile's epilogue has left it; k_begin is even)
     V3D_VM(6, 4);                                 // H0, H1 landed; (W A A) in flight (later tiles: everything but H4 landed long ago)
     V3D_BAR();
     if (wm == 1) V3D_BAR();                      // the wm = 1 waves run one barrier behind
     {
-      int t = 0;
-      for (; t < nt - 2; ++t) kstep(IntC<0>{}, t);
+      int t = k_begin;
+      for (; t < k_end - 2; ++t) kstep(IntC<0>{}, t);
       kstep(IntC<1>{}, t);
       kstep(IntC<2>{}, t + 1);
     }
@@ -695,11 +742,60 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     __syncthreads();                              // every fragment read of this tile is done: the whole ring is free
 
     const int cm0 = m0, cn0 = n0, ctn = tn;
-    const int next = bid + (int)gridDim.x;
-    const bool has_next = next < n_tiles;         // workgroup-uniform
-    if (has_next) {                               // next tile's K-step 0 -> buffer 0, in flight under the epilogue
-      setup(next);
-      stage(IntC<0>{}, 0); stage(IntC<1>{}, 0); stage(IntC<2>{}, 0); stage(IntC<3>{}, 0);
+    const bool seg_tail = k_begin > 0, seg_head = k_end < nt;        // stream-K: this segment lacks the tile's first / last K-steps
+    int nextL;
+    const bool has_next = next_segment(nextL);    // workgroup-uniform; k_begin / k_end now describe the NEXT segment (k_begin even)
+    if (has_next) {                               // next segment's first K-step -> buffer 0, in flight under the epilogue
+      setup(nextL);
+      stage(IntC<0>{}, k_begin); stage(IntC<1>{}, k_begin); stage(IntC<2>{}, k_begin); stage(IntC<3>{}, k_begin);
+    }
+    // The exchange uses no fences (an agent-scope release / acquire is a whole-L2 write-back / invalidate per wave on this chip and
+    // cost more than the idle round it removes): the image and the flag travel with device-scope instructions instead - stores
+    // written through (sc0 sc1), s_waitcnt vmcnt(0) = acknowledged, barrier, flag; the reader polls the flag with a device-scope
+    // load and reads the image with loads that bypass the caches a stale copy could sit in.
+    if (seg_tail) {
+      // a chunk c > 0: hand the accumulators to the tile's chunk-0 workgroup (f32, lane-major: the reader has the same layout)
+      const float* img = p.sk_ws + (size_t)blockIdx.x * (32 * 512 * 4);
+      unsigned off = (unsigned)tid * 16u;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" : : "v"(off), "v"(acc[i][j]), "s"(img) : "memory");
+          off += 512u * 16u;
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!has_next) break;
+      continue;
+    }
+    if (seg_head) {
+      for (int c = 1; c < p.sk_split; ++c) {
+        const int fg = c * sk_T + sk_g;                                  // chunk c of this tile (this workgroup is chunk 0: sk_g = j)
+        const unsigned from = (unsigned)((fg % wx) * 8 + fg / wx);
+        if (tid == 0)
+          while (__hip_atomic_load(p.sk_flags + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        const float* img = p.sk_ws + (size_t)from * (32 * 512 * 4);
+        unsigned off = (unsigned)tid * 16u;
+        // eight 16-byte loads in flight at a time (the fragment registers are free here)
+#pragma unroll
+        for (int u0 = 0; u0 < 4 * MT; u0 += 8) {
+          f32x4 part[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(part[u]) : "v"(off), "s"(img) : "memory");
+            off += 512u * 16u;
+          }
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7]) : : "memory");
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            f32x4& a = acc[(u0 + u) / MT][(u0 + u) % MT];
+            a[0] += part[u][0]; a[1] += part[u][1]; a[2] += part[u][2]; a[3] += part[u][3];
+          }
+        }
+      }
     }
 
     // epilogue in two halves of WROWS rows (the wave row wm = half writes, everyone stores): accumulators -> LDS (16-bit, bias
@@ -784,13 +880,12 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       __syncthreads();
     }
 #ifdef V3D_PP_PROBE
-    if (V3D_PP_PROBE == 2) { if (!has_next) break; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bid = next; continue; }
+    if (V3D_PP_PROBE == 2) { if (!has_next) break; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }
 #endif
     if (!has_next) break;
     // the counted waits of the K loop assume that only this wave's staging DMAs are outstanding, in issue order: retire the
     // epilogue's stores / residual loads (and with them the prefetch, long since landed) before the next tile starts counting
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bid = next;
   }
 #undef V3D_DSR
 #undef V3D_RDA
@@ -957,14 +1052,75 @@ static int pp_slots() {       // workgroups the chip holds at once (one per CU: 
   return cus;
 }
 
+// ---- split-K tail of the ping-pong kernel: host side ----
+// V3D_GEMM_STREAMK: 1 (default) = where the time model says it pays; 0 = never (every output then sums k in one run, whatever M); 2 = wherever legal.
+static int gemm_sk_mode() {
+  const char* e = getenv("V3D_GEMM_STREAMK");
+  return e ? atoi(e) : 1;
+}
+// Legal: grid a multiple of 8 (the XCD-major order), an even number of K-steps (granule = 2) with at least two granules per chunk,
+// and the tiles left after the whole-tile rounds fit the grid at least twice.  Returns the whole-tile rounds (or -1) and the split.
+static int sk_plan(int n_tiles, int grid, int nt, int* split) {
+  *split = 1;
+  if (grid < 8 || (grid & 7) || (nt & 1)) return -1;
+  const int dp = n_tiles / grid, rest = n_tiles - dp * grid;      // (dp = 0: fewer tiles than workgroups - the whole launch is the tail)
+  if (rest == 0) return -1;                  // whole rounds only
+  int sp = grid / rest;
+  sp = sp > 4 ? 4 : sp;
+  if (sp < 2 || (nt >> 1) < 2 * sp) return -1;
+  *split = sp;
+  return dp;
+}
+static bool sk_pays(int n_tiles, int grid, int nt) {           // the time model of launch_gemm: whole rounds vs whole rounds + split tail
+  int sp = 1;
+  const int dp = sk_plan(n_tiles, grid, nt, &sp);
+  if (dp < 0) return false;
+  const double ks = (double)nt, round = 27.8 + 1.265 * ks;
+  return dp * round + 27.8 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
+}
+struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int slots = 0; };
+// One workspace per stream (launches on one stream are ordered; two streams must not share accumulator images).  Allocated on
+// first use, never during stream capture (the caller then gets the plain walk).
+static SkWorkspace* sk_workspace(hipStream_t st, int grid) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, SkWorkspace> map;
+  std::lock_guard<std::mutex> lock(mu);
+  SkWorkspace& w = map[st];
+  if (w.slots >= grid) return &w;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+  if (w.ws) { (void)hipStreamSynchronize(st); (void)hipFree(w.ws); w = SkWorkspace{}; }
+  const size_t img = (size_t)32 * 512 * 16, bytes = (size_t)grid * img + (size_t)grid * sizeof(unsigned);
+  void* ptr = nullptr;
+  if (hipMalloc(&ptr, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  w.ws = (float*)ptr;
+  w.flags = (unsigned*)((char*)ptr + (size_t)grid * img);
+  if (hipMemsetAsync(w.flags, 0, (size_t)grid * sizeof(unsigned), st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); w = SkWorkspace{}; return nullptr; }
+  w.slots = grid; w.epoch = 0;
+  return &w;
+}
+
 template <typename T, int MT>
 static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
   p.tiles_m = (p.M + MT * 32 - 1) / (MT * 32);
   p.tiles_n = p.N / B3N;
   const int n_tiles = p.tiles_m * p.tiles_n;
-  const int grid = n_tiles < pp_slots() ? n_tiles : pp_slots();     // persistent: one workgroup per CU walks its tiles
+  int grid = n_tiles < pp_slots() ? n_tiles : pp_slots();           // persistent: one workgroup per CU walks its tiles
   { const char* e = getenv("V3D_GEMM_SKEW"); p.skew = e ? atoi(e) : 0; }
   if (n_tiles <= grid) p.skew = 0;                                  // a single round: nothing to spread
+  p.sk_dp = -1; p.sk_split = 1; p.sk_ws = nullptr; p.sk_flags = nullptr; p.sk_epoch = 0;
+  {
+    int split = 1;
+    const int slots = pp_slots() & ~7;
+    const int mode = gemm_sk_mode(), dp = sk_plan(n_tiles, slots, p.K / BK, &split);
+    if (mode != 0 && dp >= 0 && (mode == 2 || sk_pays(n_tiles, slots, p.K / BK))) {
+      if (SkWorkspace* w = sk_workspace(st, slots)) {
+        p.sk_dp = dp; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = ++w->epoch;
+        p.skew = 0;
+        grid = slots;                                               // (also when n_tiles < slots: the chunks fill the chip)
+      }
+    }
+  }
 #define V3D_GEMM4_CASE(E)                                                                                 \
   case E: {                                                                                               \
     auto k = gemm256pp_kernel<T, E, MT>;                                                                    \
@@ -995,17 +1151,29 @@ template <typename T>
 static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
   // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
   //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
-  //   256 x 256 ping-pong (256 slots): fixed 9 (prologue DMA latency + epilogue), 1.26 per K-step
-  //   192 x 256 ping-pong (256 slots): fixed 8, 1.0 per K-step   (3/4 of the tile: wins when 256-row tiles quantise badly
-  //                                    against the 256 CUs, e.g. M = 6794, N = 3584: 378 tiles = 1.48 rounds vs 504 = 1.97)
-  //   128 x 128           (512 slots): fixed 1, 0.98 per K-step  (many small tiles: small M, or N % 256 != 0)
+  //   256 x 256 ping-pong (256 slots): fixed 28 (prologue DMA latency, epilogue, dispatch), 1.265 per K-step
+  //   192 x 256 ping-pong (256 slots): fixed 14, 1.246 per K-step   (3/4 of the tile at the same step time: it only wins where
+  //                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
+  //   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
+  //   256 x 256 with the split-K tail: whole rounds as above + one round of (28 + step x K-steps / split + 40 for the exchange),
+  //                                    step 1.3 when the launch is only the tail, 1.7 behind whole rounds (measured: 6794 x 3584 x 18944
+  //                                    805 -> 715 us, 960 x 3584 x 18944 326 -> 165 us; no gain at K = 3584)
   const int var = gemm_variant();
   if (p.N % B3N == 0 && var != 1) {
     const double ks = (double)(p.K / BK);
     const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
     const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
-    const double t256 = (double)((tiles256 + 255) / 256) * (pp ? 9.0 + 1.2625 * ks : 9.0 + 1.36 * ks);
-    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 8.0 + 1.0 * ks : 2.0 + 1.32 * ks);
+    const int slots = pp_slots();
+    double t256 = (double)((tiles256 + 255) / 256) * (pp ? 27.8 + 1.265 * ks : 9.0 + 1.36 * ks);
+    if (pp && gemm_sk_mode() != 0) {
+      int sp = 1;
+      const int dp = sk_plan(tiles256, slots & ~7, p.K / BK, &sp);
+      if (dp >= 0) {
+        const double tsk = dp * (27.8 + 1.265 * ks) + 27.8 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
+        if (tsk < t256 || gemm_sk_mode() == 2) t256 = tsk;          // launch_gemm256pp takes the same decision (sk_pays)
+      }
+    }
+    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 13.8 + 1.246 * ks : 2.0 + 1.32 * ks);
     const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
     if (var == 4) return pp ? launch_gemm256pp<T, 6>(p, epi, st) : launch_gemm256x256<T, 6>(p, epi, st);
     if (var == 3) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
