@@ -1,6 +1,8 @@
 // Probe (not product): where does a tile of the ping-pong GEMM spend its time?  Builds gemm.hip three ways and times one shape:
 //   V3D_PP_PROBE=0  the product kernel
 //   V3D_PP_PROBE=1  K loop alone (epilogue replaced by a never-taken store; results wrong)
+//   V3D_PP_PROBE=1 -DV3D_PP_SAMETILE  the same with every workgroup reading tile (0, 0)'s operands (all L2 hits): gate/up 1236 -> 1166 us,
+//                   i.e. memory latency costs the K loop ~6 %; the rest of the gap to the MFMA peak is issue / LDS and the sustained clock
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DV3D_PP_PROBE=1 -Iinclude -Ivideo-3d-llm_amd/csrc tools/probes/gemm_pp_probe.hip \
 //         video-3d-llm_amd/csrc/host.cpp -o tools/probes/_build/gemm_pp_probe1
 #include "../../video-3d-llm_amd/csrc/gemm.hip"

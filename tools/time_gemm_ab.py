@@ -22,7 +22,7 @@ def run(M, N, K, epi, iters=30):
     return e0.elapsed_time(e1) / iters
 S = 6794
 shapes = [("llm qkv", S, 4608, 3584, 1), ("llm o_proj", S, 3584, 3584, 5), ("llm gate_up swiglu", S, 37888, 3584, 6), ("llm down", S, 3584, 18944, 5),
-          ("vit qkv", 23328, 4608, 1152, 1), ("vit fc1 gelu", 23328, 4352, 1152, 3), ("vit fc2", 23328, 1280, 4352, 4 if False else 1), ("proj1 gelu", 23328, 3584, 1152, 2),
+          ("vit qkv", 23328, 4608, 1152, 1), ("vit qkv packed", 23328, 3584, 1152, 1), ("vit fc1 gelu", 23328, 4352, 1152, 3), ("vit fc2", 23328, 1280, 4352, 4 if False else 1), ("proj1 gelu", 23328, 3584, 1152, 2),
           ("proj2", 23328, 3584, 3584, 1), ("vit out 1152", 23328, 1152, 1152, 1), ("vit out 1280", 23328, 1280, 1152, 1), ("patch embed", 23328, 1152, 640, 1),
           ("answer grp o", 960, 3584, 3584, 5), ("answer grp qkv", 960, 4608, 3584, 1), ("answer grp gate_up", 960, 37888, 3584, 6), ("answer grp down", 960, 3584, 18944, 5),
           ("square 4096", 4096, 4096, 4096, 0), ("square 8192", 8192, 8192, 8192, 0)]
@@ -31,11 +31,11 @@ os.environ.pop("V3D_GEMM_SKEW", None)
 for name, M, N, K, epi in shapes:
     row = []
     # automatic tile choice without / with the stream-K tail, then the 256 x 256 tile forced without / with it
-    for var, sk in ((None, "0"), (None, "1"), ("3", "0"), ("3", "2"), ("4", "0")):
+    for var, sk in ((None, "0"), (None, "1"), ("3", "0"), ("3", "2"), ("4", "0"), ("1", "0")):
         if var is None: os.environ.pop("V3D_GEMM_VARIANT", None)
         else: os.environ["V3D_GEMM_VARIANT"] = var
         os.environ["V3D_GEMM_STREAMK"] = sk
         ms = run(M, N, K, epi)
         row.append(f"{ms*1e3:7.1f}")
     tf = 2.0 * M * N * K / (float(row[1]) * 1e-6) / 1e12
-    print(f"{name:18s} {M:5d}x{N:5d}x{K:5d} | auto sk=0 / sk=1: {row[0]} {row[1]} ({tf:6.0f} TF/s) | pp-256 sk=0 / sk=2: {row[2]} {row[3]} | pp-192: {row[4]}", flush=True)
+    print(f"{name:18s} {M:5d}x{N:5d}x{K:5d} | auto sk=0 / sk=1: {row[0]} {row[1]} ({tf:6.0f} TF/s) | pp-256 sk=0 / sk=2: {row[2]} {row[3]} | pp-192: {row[4]} | 128x128: {row[5]}", flush=True)

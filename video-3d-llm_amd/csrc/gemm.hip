@@ -617,6 +617,9 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   unsigned a_off[2][2], w_off[2][2];        // [half][piece] byte offsets of this lane's 16-byte source chunk
   auto setup = [&](int L) {
     tile_of_logical(L, p.tiles_m, p.tiles_n, tm, tn);
+#if defined(V3D_PP_PROBE) && defined(V3D_PP_SAMETILE)   // probe: every workgroup reads tile (0, 0)'s operands - the K loop with everything L2-resident
+    tm = 0; tn = 0;
+#endif
     m0 = tm * BM; n0 = tn * B3N;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1101,7 +1104,7 @@ static SkWorkspace* sk_workspace(hipStream_t st, int grid) {
 }
 
 template <typename T, int MT>
-static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
+static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = -1) {   // sk_allow: -1 decide here (forced tile), 0 / 1 = the caller's model decided
   p.tiles_m = (p.M + MT * 32 - 1) / (MT * 32);
   p.tiles_n = p.N / B3N;
   const int n_tiles = p.tiles_m * p.tiles_n;
@@ -1113,7 +1116,7 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st) {
     int split = 1;
     const int slots = pp_slots() & ~7;
     const int mode = gemm_sk_mode(), dp = sk_plan(n_tiles, slots, p.K / BK, &split);
-    if (mode != 0 && dp >= 0 && (mode == 2 || sk_pays(n_tiles, slots, p.K / BK))) {
+    if (mode != 0 && dp >= 0 && (mode == 2 || (sk_allow < 0 ? sk_pays(n_tiles, slots, p.K / BK) : sk_allow != 0))) {
       if (SkWorkspace* w = sk_workspace(st, slots)) {
         p.sk_dp = dp; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = ++w->epoch;
         p.skew = 0;
@@ -1165,20 +1168,22 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
     const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
     const int slots = pp_slots();
     double t256 = (double)((tiles256 + 255) / 256) * (pp ? 27.8 + 1.265 * ks : 9.0 + 1.36 * ks);
+    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 13.8 + 1.246 * ks : 2.0 + 1.32 * ks);
+    const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
+    int sk_use = 0;
     if (pp && gemm_sk_mode() != 0) {
       int sp = 1;
       const int dp = sk_plan(tiles256, slots & ~7, p.K / BK, &sp);
       if (dp >= 0) {
         const double tsk = dp * (27.8 + 1.265 * ks) + 27.8 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
-        if (tsk < t256 || gemm_sk_mode() == 2) t256 = tsk;          // launch_gemm256pp takes the same decision (sk_pays)
+        const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
+        if (tsk < 0.95 * best || gemm_sk_mode() == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 5 % margin: the model is coarse)
       }
     }
-    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 13.8 + 1.246 * ks : 2.0 + 1.32 * ks);
-    const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
     if (var == 4) return pp ? launch_gemm256pp<T, 6>(p, epi, st) : launch_gemm256x256<T, 6>(p, epi, st);
-    if (var == 3) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
-    if (t192 < t256 && t192 < t1) return pp ? launch_gemm256pp<T, 6>(p, epi, st) : launch_gemm256x256<T, 6>(p, epi, st);
-    if (t256 < t1) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);
+    if (var == 3) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);       // (forced tiles decide the split themselves)
+    if (t192 < t256 && t192 < t1) return pp ? launch_gemm256pp<T, 6>(p, epi, st, 0) : launch_gemm256x256<T, 6>(p, epi, st);
+    if (t256 < t1) return pp ? launch_gemm256pp<T, 8>(p, epi, st, sk_use) : launch_gemm256x256<T, 8>(p, epi, st);
   }
 #define V3D_GEMM_CASE(E)                                                                                  \
   case E: {                                                                                               \
