@@ -148,6 +148,8 @@ def test_gemm_pingpong_tile_equals_v3_tile_bitwise(ops, kind, M, N, K, epi, monk
     monkeypatch.delenv("V3D_GEMM_PP_GRID")
     assert torch.equal(outs["3", "0"], outs["3", "1"]) and torch.equal(outs["4", "0"], outs["4", "1"])
     assert torch.equal(outs["3", "1"], outs["4", "1"])    # every tile shape sums k in the same order
+    monkeypatch.setenv("V3D_GEMM_VARIANT", "1")            # ... the 128 x 128 kernel included
+    assert torch.equal(ops.gemm(a, w, **kw), outs["3", "1"])
     if epi in ("none", "bias"):
         close(outs["4", "1"], ref_linear(a.cpu(), w.cpu(), b.cpu() if epi == "bias" else None, dt), kind)
 

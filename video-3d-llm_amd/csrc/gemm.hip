@@ -615,8 +615,8 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   };
   // ---- staging: piece q = wave + 8 i (8 rows, 1 KiB) of every half-tile; W halves have 16 pieces, A halves NPA ----
   unsigned a_off[2][2], w_off[2][2];        // [half][piece] byte offsets of this lane's 16-byte source chunk
-  auto setup = [&](int L) {
-    tile_of_logical(L, p.tiles_m, p.tiles_n, tm, tn);
+  auto setup = [&](int tm_, int tn_) {         // per-lane source offsets of tile (tm_, tn_)
+    tm = tm_; tn = tn_;
 #if defined(V3D_PP_PROBE) && defined(V3D_PP_SAMETILE)   // probe: every workgroup reads tile (0, 0)'s operands - the K loop with everything L2-resident
     tm = 0; tn = 0;
 #endif
@@ -631,7 +631,11 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
         int gm = m0 + WROWS * awm + HR * h + ar;
         gm = gm < p.M ? gm : p.M - 1;                            // M tail: re-read the last row, never stored
         a_off[h][i] = (unsigned)(gm * (int)p.lda + chunk * 8) * 2u;
-        const int gn = n0 + 64 * (lr >> 5) + 32 * h + (lr & 31);
+        // W half hn holds, for every wave column wn = lr >> 5, the 32 tile columns the wave multiplies in the (., hn) phases.
+        // SwiGLU (tile columns = two groups of [gate64 | up64]): wave wn gets gate columns (hn 0) and the MATCHING up columns
+        // (hn 1) of one 32-wide output block, so silu(gate) * up is formed in registers, without an exchange between waves.
+        const int gn = EPI == EPI_SWIGLU ? n0 + 128 * (lr >> 6) + 64 * h + 32 * ((lr >> 5) & 1) + (lr & 31)
+                                         : n0 + 64 * (lr >> 5) + 32 * h + (lr & 31);
         w_off[h][i] = (unsigned)(gn * (int)p.ldw + chunk * 8) * 2u;
       }
     }
@@ -715,18 +719,28 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     V3D_BAR();
   };
 
-  constexpr int C3_ROW = B3N * 2 + 16;
-  char* const cst = smem + PP_BUF;            // C staging of the epilogue: K-step buffer 1 onwards (buffer 0 receives the next tile)
   const T* bias = (const T*)p.bias;
   T* out = (T*)p.out;
 
   {
-    int L;
+    int L, t0, t1;
     if (!next_segment(L)) return;               // (split tail with fewer items than workgroups: nothing to do)
-    setup(L);
+    tile_of_logical(L, p.tiles_m, p.tiles_n, t0, t1);
+    setup(t0, t1);
   }
   stage(IntC<0>{}, k_begin); stage(IntC<1>{}, k_begin); stage(IntC<2>{}, k_begin); stage(IntC<3>{}, k_begin);
   while (true) {
+    // the NEXT segment is located here, before the accumulators are live (its integer divisions want registers)
+    const int cur_kb = k_begin, cur_ke = k_end;
+    int n_tm = 0, n_tn = 0;
+    bool has_next;
+    {
+      int L;
+      has_next = next_segment(L);                 // workgroup-uniform; k_begin / k_end now describe the NEXT segment (k_begin even)
+      if (has_next) tile_of_logical(L, p.tiles_m, p.tiles_n, n_tm, n_tn);
+    }
+    const int n_kb = k_begin, n_ke = k_end;
+    k_begin = cur_kb; k_end = cur_ke;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -745,11 +759,10 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     __syncthreads();                              // every fragment read of this tile is done: the whole ring is free
 
     const int cm0 = m0, cn0 = n0, ctn = tn;
-    const bool seg_tail = k_begin > 0, seg_head = k_end < nt;        // stream-K: this segment lacks the tile's first / last K-steps
-    int nextL;
-    const bool has_next = next_segment(nextL);    // workgroup-uniform; k_begin / k_end now describe the NEXT segment (k_begin even)
+    const bool seg_tail = k_begin > 0, seg_head = k_end < nt;        // split tail: this segment lacks the tile's first / last K-steps
+    k_begin = n_kb; k_end = n_ke;
     if (has_next) {                               // next segment's first K-step -> buffer 0, in flight under the epilogue
-      setup(nextL);
+      setup(n_tm, n_tn);
       stage(IntC<0>{}, k_begin); stage(IntC<1>{}, k_begin); stage(IntC<2>{}, k_begin); stage(IntC<3>{}, k_begin);
     }
     // The exchange uses no fences (an agent-scope release / acquire is a whole-L2 write-back / invalidate per wave on this chip and
@@ -801,8 +814,11 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       }
     }
 
-    // epilogue in two halves of WROWS rows (the wave row wm = half writes, everyone stores): accumulators -> LDS (16-bit, bias
-    // added in f32 first) -> whole 512-byte row segments
+    // Epilogue straight from the accumulators (r02b; the LDS-staged form cost 6-8 % of an LLM tile and 15-25 % of a K = 1152 tile in
+    // barriers and the LDS round trip with the matrix cores idle): lane (l15 = lane & 15, l4 = lane >> 4) holds, per (ni, mi), the four
+    // consecutive output columns 64 wn + 16 ni + 4 l4 + r of row 128|96 wm + 16 mi + l15 - an 8-byte store per lane, sixteen rows x
+    // 32 bytes per instruction, four instructions complete a row's 128-byte line in L2.  Same arithmetic and rounding points as the
+    // staged form (product + bias rounded to 16 bits, then activation / residual on the rounded value, rounded again): bit-identical.
 #ifdef V3D_PP_PROBE   // tools/probes/gemm_pp_probe.hip only (WRONG RESULTS): 1 = K loop alone, the accumulators folded into one store
     if (V3D_PP_PROBE == 1) {
       float sacc = 0.f;
@@ -810,77 +826,79 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       if (sacc == 12345.678f) out[tid] = from_f32<T>(sacc);
     } else
 #endif
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      // residual rows of this half: all loads in flight BEFORE the staging pass (issued one by one inside the store loop, each
-      // exposed its HBM round trip: 20 us per tile on the SigLIP fc2 shape)
+    {
+      const int l15 = lane & 15, l4 = lane >> 4;
+      const int row0 = cm0 + wm * WROWS + l15;                 // + 16 mi
       constexpr bool HAS_RES = EPI == EPI_BIAS_RES || EPI == EPI_RES;
-      constexpr int RIT = WROWS / 16;                 // store-loop iterations per thread
-      uint4 rres[HAS_RES ? RIT : 1];
-      if constexpr (HAS_RES) {
+      if constexpr (EPI == EPI_SWIGLU) {
+        T* const orow = out + ctn * 128 + (wn >> 1) * 64 + (wn & 1) * 32 + 4 * l4;     // + 16 n2
 #pragma unroll
-        for (int it = 0; it < RIT; ++it) {
-          const int gm = cm0 + half * WROWS + (tid >> 5) + 16 * it;
-          const int64_t rm = p.res_mod > 0 ? ((gm < p.M ? gm : p.M - 1) % p.res_mod) : (gm < p.M ? gm : p.M - 1);
-          rres[it] = *reinterpret_cast<const uint4*>((const T*)p.res + rm * p.ldr + cn0 + (tid & 31) * 8);
-        }
-      }
-      if (wm == half) {
+        for (int mi = 0; mi < MT; ++mi) {
+          const int gm = row0 + 16 * mi;
+          if (gm < p.M) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
-          float bv[4] = {0.f, 0.f, 0.f, 0.f};
-          if (epi_has_bias(EPI)) {
+            for (int n2 = 0; n2 < 2; ++n2) {
+              float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[cn0 + nl + r]);
+              for (int r = 0; r < 4; ++r) v[r] = round_to<T>(silu(round_to<T>(acc[n2][mi][r]))) * round_to<T>(acc[2 + n2][mi][r]);
+              uint2 pk;
+              pk.x = pack2<T>(v[0], v[1]); pk.y = pack2<T>(v[2], v[3]);
+              *reinterpret_cast<uint2*>(orow + (int64_t)gm * p.ldo + 16 * n2) = pk;
+            }
           }
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi) {
-            const int ml = mi * 16 + (lane & 15);
-            uint2 pk;
-            pk.x = pack2<T>(acc[ni][mi][0] + bv[0], acc[ni][mi][1] + bv[1]);
-            pk.y = pack2<T>(acc[ni][mi][2] + bv[2], acc[ni][mi][3] + bv[3]);
-            *reinterpret_cast<uint2*>(cst + ml * C3_ROW + nl * 2) = pk;
-          }
-        }
-      }
-      __syncthreads();
-      if (EPI == EPI_SWIGLU) {
-        // tile columns: per 128-column group [gate64 | up64]; two groups per tile -> 128 output columns
-#pragma unroll
-        for (int row = tid >> 4; row < WROWS; row += 32) {
-          const int c16 = tid & 15, grp = c16 >> 3, ch = c16 & 7;
-          const int gm = cm0 + half * WROWS + row;
-          const uint4 g = *reinterpret_cast<const uint4*>(cst + row * C3_ROW + grp * 256 + ch * 16);
-          const uint4 u = *reinterpret_cast<const uint4*>(cst + row * C3_ROW + grp * 256 + 128 + ch * 16);
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu(vec_get<T>(g, j))) * vec_get<T>(u, j);
-          if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + ctn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
         }
       } else {
+        const int col0 = cn0 + wn * 64 + 4 * l4;                // + 16 ni
+        float bv[4][4];
 #pragma unroll
-        for (int it = 0; it < RIT; ++it) {
-          const int row = (tid >> 5) + 16 * it;
-          const int ch = tid & 31;
-          const int gm = cm0 + half * WROWS + row;
+        for (int ni = 0; ni < 4; ++ni) {
+          if (epi_has_bias(EPI)) {
+            const uint2 b2 = *reinterpret_cast<const uint2*>(bias + col0 + 16 * ni);
+            bv[ni][0] = pair_lo<T>(b2.x); bv[ni][1] = pair_hi<T>(b2.x); bv[ni][2] = pair_lo<T>(b2.y); bv[ni][3] = pair_hi<T>(b2.y);
+          } else {
+            bv[ni][0] = bv[ni][1] = bv[ni][2] = bv[ni][3] = 0.f;
+          }
+        }
+        // residual rows: the four 8-byte loads of the NEXT mi are in flight while this one is finished (fragment registers are free)
+        uint2 rr[2][4];
+        auto load_res = [&](int mi, uint2 (&dst)[4]) {
+          const int gm = row0 + 16 * mi;
+          const int gc = gm < p.M ? gm : p.M - 1;
+          const int64_t rm = p.res_mod > 0 ? (gc % p.res_mod) : gc;
+          const T* rp = (const T*)p.res + rm * p.ldr + col0;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const uint2*>(rp + 16 * ni);
+        };
+        if constexpr (HAS_RES) load_res(0, rr[0]);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          if constexpr (HAS_RES) { if (mi + 1 < MT) load_res(mi + 1, rr[(mi + 1) & 1]); }
+          const int gm = row0 + 16 * mi;
           if (gm < p.M) {
-            uint4 c = *reinterpret_cast<const uint4*>(cst + row * C3_ROW + ch * 16);
-            if (EPI == EPI_BIAS_GELU_ERF || EPI == EPI_BIAS_GELU_TANH || EPI == EPI_BIAS_RES || EPI == EPI_RES || EPI == EPI_BIAS_RELU) {
-              float v[8];
-              const uint4 rr = HAS_RES ? rres[it] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float x = vec_get<T>(c, j);
-                v[j] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + vec_get<T>(rr, j);
+            for (int ni = 0; ni < 4; ++ni) {
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bv[ni][r];
+              if constexpr (EPI != EPI_NONE && EPI != EPI_BIAS) {
+                float q[4];
+                if constexpr (HAS_RES) {
+                  const uint2 r2 = rr[mi & 1][ni];
+                  q[0] = pair_lo<T>(r2.x); q[1] = pair_hi<T>(r2.x); q[2] = pair_lo<T>(r2.y); q[3] = pair_hi<T>(r2.y);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float x = round_to<T>(v[r]);
+                  v[r] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + q[r];
+                }
               }
-              c = vec_pack<T>(v);
+              uint2 pk;
+              pk.x = pack2<T>(v[0], v[1]); pk.y = pack2<T>(v[2], v[3]);
+              *reinterpret_cast<uint2*>(out + (int64_t)gm * p.ldo + col0 + 16 * ni) = pk;
             }
-            *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + cn0 + ch * 8) = c;
           }
         }
       }
-      __syncthreads();
     }
 #ifdef V3D_PP_PROBE
     if (V3D_PP_PROBE == 2) { if (!has_next) break; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }
@@ -1078,8 +1096,8 @@ static bool sk_pays(int n_tiles, int grid, int nt) {           // the time model
   int sp = 1;
   const int dp = sk_plan(n_tiles, grid, nt, &sp);
   if (dp < 0) return false;
-  const double ks = (double)nt, round = 27.8 + 1.265 * ks;
-  return dp * round + 27.8 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
+  const double ks = (double)nt, round = 22.0 + 1.263 * ks;
+  return dp * round + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
 }
 struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int slots = 0; };
 // One workspace per stream (launches on one stream are ordered; two streams must not share accumulator images).  Allocated on
@@ -1154,11 +1172,11 @@ template <typename T>
 static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
   // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
   //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
-  //   256 x 256 ping-pong (256 slots): fixed 28 (prologue DMA latency, epilogue, dispatch), 1.265 per K-step
-  //   192 x 256 ping-pong (256 slots): fixed 14, 1.246 per K-step   (3/4 of the tile at the same step time: it only wins where
+  //   256 x 256 ping-pong (256 slots): fixed 22 (prologue DMA latency, epilogue, dispatch), 1.263 per K-step
+  //   192 x 256 ping-pong (256 slots): fixed 10, 1.25 per K-step   (3/4 of the tile at the same step time: it only wins where
   //                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
   //   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
-  //   256 x 256 with the split-K tail: whole rounds as above + one round of (28 + step x K-steps / split + 40 for the exchange),
+  //   256 x 256 with the split-K tail: whole rounds as above + one round of (22 + step x K-steps / split + 40 for the exchange),
   //                                    step 1.3 when the launch is only the tail, 1.7 behind whole rounds (measured: 6794 x 3584 x 18944
   //                                    805 -> 715 us, 960 x 3584 x 18944 326 -> 165 us; no gain at K = 3584)
   const int var = gemm_variant();
@@ -1167,15 +1185,15 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
     const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
     const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
     const int slots = pp_slots();
-    double t256 = (double)((tiles256 + 255) / 256) * (pp ? 27.8 + 1.265 * ks : 9.0 + 1.36 * ks);
-    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 13.8 + 1.246 * ks : 2.0 + 1.32 * ks);
+    double t256 = (double)((tiles256 + 255) / 256) * (pp ? 22.0 + 1.263 * ks : 9.0 + 1.36 * ks);
+    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 10.0 + 1.25 * ks : 2.0 + 1.32 * ks);
     const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
     int sk_use = 0;
     if (pp && gemm_sk_mode() != 0) {
       int sp = 1;
       const int dp = sk_plan(tiles256, slots & ~7, p.K / BK, &sp);
       if (dp >= 0) {
-        const double tsk = dp * (27.8 + 1.265 * ks) + 27.8 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
+        const double tsk = dp * (22.0 + 1.263 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
         const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
         if (tsk < 0.95 * best || gemm_sk_mode() == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 5 % margin: the model is coarse)
       }

@@ -86,6 +86,14 @@ template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// the two 16-bit values of one packed 32-bit word, widened to f32
+template <typename T> __device__ __forceinline__ float pair_lo(uint32_t w);
+template <typename T> __device__ __forceinline__ float pair_hi(uint32_t w);
+template <> __device__ __forceinline__ float pair_lo<bf16_t>(uint32_t w) { return __uint_as_float(w << 16); }
+template <> __device__ __forceinline__ float pair_hi<bf16_t>(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+template <> __device__ __forceinline__ float pair_lo<f16_t>(uint32_t w) { f16_t h; h.v = (uint16_t)(w & 0xffffu); return to_f32(h); }
+template <> __device__ __forceinline__ float pair_hi<f16_t>(uint32_t w) { f16_t h; h.v = (uint16_t)(w >> 16); return to_f32(h); }
+
 template <typename T> __device__ __forceinline__ uint4 vec_pack(const float* v);
 template <> __device__ __forceinline__ uint4 vec_pack<float>(const float* v) {
   return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
