@@ -621,10 +621,12 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     tm = 0; tn = 0;
 #endif
     m0 = tm * BM; n0 = tn * B3N;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));               // recompute the lane constants here: hoisted, they live across the K loop and spill
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int lr = (wave + 8 * i) * 8 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((lr >> 1) & 7);
+      const int lr = (wave + 8 * i) * 8 + (ln >> 3);
+      const int chunk = (ln & 7) ^ ((lr >> 1) & 7);
       const int awm = lr / HR, ar = lr - awm * HR;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -758,7 +760,11 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     if (wm == 0) V3D_BAR();
     __syncthreads();                              // every fragment read of this tile is done: the whole ring is free
 
+#if defined(V3D_PP_PROBE) && V3D_PP_PROBE == 3          // probe: every tile stores to tile (0, 0)'s output (C traffic stays in L2)
+    const int cm0 = 0, cn0 = 0, ctn = 0;
+#else
     const int cm0 = m0, cn0 = n0, ctn = tn;
+#endif
     const bool seg_tail = k_begin > 0, seg_head = k_end < nt;        // split tail: this segment lacks the tile's first / last K-steps
     k_begin = n_kb; k_end = n_ke;
     if (has_next) {                               // next segment's first K-step -> buffer 0, in flight under the epilogue
@@ -773,11 +779,14 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       // a chunk c > 0: hand the accumulators to the tile's chunk-0 workgroup (f32, lane-major: the reader has the same layout)
       const float* img = p.sk_ws + (size_t)blockIdx.x * (32 * 512 * 4);
       unsigned off = (unsigned)tid * 16u;
+      asm volatile("" : "+v"(off));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" : : "v"(off), "v"(acc[i][j]), "s"(img) : "memory");
+          // (s_nop: a VALU write to the data registers of a > 64-bit store needs 2 wait states after it; hipcc pads that hazard for
+          //  its own stores but cannot see into an asm statement - without it the next address add corrupted the image)
+          asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" : : "v"(off), "v"(acc[i][j]), "s"(img) : "memory");
           off += 512u * 16u;
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -795,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
         __syncthreads();
         const float* img = p.sk_ws + (size_t)from * (32 * 512 * 4);
         unsigned off = (unsigned)tid * 16u;
+        asm volatile("" : "+v"(off));
         // eight 16-byte loads in flight at a time (the fragment registers are free here)
 #pragma unroll
         for (int u0 = 0; u0 < 4 * MT; u0 += 8) {
@@ -827,7 +837,9 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     } else
 #endif
     {
-      const int l15 = lane & 15, l4 = lane >> 4;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));             // (as in setup: keep the epilogue's lane constants out of the K loop's registers)
+      const int l15 = ln & 15, l4 = ln >> 4;
       const int row0 = cm0 + wm * WROWS + l15;                 // + 16 mi
       constexpr bool HAS_RES = EPI == EPI_BIAS_RES || EPI == EPI_RES;
       if constexpr (EPI == EPI_SWIGLU) {
@@ -906,7 +918,9 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     if (!has_next) break;
     // the counted waits of the K loop assume that only this wave's staging DMAs are outstanding, in issue order: retire the
     // epilogue's stores / residual loads (and with them the prefetch, long since landed) before the next tile starts counting
+#if !(defined(V3D_PP_PROBE) && V3D_PP_PROBE == 4)        // probe 4 (timing only, races): do not wait for the epilogue's stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   }
 #undef V3D_DSR
 #undef V3D_RDA
@@ -1096,7 +1110,7 @@ static bool sk_pays(int n_tiles, int grid, int nt) {           // the time model
   int sp = 1;
   const int dp = sk_plan(n_tiles, grid, nt, &sp);
   if (dp < 0) return false;
-  const double ks = (double)nt, round = 22.0 + 1.263 * ks;
+  const double ks = (double)nt, round = 22.0 + 1.25 * ks;
   return dp * round + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
 }
 struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int slots = 0; };
@@ -1172,8 +1186,8 @@ template <typename T>
 static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
   // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
   //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
-  //   256 x 256 ping-pong (256 slots): fixed 22 (prologue DMA latency, epilogue, dispatch), 1.263 per K-step
-  //   192 x 256 ping-pong (256 slots): fixed 10, 1.25 per K-step   (3/4 of the tile at the same step time: it only wins where
+  //   256 x 256 ping-pong (256 slots): fixed 22 (prologue DMA latency, epilogue, dispatch), 1.25 per K-step
+  //   192 x 256 ping-pong (256 slots): fixed 8, 1.24 per K-step   (3/4 of the tile at the same step time: it only wins where
   //                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
   //   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
   //   256 x 256 with the split-K tail: whole rounds as above + one round of (22 + step x K-steps / split + 40 for the exchange),
@@ -1185,15 +1199,15 @@ static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
     const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
     const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
     const int slots = pp_slots();
-    double t256 = (double)((tiles256 + 255) / 256) * (pp ? 22.0 + 1.263 * ks : 9.0 + 1.36 * ks);
-    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 10.0 + 1.25 * ks : 2.0 + 1.32 * ks);
-    const double t1 = (double)((p.tiles_m * p.tiles_n + 511) / 512) * (1.0 + 0.98 * ks);
+    double t256 = (double)((tiles256 + 255) / 256) * (pp ? 22.0 + 1.25 * ks : 9.0 + 1.36 * ks);
+    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 8.0 + 1.24 * ks : 2.0 + 1.32 * ks);
+    const double t1 = (double)((p.tiles_m * p.tiles_n + 511 - 25) / 512 > 0 ? (p.tiles_m * p.tiles_n + 511 - 25) / 512 : 1) * (1.0 + 0.98 * ks);   // (a last round under 5 % full is not felt)
     int sk_use = 0;
     if (pp && gemm_sk_mode() != 0) {
       int sp = 1;
       const int dp = sk_plan(tiles256, slots & ~7, p.K / BK, &sp);
       if (dp >= 0) {
-        const double tsk = dp * (22.0 + 1.263 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
+        const double tsk = dp * (22.0 + 1.25 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
         const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
         if (tsk < 0.95 * best || gemm_sk_mode() == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 5 % margin: the model is coarse)
       }
