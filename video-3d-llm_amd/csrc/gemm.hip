@@ -553,6 +553,15 @@ constexpr int PP_HALF = 128 * BK * 2;                   // 16 KiB per half-tile
 constexpr int PP_BUF = 4 * PP_HALF;                     // one K-step: A0 | W0 | W1 | A1
 constexpr int PP_LDS_BYTES = 256 * (B3N * 2 + 16);      // 132 KiB: the C tile of the epilogue (the 128 KiB ring fits inside)
 
+#ifdef V3D_PP_TIMELINE   // tools/probes/gemm_pp_timeline.hip only: shader-clock stamps around a tile of the ping-pong kernel
+__device__ unsigned long long g_pp_tl[256 * 8 * 8];     // [workgroup][wave][segment sums: 0 zero+first wait, 1 K loop, 2 ring-free barrier, 3 next-tile issue, 4 epilogue, 5 store drain, 6 tiles]
+#define V3D_TL(v) unsigned long long v; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory")
+#define V3D_TL_ACC(i, a, b) tl_acc[i] += (b) - (a)
+#else
+#define V3D_TL(v)
+#define V3D_TL_ACC(i, a, b)
+#endif
+
 template <typename T, int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -731,7 +740,11 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     setup(t0, t1);
   }
   stage(IntC<0>{}, k_begin); stage(IntC<1>{}, k_begin); stage(IntC<2>{}, k_begin); stage(IntC<3>{}, k_begin);
+#ifdef V3D_PP_TIMELINE
+  unsigned long long tl_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
   while (true) {
+    V3D_TL(tl0);
     // the NEXT segment is located here, before the accumulators are live (its integer divisions want registers)
     const int cur_kb = k_begin, cur_ke = k_end;
     int n_tm = 0, n_tn = 0;
@@ -751,15 +764,55 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     V3D_VM(6, 4);                                 // H0, H1 landed; (W A A) in flight (later tiles: everything but H4 landed long ago)
     V3D_BAR();
     if (wm == 1) V3D_BAR();                      // the wm = 1 waves run one barrier behind
+    V3D_TL(tl1);
     {
       int t = k_begin;
       for (; t < k_end - 2; ++t) kstep(IntC<0>{}, t);
       kstep(IntC<1>{}, t);
       kstep(IntC<2>{}, t + 1);
     }
+    V3D_TL(tl2);
+    // Epilogue operands - bias, and the residual rows of the first two 32-row quarters in the epilogue's read-back layout - are
+    // requested here and COMPLETED right after the ring-free barrier, before the next tile's DMAs are issued: the compiler waits for a
+    // load with a vmcnt that counts only the memory operations it knows, and a load issued after those DMAs would wait for their
+    // HBM latency too (16 k cycles per tile for a bias epilogue, 35-40 k for a residual one: tools/probes/gemm_pp_timeline.hip).
+    // (Asm loads with hand-counted waits were tried: hipcc spills or copies their destination registers while the data is in flight.)
+    constexpr bool HAS_RES = EPI == EPI_BIAS_RES || EPI == EPI_RES;
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    v2i_t e_bias[4];
+    v4i e_res[HAS_RES ? 2 : 1][4];
+    auto res_load = [&](int q, v4i (&dst)[4], int ln) {
+      const int colr = n0 + wn * 64 + (ln & 7) * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gm = m0 + wm * WROWS + 32 * q + (ln >> 3) + 8 * j;
+        const int gc = gm < p.M ? gm : p.M - 1;
+        const int64_t rm = p.res_mod > 0 ? (gc % p.res_mod) : gc;
+        dst[j] = *reinterpret_cast<const v4i*>((const T*)p.res + rm * p.ldr + colr);
+      }
+    };
+    if constexpr (EPI != EPI_SWIGLU) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      if constexpr (epi_has_bias(EPI)) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) e_bias[ni] = *reinterpret_cast<const v2i_t*>(bias + n0 + wn * 64 + 16 * ni + 4 * (ln >> 4));
+      }
+      if constexpr (HAS_RES) { res_load(0, e_res[0], ln); res_load(1, e_res[1], ln); }
+    }
     if (wm == 0) V3D_BAR();
     __syncthreads();                              // every fragment read of this tile is done: the whole ring is free
-
+    if constexpr (EPI != EPI_SWIGLU) {
+      if constexpr (epi_has_bias(EPI)) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) asm volatile("" : "+v"(e_bias[ni]));
+      }
+      if constexpr (HAS_RES) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(e_res[0][j])); asm volatile("" : "+v"(e_res[1][j])); }
+      }
+    }
+    V3D_TL(tl3);
 #if defined(V3D_PP_PROBE) && V3D_PP_PROBE == 3          // probe: every tile stores to tile (0, 0)'s output (C traffic stays in L2)
     const int cm0 = 0, cn0 = 0, ctn = 0;
 #else
@@ -775,6 +828,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     // cost more than the idle round it removes): the image and the flag travel with device-scope instructions instead - stores
     // written through (sc0 sc1), s_waitcnt vmcnt(0) = acknowledged, barrier, flag; the reader polls the flag with a device-scope
     // load and reads the image with loads that bypass the caches a stale copy could sit in.
+    V3D_TL(tl4);
     if (seg_tail) {
       // a chunk c > 0: hand the accumulators to the tile's chunk-0 workgroup (f32, lane-major: the reader has the same layout)
       const float* img = p.sk_ws + (size_t)blockIdx.x * (32 * 512 * 4);
@@ -805,18 +859,23 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
         const float* img = p.sk_ws + (size_t)from * (32 * 512 * 4);
         unsigned off = (unsigned)tid * 16u;
         asm volatile("" : "+v"(off));
-        // eight 16-byte loads in flight at a time (the fragment registers are free here)
+        // four 16-byte loads in flight at a time (more of them push accumulators out to scratch for EVERY tile, not just the cut ones).
+        // Loads AND their wait are one asm statement: hipcc may spill or copy an asm output the moment the statement ends, which for a
+        // load still in flight stores stale bytes and lets the returning data land in whatever reuses the register.
 #pragma unroll
-        for (int u0 = 0; u0 < 4 * MT; u0 += 8) {
-          f32x4 part[8];
+        for (int u0 = 0; u0 < 4 * MT; u0 += 4) {
+          f32x4 part[4];
+          const unsigned o0 = off, o1 = off + 512u * 16u, o2 = off + 2u * 512u * 16u, o3 = off + 3u * 512u * 16u;
+          asm volatile("global_load_dwordx4 %0, %4, %8 sc0 sc1\n\t"
+                       "global_load_dwordx4 %1, %5, %8 sc0 sc1\n\t"
+                       "global_load_dwordx4 %2, %6, %8 sc0 sc1\n\t"
+                       "global_load_dwordx4 %3, %7, %8 sc0 sc1\n\t"
+                       "s_waitcnt vmcnt(0)"
+                       : "=&v"(part[0]), "=&v"(part[1]), "=&v"(part[2]), "=&v"(part[3])
+                       : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(img) : "memory");
+          off += 4u * 512u * 16u;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(part[u]) : "v"(off), "s"(img) : "memory");
-            off += 512u * 16u;
-          }
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7]) : : "memory");
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
+          for (int u = 0; u < 4; ++u) {
             f32x4& a = acc[(u0 + u) / MT][(u0 + u) % MT];
             a[0] += part[u][0]; a[1] += part[u][1]; a[2] += part[u][2]; a[3] += part[u][3];
           }
@@ -824,11 +883,13 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       }
     }
 
-    // Epilogue straight from the accumulators (r02b; the LDS-staged form cost 6-8 % of an LLM tile and 15-25 % of a K = 1152 tile in
-    // barriers and the LDS round trip with the matrix cores idle): lane (l15 = lane & 15, l4 = lane >> 4) holds, per (ni, mi), the four
-    // consecutive output columns 64 wn + 16 ni + 4 l4 + r of row 128|96 wm + 16 mi + l15 - an 8-byte store per lane, sixteen rows x
-    // 32 bytes per instruction, four instructions complete a row's 128-byte line in L2.  Same arithmetic and rounding points as the
-    // staged form (product + bias rounded to 16 bits, then activation / residual on the rounded value, rounded again): bit-identical.
+    // Epilogue (r02b): each wave turns its own 128|96 x 64 part of the C tile around in a PRIVATE 6 KiB of LDS, 32 rows at a time -
+    // no workgroup barrier, and whole 128-byte row segments (16 bytes per lane, 8 rows per instruction) go out.  The two earlier forms
+    // both cost 5-12 us per tile (tools/probes/gemm_pp_timeline.hip): the workgroup-wide LDS staging in barriers with the matrix cores
+    // idle, 8-byte stores straight from the accumulators (a lane owns 4 columns) in 4096 32-byte write requests per tile.  The private
+    // regions sit in K-step buffer 1 above its first half-tile slot: buffer 0 receives the next tile's first K-step meanwhile, and the
+    // first DMA of the next K loop (H4 -> that first slot) may start while slower waves are still here.  Same arithmetic and rounding
+    // points as the other forms (product + bias rounded to 16 bits, activation / residual on the rounded value, rounded again).
 #ifdef V3D_PP_PROBE   // tools/probes/gemm_pp_probe.hip only (WRONG RESULTS): 1 = K loop alone, the accumulators folded into one store
     if (V3D_PP_PROBE == 1) {
       float sacc = 0.f;
@@ -840,80 +901,112 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       int ln = lane;
       asm volatile("" : "+v"(ln));             // (as in setup: keep the epilogue's lane constants out of the K loop's registers)
       const int l15 = ln & 15, l4 = ln >> 4;
-      const int row0 = cm0 + wm * WROWS + l15;                 // + 16 mi
-      constexpr bool HAS_RES = EPI == EPI_BIAS_RES || EPI == EPI_RES;
+      char* const reg = smem + PP_BUF + PP_HALF + wave * 6144;
       if constexpr (EPI == EPI_SWIGLU) {
-        T* const orow = out + ctn * 128 + (wn >> 1) * 64 + (wn & 1) * 32 + 4 * l4;     // + 16 n2
+        // silu(gate) * up in registers (the wave holds both, see setup), 32 output columns per wave: rows of 64 bytes, pitch 80
+        constexpr int CP = 80;
+        const int rrow = ln >> 2, rch = ln & 3;                 // read-back: 16 rows x 4 chunks per instruction
+        T* const obase = out + ctn * 128 + (wn >> 1) * 64 + (wn & 1) * 32 + rch * 8;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int gm = row0 + 16 * mi;
-          if (gm < p.M) {
+        for (int q = 0; q < MT / 2; ++q) {
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
+              const int mi = 2 * q + m2;
               float v[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = round_to<T>(silu(round_to<T>(acc[n2][mi][r]))) * round_to<T>(acc[2 + n2][mi][r]);
               uint2 pk;
               pk.x = pack2<T>(v[0], v[1]); pk.y = pack2<T>(v[2], v[3]);
-              *reinterpret_cast<uint2*>(orow + (int64_t)gm * p.ldo + 16 * n2) = pk;
+              *reinterpret_cast<uint2*>(reg + (m2 * 16 + l15) * CP + (16 * n2 + 4 * l4) * 2) = pk;
             }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = rrow + 16 * j;
+            const uint4 c = *reinterpret_cast<const uint4*>(reg + row * CP + rch * 16);
+            const int gm = cm0 + wm * WROWS + 32 * q + row;
+            if (gm < p.M) *reinterpret_cast<uint4*>(obase + (int64_t)gm * p.ldo) = c;
           }
         }
       } else {
-        const int col0 = cn0 + wn * 64 + 4 * l4;                // + 16 ni
+        constexpr int CP = 144;                                 // 64 columns = 128 bytes per row + 16
+        const int rrow = ln >> 3, rch = ln & 7;                 // read-back: 8 rows x 8 chunks (whole 128-byte lines) per instruction
+        const int colr = cn0 + wn * 64 + rch * 8;
+        auto res_load_c = [&](int q, v4i (&dst)[4]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int gm = cm0 + wm * WROWS + 32 * q + rrow + 8 * j;
+            const int gc = gm < p.M ? gm : p.M - 1;
+            const int64_t rm = p.res_mod > 0 ? (gc % p.res_mod) : gc;
+            dst[j] = *reinterpret_cast<const v4i*>((const T*)p.res + rm * p.ldr + colr);
+          }
+        };
         float bv[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
           if (epi_has_bias(EPI)) {
-            const uint2 b2 = *reinterpret_cast<const uint2*>(bias + col0 + 16 * ni);
+            const uint2 b2 = make_uint2((unsigned)e_bias[ni][0], (unsigned)e_bias[ni][1]);
             bv[ni][0] = pair_lo<T>(b2.x); bv[ni][1] = pair_hi<T>(b2.x); bv[ni][2] = pair_lo<T>(b2.y); bv[ni][3] = pair_hi<T>(b2.y);
           } else {
             bv[ni][0] = bv[ni][1] = bv[ni][2] = bv[ni][3] = 0.f;
           }
         }
-        // residual rows: the four 8-byte loads of the NEXT mi are in flight while this one is finished (fragment registers are free)
-        uint2 rr[2][4];
-        auto load_res = [&](int mi, uint2 (&dst)[4]) {
-          const int gm = row0 + 16 * mi;
-          const int gc = gm < p.M ? gm : p.M - 1;
-          const int64_t rm = p.res_mod > 0 ? (gc % p.res_mod) : gc;
-          const T* rp = (const T*)p.res + rm * p.ldr + col0;
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) dst[ni] = *reinterpret_cast<const uint2*>(rp + 16 * ni);
-        };
-        if constexpr (HAS_RES) load_res(0, rr[0]);
+        for (int q = 0; q < MT / 2; ++q) {
+          uint4 rr[4];
+          if constexpr (HAS_RES) {
+            // quarters 0, 1 were requested after the K loop; 2 (, 3) are requested when 1 has been consumed (the next tile's DMAs,
+            // issued before these loads, have landed or nearly so by then)
+            if (q == 2) { res_load_c(2, e_res[0]); if (MT / 2 > 3) res_load_c(3, e_res[1]); }
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          if constexpr (HAS_RES) { if (mi + 1 < MT) load_res(mi + 1, rr[(mi + 1) & 1]); }
-          const int gm = row0 + 16 * mi;
-          if (gm < p.M) {
+            for (int j = 0; j < 4; ++j) {
+              rr[j] = make_uint4((unsigned)e_res[q & 1][j][0], (unsigned)e_res[q & 1][j][1], (unsigned)e_res[q & 1][j][2], (unsigned)e_res[q & 1][j][3]);
+            }
+          }
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-              float v[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + bv[ni][r];
-              if constexpr (EPI != EPI_NONE && EPI != EPI_BIAS) {
-                float q[4];
-                if constexpr (HAS_RES) {
-                  const uint2 r2 = rr[mi & 1][ni];
-                  q[0] = pair_lo<T>(r2.x); q[1] = pair_hi<T>(r2.x); q[2] = pair_lo<T>(r2.y); q[3] = pair_hi<T>(r2.y);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const float x = round_to<T>(v[r]);
-                  v[r] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f) : x + q[r];
-                }
-              }
+              const int mi = 2 * q + m2;
               uint2 pk;
-              pk.x = pack2<T>(v[0], v[1]); pk.y = pack2<T>(v[2], v[3]);
-              *reinterpret_cast<uint2*>(out + (int64_t)gm * p.ldo + col0 + 16 * ni) = pk;
+              pk.x = pack2<T>(acc[ni][mi][0] + bv[ni][0], acc[ni][mi][1] + bv[ni][1]);
+              pk.y = pack2<T>(acc[ni][mi][2] + bv[ni][2], acc[ni][mi][3] + bv[ni][3]);
+              *reinterpret_cast<uint2*>(reg + (m2 * 16 + l15) * CP + (16 * ni + 4 * l4) * 2) = pk;
             }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = rrow + 8 * j;
+            uint4 c = *reinterpret_cast<const uint4*>(reg + row * CP + rch * 16);
+            const int gm = cm0 + wm * WROWS + 32 * q + row;
+            if constexpr (EPI != EPI_NONE && EPI != EPI_BIAS) {
+              float v[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float x = vec_get<T>(c, e);
+                v[e] = EPI == EPI_BIAS_GELU_ERF ? gelu_erf(x) : EPI == EPI_BIAS_GELU_TANH ? gelu_tanh(x) : EPI == EPI_BIAS_RELU ? fmaxf(x, 0.f)
+                                                                                                                                : x + (HAS_RES ? vec_get<T>(rr[j], e) : 0.f);
+              }
+              c = vec_pack<T>(v);
+            }
+            if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + colr) = c;
           }
         }
       }
     }
 #ifdef V3D_PP_PROBE
     if (V3D_PP_PROBE == 2) { if (!has_next) break; asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; }
+#endif
+    V3D_TL(tl5);
+#ifdef V3D_PP_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    { V3D_TL(tl6);
+      V3D_TL_ACC(0, tl0, tl1); V3D_TL_ACC(1, tl1, tl2); V3D_TL_ACC(2, tl2, tl3); V3D_TL_ACC(3, tl3, tl4); V3D_TL_ACC(4, tl4, tl5); V3D_TL_ACC(5, tl5, tl6);
+      tl_acc[6] += 1; }
+    if (!has_next) {
+      if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 7; ++i) g_pp_tl[((int)blockIdx.x * 8 + wave) * 8 + i] = tl_acc[i];
+    }
 #endif
     if (!has_next) break;
     // the counted waits of the K loop assume that only this wave's staging DMAs are outstanding, in issue order: retire the
