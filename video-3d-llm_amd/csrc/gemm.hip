@@ -1209,12 +1209,12 @@ static bool sk_pays(int n_tiles, int grid, int nt) {           // the time model
 struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int slots = 0; };
 // One workspace per stream (launches on one stream are ordered; two streams must not share accumulator images).  Allocated on
 // first use, never during stream capture (the caller then gets the plain walk).
-static SkWorkspace* sk_workspace(hipStream_t st, int grid) {
+static SkWorkspace* sk_workspace(hipStream_t st, int grid, unsigned* epoch) {      // *epoch: this launch's flag value (taken under the lock)
   static std::mutex mu;
   static std::unordered_map<hipStream_t, SkWorkspace> map;
   std::lock_guard<std::mutex> lock(mu);
   SkWorkspace& w = map[st];
-  if (w.slots >= grid) return &w;
+  if (w.slots >= grid) { *epoch = ++w.epoch; return &w; }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
   if (w.ws) { (void)hipStreamSynchronize(st); (void)hipFree(w.ws); w = SkWorkspace{}; }
@@ -1225,6 +1225,7 @@ static SkWorkspace* sk_workspace(hipStream_t st, int grid) {
   w.flags = (unsigned*)((char*)ptr + (size_t)grid * img);
   if (hipMemsetAsync(w.flags, 0, (size_t)grid * sizeof(unsigned), st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); w = SkWorkspace{}; return nullptr; }
   w.slots = grid; w.epoch = 0;
+  *epoch = ++w.epoch;
   return &w;
 }
 
@@ -1242,8 +1243,9 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
     const int slots = pp_slots() & ~7;
     const int mode = gemm_sk_mode(), dp = sk_plan(n_tiles, slots, p.K / BK, &split);
     if (mode != 0 && dp >= 0 && (mode == 2 || (sk_allow < 0 ? sk_pays(n_tiles, slots, p.K / BK) : sk_allow != 0))) {
-      if (SkWorkspace* w = sk_workspace(st, slots)) {
-        p.sk_dp = dp; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = ++w->epoch;
+      unsigned epoch = 0;
+      if (SkWorkspace* w = sk_workspace(st, slots, &epoch)) {
+        p.sk_dp = dp; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = epoch;
         p.skew = 0;
         grid = slots;                                               // (also when n_tiles < slots: the chunks fill the chip)
       }
