@@ -62,13 +62,17 @@ def _zero2_worker(rank, world, port, q):
     grad = torch.randn(numel, generator=g)
     part = D.reduce_scatter_grads(grad, bucket_elems=128)          # several buckets
     part_one = D.reduce_scatter_grads(grad, bucket_elems=10 ** 9)  # one bucket: same result
+    try:
+        part_direct = D.reduce_scatter_grads(grad, bucket_elems=128, algorithm="direct")    # one-shot all-to-all + local sum
+    except RuntimeError as e:                                      # a gloo build without all-to-all: say so, do not pass silently
+        part_direct = str(e)
     bounds, per = D.partition_bounds(numel, world)
     params = torch.arange(numel, dtype=torch.float32)
     mine = torch.zeros(per)
     b, e = bounds[rank]
     mine[: e - b] = params[b:e] - 0.1 * part[: e - b]              # an SGD step on the rank's own partition
     full = D.all_gather_params(mine, numel, bucket_elems=200)
-    q.put((rank, part, part_one, full))
+    q.put((rank, part, part_one, full, part_direct))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,7 +93,9 @@ def test_zero2_reduce_scatter_and_all_gather_world2():
     grads = [torch.randn(1003, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)]
     mean = (grads[0] + grads[1]) / 2
     bounds, per = D.partition_bounds(1003, 2)
-    for rank, part, part_one, full in res:
+    for rank, part, part_one, full, part_direct in res:
         b, e = bounds[rank]
         assert torch.allclose(part[: e - b], mean[b:e]) and torch.equal(part, part_one) and not bool(part[e - b:].any())
+        assert not isinstance(part_direct, str), part_direct
+        assert torch.allclose(part_direct, part) and not bool(part_direct[e - b:].any())
         assert torch.allclose(full, torch.arange(1003, dtype=torch.float32) - 0.1 * mean)

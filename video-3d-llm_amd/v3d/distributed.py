@@ -61,11 +61,18 @@ def partition_bounds(numel, world):
     return [(min(r * per, numel), min((r + 1) * per, numel)) for r in range(world)], per
 
 
-def reduce_scatter_grads(flat_grad, bucket_elems=ZERO2_BUCKET_ELEMS, average=True):
+def reduce_scatter_grads(flat_grad, bucket_elems=ZERO2_BUCKET_ELEMS, average=True, algorithm="ring"):
     """flat_grad: this rank's flat gradient buffer [numel] (any float dtype).  Returns this rank's partition of the SUM (or
     mean) over ranks, [per] (zero-padded at the tail), exchanged bucket by bucket so that no more than `bucket_elems` elements are
-    in flight: per bucket ONE reduce-scatter (RCCL) - or, where the backend has none (gloo), an all-reduce of the bucket followed
-    by the local slice (same result, CPU tests only)."""
+    in flight.  algorithm:
+      "ring"    per bucket ONE reduce-scatter of the backend (RCCL) - or, where the backend has none (gloo), an all-reduce of the
+                bucket followed by the local slice (same result, CPU tests only);
+      "direct"  per bucket ONE all-to-all (rank r receives every peer's r-th chunk) and a local sum in rank order: on the
+                point-to-point xGMI mesh every peer pair has its own link, so the one-shot exchange moves a bucket over all seven
+                links at once where a ring is bound by one; the sum order is fixed, so the result does not
+                depend on arrival order.  (Not yet run on an 8-GPU node: CPU test with gloo, world 2.)"""
+    if algorithm not in ("ring", "direct"):
+        raise ValueError(f"unknown reduce-scatter algorithm {algorithm!r}")
     world, rank = dist.get_world_size(), dist.get_rank()
     numel = flat_grad.numel()
     bounds, per = partition_bounds(numel, world)
@@ -81,7 +88,11 @@ def reduce_scatter_grads(flat_grad, bucket_elems=ZERO2_BUCKET_ELEMS, average=Tru
             e = min(b + n, numel)
             if e > b:
                 send[r * n: r * n + (e - b)] = flat_grad[b:e]
-        if has_rs:
+        if algorithm == "direct":
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send)                      # recv[r * n : (r + 1) * n] = rank r's chunk for this rank
+            out[o: o + n] = recv.view(world, n).sum(dim=0)
+        elif has_rs:
             dist.reduce_scatter_tensor(out[o: o + n], send, op=dist.ReduceOp.SUM)
         else:
             dist.all_reduce(send, op=dist.ReduceOp.SUM)
