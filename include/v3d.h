@@ -345,6 +345,13 @@ int v3d_visual_tokens_grad(const void* dout, int64_t dout_stride, void* dfeat, f
 
 /* ------------------------------------------------------------------ host helpers -------- */
 
+/* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;
+ * defaults of the V3D_GEMM_* switches): *kernel 0 = skinny (M <= 8), 1 = 128 x 128 tile, 2 = 256 x 256 ping-pong, 3 = 192 x 256
+ * ping-pong; *tiles of that kernel; with the split-K tail (kernel 2 only) *dp = whole-tile rounds and *split = K-chunks per left-over
+ * tile (2..4), else *dp = -1, *split = 1.  Invariants a test can hold it to: (tiles - dp * (slots & ~7)) * split <= slots & ~7 (every
+ * chunk has a workgroup), K / 64 even and K / 128 >= 2 * split (a chunk is at least two 2-K-step granules). */
+int v3d_gemm_plan_host(int M, int N, int K, int slots, int* kernel, int* tiles, int* dp, int* split);
+
 /* a1  llava/video_utils.py:187  np.linspace(0, total-1, n, dtype=int).  out_host[n]. */
 int v3d_uniform_frame_indices_host(int total_frames, int n, int32_t* out_host);
 

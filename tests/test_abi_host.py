@@ -89,3 +89,69 @@ def test_host_half_under_asan_ubsan():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "video-3d-llm_amd", "csrc"), "sanitize"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "host_selftest ok" in r.stdout
+
+
+def _plan(M, N, K, slots=256):
+    import ctypes
+    out = [ctypes.c_int(0) for _ in range(4)]
+    rc = _native.lib().v3d_gemm_plan_host(M, N, K, slots, *[ctypes.byref(o) for o in out])
+    assert rc == 0, _native.lib().v3d_last_error()
+    return tuple(o.value for o in out)          # kernel, tiles, dp, split
+
+
+def test_gemm_plan_of_the_paths_shapes():
+    """The tile choice for the shapes of the path on a 256-CU chip (host code only): the decoder's gate/up and qkv take whole rounds
+    of the 256 x 256 tile, o_proj the 192-row tile, down_proj (378 tiles = 1.48 rounds, K = 18944) the split-K tail, a batch of
+    question rows the 128 x 128 tile except for its down_proj (56 tiles cut in four)."""
+    assert _plan(6794, 37888, 3584) == (2, 27 * 148, -1, 1)
+    assert _plan(6794, 4608, 3584) == (2, 27 * 18, -1, 1)
+    assert _plan(6794, 3584, 3584)[0] == 3
+    assert _plan(6794, 3584, 18944) == (2, 378, 1, 2)
+    assert _plan(960, 3584, 18944) == (2, 56, 0, 4)
+    assert _plan(960, 4608, 3584)[0] == 1
+    assert _plan(4, 3584, 3584)[0] == 0                        # skinny (decode) path
+    assert _plan(23328, 1152, 1152)[0] == 1                    # N % 256 != 0: only the 128 x 128 tile fits
+
+
+def test_gemm_split_k_plans_are_well_formed():
+    """Every split-K plan the launcher can produce must give each K-chunk a workgroup and each chunk-0 workgroup existing partners -
+    a plan that does not would leave a workgroup polling a flag nobody raises.  Sweep of shapes and chip sizes; the item list
+    is rebuilt here the way the kernel walks it (gemm256pp_kernel: XCD-major id g = xcd * wx + idx, item g = (chunk g / T, tile g mod T))."""
+    rng = np.random.default_rng(5)
+    seen = 0
+    for _ in range(4000):
+        M = int(rng.integers(9, 30000))
+        N = 256 * int(rng.integers(1, 160))
+        K = 64 * int(rng.integers(1, 320))
+        slots = int(rng.choice([8, 16, 64, 104, 256, 304]))
+        kernel, tiles, dp, split = _plan(M, N, K, slots)
+        assert kernel in (1, 2, 3)
+        if dp < 0:
+            assert split == 1
+            continue
+        seen += 1
+        grid = slots & ~7
+        assert kernel == 2 and tiles == ((M + 255) // 256) * (N // 256)
+        nt = K // 64
+        T = tiles - dp * grid                                  # tiles left after the whole-tile rounds
+        assert 2 <= split <= 4 and dp >= 0 and T > 0
+        assert T * split <= grid, "a chunk without a workgroup"
+        assert nt % 2 == 0 and (nt // 2) >= 2 * split, "a chunk shorter than two granules"
+        wx = grid // 8
+        owners = {}
+        for b in range(grid):                                  # workgroup id -> its tail item
+            g = (b & 7) * wx + (b >> 3)
+            if g < split * T:
+                owners[(g // T, g % T)] = b
+        assert len(owners) == split * T                        # every (chunk, tile) exactly once
+        for j in range(T):
+            b0 = owners[(0, j)]
+            g0 = (b0 & 7) * wx + (b0 >> 3)
+            for c in range(1, split):
+                fg = c * T + g0                                # the kernel's partner formula
+                partner = (fg % wx) * 8 + fg // wx
+                assert partner == owners[(c, j)] and partner < grid
+            gpt = nt // 2
+            cuts = [2 * (c * gpt // split) for c in range(split + 1)]
+            assert cuts[0] == 0 and cuts[-1] == nt and all(b - a >= 2 for a, b in zip(cuts, cuts[1:]))
+    assert seen > 50

@@ -1277,41 +1277,49 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
   return check_launch("v3d_gemm (256-wide, ping-pong)");
 }
 
+// Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
+//   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
+//   256 x 256 ping-pong (256 slots): fixed 22 (prologue DMA latency, epilogue, dispatch), 1.25 per K-step
+//   192 x 256 ping-pong (256 slots): fixed 8, 1.24 per K-step   (3/4 of the tile at the same step time: it only wins where
+//                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
+//   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
+//   256 x 256 with the split-K tail: whole rounds as above + one round of (22 + step x K-steps / split + 40 for the exchange),
+//                                    step 1.3 when the launch is only the tail, 1.7 behind whole rounds (measured: 6794 x 3584 x 18944
+//                                    780 -> 685 us, 960 x 3584 x 18944 330 -> 152 us; no gain at K = 3584)
+struct GemmPlan { int kernel; int sk; int dp; int split; int tiles; };    // kernel: 1 = 128 x 128, 2 = 256 x 256, 3 = 192 x 256 (2, 3: ping-pong or v3)
+static GemmPlan gemm_plan(int M, int N, int K, int slots, int var, bool pp_on, int sk_mode) {
+  GemmPlan g = {1, 0, -1, 1, ((M + BM - 1) / BM) * (N / BN)};
+  if (N % B3N != 0 || var == 1) return g;
+  const double ks = (double)(K / BK);
+  const int tiles256 = ((M + 255) / 256) * (N / B3N), tiles192 = ((M + 191) / 192) * (N / B3N);
+  const bool pp = pp_on && K >= 2 * BK;
+  double t256 = (double)((tiles256 + 255) / 256) * (pp ? 22.0 + 1.25 * ks : 9.0 + 1.36 * ks);
+  const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 8.0 + 1.24 * ks : 2.0 + 1.32 * ks);
+  const int r1 = (g.tiles + 511 - 25) / 512;                     // (a last round under 5 % full is not felt)
+  const double t1 = (double)(r1 > 0 ? r1 : 1) * (1.0 + 0.98 * ks);
+  int sk_use = 0, sp = 1, dp = -1;
+  if (pp && sk_mode != 0) {
+    dp = sk_plan(tiles256, slots & ~7, K / BK, &sp);
+    if (dp >= 0) {
+      const double tsk = dp * (22.0 + 1.25 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
+      const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
+      if (tsk < 0.95 * best || sk_mode == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 5 % margin: the model is coarse)
+    }
+  }
+  if (var == 4) { g.kernel = 3; g.tiles = tiles192; g.sk = -1; return g; }       // forced tiles decide the split themselves (sk = -1)
+  if (var == 3) { g.kernel = 2; g.tiles = tiles256; g.sk = -1; return g; }
+  if (t192 < t256 && t192 < t1) { g.kernel = 3; g.tiles = tiles192; return g; }
+  if (t256 < t1) { g.kernel = 2; g.tiles = tiles256; g.sk = sk_use; if (sk_use) { g.dp = dp; g.split = sp; } return g; }
+  return g;
+}
+
 template <typename T>
 static int launch_gemm(const GemmArgs& p, int epi, hipStream_t st) {
-  // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
-  //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
-  //   256 x 256 ping-pong (256 slots): fixed 22 (prologue DMA latency, epilogue, dispatch), 1.25 per K-step
-  //   192 x 256 ping-pong (256 slots): fixed 8, 1.24 per K-step   (3/4 of the tile at the same step time: it only wins where
-  //                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
-  //   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
-  //   256 x 256 with the split-K tail: whole rounds as above + one round of (22 + step x K-steps / split + 40 for the exchange),
-  //                                    step 1.3 when the launch is only the tail, 1.7 behind whole rounds (measured: 6794 x 3584 x 18944
-  //                                    805 -> 715 us, 960 x 3584 x 18944 326 -> 165 us; no gain at K = 3584)
-  const int var = gemm_variant();
-  if (p.N % B3N == 0 && var != 1) {
-    const double ks = (double)(p.K / BK);
-    const int tiles256 = ((p.M + 255) / 256) * (p.N / B3N), tiles192 = ((p.M + 191) / 192) * (p.N / B3N);
-    const bool pp = gemm_pp_mode() != 0 && p.K >= 2 * BK;
-    const int slots = pp_slots();
-    double t256 = (double)((tiles256 + 255) / 256) * (pp ? 22.0 + 1.25 * ks : 9.0 + 1.36 * ks);
-    const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 8.0 + 1.24 * ks : 2.0 + 1.32 * ks);
-    const double t1 = (double)((p.tiles_m * p.tiles_n + 511 - 25) / 512 > 0 ? (p.tiles_m * p.tiles_n + 511 - 25) / 512 : 1) * (1.0 + 0.98 * ks);   // (a last round under 5 % full is not felt)
-    int sk_use = 0;
-    if (pp && gemm_sk_mode() != 0) {
-      int sp = 1;
-      const int dp = sk_plan(tiles256, slots & ~7, p.K / BK, &sp);
-      if (dp >= 0) {
-        const double tsk = dp * (22.0 + 1.25 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
-        const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
-        if (tsk < 0.95 * best || gemm_sk_mode() == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 5 % margin: the model is coarse)
-      }
-    }
-    if (var == 4) return pp ? launch_gemm256pp<T, 6>(p, epi, st) : launch_gemm256x256<T, 6>(p, epi, st);
-    if (var == 3) return pp ? launch_gemm256pp<T, 8>(p, epi, st) : launch_gemm256x256<T, 8>(p, epi, st);       // (forced tiles decide the split themselves)
-    if (t192 < t256 && t192 < t1) return pp ? launch_gemm256pp<T, 6>(p, epi, st, 0) : launch_gemm256x256<T, 6>(p, epi, st);
-    if (t256 < t1) return pp ? launch_gemm256pp<T, 8>(p, epi, st, sk_use) : launch_gemm256x256<T, 8>(p, epi, st);
-  }
+  const bool pp_on = gemm_pp_mode() != 0;
+  const GemmPlan g = gemm_plan(p.M, p.N, p.K, pp_slots(), gemm_variant(), pp_on, gemm_sk_mode());
+  const bool pp = pp_on && p.K >= 2 * BK;
+  if (g.kernel == 3) return pp ? launch_gemm256pp<T, 6>(p, epi, st, g.sk < 0 ? -1 : 0) : launch_gemm256x256<T, 6>(p, epi, st);
+  if (g.kernel == 2) return pp ? launch_gemm256pp<T, 8>(p, epi, st, g.sk) : launch_gemm256x256<T, 8>(p, epi, st);
 #define V3D_GEMM_CASE(E)                                                                                  \
   case E: {                                                                                               \
     auto k = gemm_kernel<T, E>;                                                                           \
@@ -1359,6 +1367,15 @@ static int launch_gemv(const GemmArgs& p, int epi, hipStream_t st) {
 }  // namespace v3d
 
 using namespace v3d;
+
+extern "C" int v3d_gemm_plan_host(int M, int N, int K, int slots, int* kernel, int* tiles, int* dp, int* split) {
+  V3D_REQUIRE(M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0 && slots > 0, "v3d_gemm_plan_host: bad shape");
+  V3D_REQUIRE(kernel && tiles && dp && split, "v3d_gemm_plan_host: null pointer");
+  if (M <= 8) { *kernel = 0; *tiles = 0; *dp = -1; *split = 1; return V3D_OK; }
+  const GemmPlan g = gemm_plan(M, N, K, slots, 0, true, 1);
+  *kernel = g.kernel; *tiles = g.tiles; *dp = g.sk > 0 ? g.dp : -1; *split = g.sk > 0 ? g.split : 1;
+  return V3D_OK;
+}
 
 extern "C" int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, const void* res,
                         int64_t ldr, int res_mod, void* out, int64_t ldo, int M, int N, int K, int dtype, int epilogue,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "v3d_cross_entropy_grad": (c_i, [c_p, c_l, c_i, c_l, c_i, c_p, c_l, c_p, c_p, c_f, c_p, c_l, c_i, c_p]),
     "v3d_visual_tokens_grad": (c_i, [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),
+    "v3d_gemm_plan_host": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "v3d_voxel_keys_f32": (c_i, [c_p, c_l, c_f, c_p, c_p]),
     "v3d_greedy_cover_workspace_bytes": (c_l, [c_i, c_l]),
     "v3d_greedy_cover": (c_i, [c_p, c_i, c_l, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p]),
