@@ -81,7 +81,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Fp8GemmArgs p) {
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + i * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    w_off[i] = (unsigned)((n0 + row) * (int)p.ldw + chunk * 16);
+    // SwiGLU (tile columns = two groups of [gate64 | up64]): wave column wn = row >> 6 gets the gate columns and the MATCHING up
+    // columns of one 32-wide output block, so silu(gate) * up is formed in registers (as gemm256pp_kernel)
+    const int wcol = EPI == F8_EPI_SWIGLU ? 128 * (row >> 7) + ((row & 32) ? 64 : 0) + 32 * ((row >> 6) & 1) + (row & 31) : row;
+    w_off[i] = (unsigned)((n0 + wcol) * (int)p.ldw + chunk * 16);
   }
   auto stage = [&](int buf, int kt) {
     char* ba = smem + buf * F8_STAGE + (wave * APW * 8) * F8_BK;
@@ -163,66 +166,108 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Fp8GemmArgs p) {
   }
   __syncthreads();
 
-  // epilogue: dequantise (sa[m] * sw[n]), then as the bf16 kernel: two halves through LDS, whole rows out
-  constexpr int C_ROW = F8_BN * 2 + 16;
+  // epilogue: dequantise (sa[m] * sw[n]), then as gemm256pp_kernel: each wave turns its 128 x 64 part of the C tile around in a
+  // private 8 KiB of LDS, 32 rows at a time - no workgroup barrier, whole row segments out; SwiGLU formed in registers first
   const T* bias = (const T*)p.bias;
   T* out = (T*)p.out;
+  {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int l15 = ln & 15, l4 = ln >> 4;
+    char* const reg = smem + wave * 8192;
+    if constexpr (EPI == F8_EPI_SWIGLU) {
+      constexpr int CP = 80;
+      const int rrow = ln >> 2, rch = ln & 3;
+      const int gcol = n0 + 128 * (wn >> 1) + 32 * (wn & 1) + 4 * l4;       // + 16 n2 (+ 64 for up): W rows behind acc[n2] / acc[2 + n2]
+      float swg[2][4], swu[2][4];
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (wm == half) {
+      for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int nl = wn * 64 + ni * 16 + 4 * (lane >> 4);
-        float swv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) { swg[n2][r] = p.sw[gcol + 16 * n2 + r]; swu[n2][r] = p.sw[gcol + 64 + 16 * n2 + r]; }
+      T* const obase = out + tn * 128 + (wn >> 1) * 64 + (wn & 1) * 32 + rch * 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) swv[r] = p.sw[n0 + nl + r];
-        if (bias != nullptr) {
+      for (int q = 0; q < MT / 2; ++q) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) bv[r] = to_f32(bias[n0 + nl + r]);
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const int mi = 2 * q + m2;
+          int gmc = m0 + wm * WROWS + 16 * mi + l15;
+          gmc = gmc < p.M ? gmc : p.M - 1;
+          const float sa = p.sa[gmc];
+#pragma unroll
+          for (int n2 = 0; n2 < 2; ++n2) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              v[r] = round_to<T>(silu8(round_to<T>(acc[n2][mi][r] * (sa * swg[n2][r])))) * round_to<T>(acc[2 + n2][mi][r] * (sa * swu[n2][r]));
+            uint2 pk;
+            pk.x = pack2<T>(v[0], v[1]); pk.y = pack2<T>(v[2], v[3]);
+            *reinterpret_cast<uint2*>(reg + (m2 * 16 + l15) * CP + (16 * n2 + 4 * l4) * 2) = pk;
+          }
         }
+        uint4 cq[2];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          const int ml = mi * 16 + (lane & 15);
-          int gm = m0 + half * WROWS + ml;
-          gm = gm < p.M ? gm : p.M - 1;
-          const float sa = p.sa[gm];
-          uint2 pk;
-          pk.x = pack2<T>(acc[ni][mi][0] * (sa * swv[0]) + bv[0], acc[ni][mi][1] * (sa * swv[1]) + bv[1]);
-          pk.y = pack2<T>(acc[ni][mi][2] * (sa * swv[2]) + bv[2], acc[ni][mi][3] * (sa * swv[3]) + bv[3]);
-          *reinterpret_cast<uint2*>(smem + ml * C_ROW + nl * 2) = pk;
+        for (int j = 0; j < 2; ++j) cq[j] = *reinterpret_cast<const uint4*>(reg + (rrow + 16 * j) * CP + rch * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int gm = m0 + wm * WROWS + 32 * q + rrow + 16 * j;
+          if (gm < p.M) *reinterpret_cast<uint4*>(obase + (int64_t)gm * p.ldo) = cq[j];
         }
-      }
-    }
-    __syncthreads();
-    if (EPI == F8_EPI_SWIGLU) {
-      for (int row = tid >> 4; row < WROWS; row += 32) {
-        const int c16 = tid & 15, grp = c16 >> 3, ch = c16 & 7;
-        const int gm = m0 + half * WROWS + row;
-        const uint4 gg = *reinterpret_cast<const uint4*>(smem + row * C_ROW + grp * 256 + ch * 16);
-        const uint4 uu = *reinterpret_cast<const uint4*>(smem + row * C_ROW + grp * 256 + 128 + ch * 16);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = round_to<T>(silu8(vec_get<T>(gg, j))) * vec_get<T>(uu, j);
-        if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + tn * 128 + grp * 64 + ch * 8) = vec_pack<T>(v);
       }
     } else {
-      for (int row = tid >> 5; row < WROWS; row += 16) {
-        const int ch = tid & 31;
-        const int gm = m0 + half * WROWS + row;
-        if (gm < p.M) {
-          uint4 c = *reinterpret_cast<const uint4*>(smem + row * C_ROW + ch * 16);
-          if (EPI == F8_EPI_RES) {
-            const uint4 rr = *reinterpret_cast<const uint4*>((const T*)p.res + (int64_t)gm * p.ldr + n0 + ch * 8);
+      constexpr int CP = 144;
+      const int rrow = ln >> 3, rch = ln & 7;
+      const int colr = n0 + wn * 64 + rch * 8;
+      float swv[4][4], bv[4][4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = n0 + wn * 64 + 16 * ni + 4 * l4 + r;
+          swv[ni][r] = p.sw[c];
+          bv[ni][r] = bias != nullptr ? to_f32(bias[c]) : 0.f;
+        }
+#pragma unroll
+      for (int q = 0; q < MT / 2; ++q) {
+        uint4 rr[4];
+        if constexpr (EPI == F8_EPI_RES) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int gc = m0 + wm * WROWS + 32 * q + rrow + 8 * j;
+            gc = gc < p.M ? gc : p.M - 1;
+            rr[j] = *reinterpret_cast<const uint4*>((const T*)p.res + (int64_t)gc * p.ldr + colr);
+          }
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const int mi = 2 * q + m2;
+          int gmc = m0 + wm * WROWS + 16 * mi + l15;
+          gmc = gmc < p.M ? gmc : p.M - 1;
+          const float sa = p.sa[gmc];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            uint2 pk;
+            pk.x = pack2<T>(acc[ni][mi][0] * (sa * swv[ni][0]) + bv[ni][0], acc[ni][mi][1] * (sa * swv[ni][1]) + bv[ni][1]);
+            pk.y = pack2<T>(acc[ni][mi][2] * (sa * swv[ni][2]) + bv[ni][2], acc[ni][mi][3] * (sa * swv[ni][3]) + bv[ni][3]);
+            *reinterpret_cast<uint2*>(reg + (m2 * 16 + l15) * CP + (16 * ni + 4 * l4) * 2) = pk;
+          }
+        }
+        uint4 cq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cq[j] = *reinterpret_cast<const uint4*>(reg + (rrow + 8 * j) * CP + rch * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint4 c = cq[j];
+          const int gm = m0 + wm * WROWS + 32 * q + rrow + 8 * j;
+          if constexpr (EPI == F8_EPI_RES) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = vec_get<T>(c, j) + vec_get<T>(rr, j);
+            for (int e = 0; e < 8; ++e) v[e] = vec_get<T>(c, e) + vec_get<T>(rr[j], e);
             c = vec_pack<T>(v);
           }
-          *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + n0 + ch * 8) = c;
+          if (gm < p.M) *reinterpret_cast<uint4*>(out + (int64_t)gm * p.ldo + colr) = c;
         }
       }
     }
-    __syncthreads();
   }
 #undef F8_DSR
 #undef F8_RDT
