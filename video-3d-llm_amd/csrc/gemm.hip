@@ -562,7 +562,9 @@ __device__ unsigned long long g_pp_tl[256 * 8 * 8];     // [workgroup][wave][seg
 #define V3D_TL_ACC(i, a, b)
 #endif
 
-template <typename T, int EPI, int MT>
+// SKT: the split-K tail's exchange code is compiled in (its register needs push accumulators of the 256-row tile to scratch in
+// EVERY tile, cut or not: launches without a split take the instantiation without it, which has no spills at all)
+template <typename T, int EPI, int MT, bool SKT>
 __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using M16 = Mfma16<T>;
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   // A chunk c > 0 ends by writing its accumulators to the workspace and raising its flag - it never waits - and chunk 0 adds the
   // images of the workgroups that ran the tile's other chunks and runs the epilogue.
   const int nt = p.K / BK;       // >= 2 (the launcher sends shorter K to the v3 kernel)
-  const bool sk = p.sk_dp >= 0;
+  const bool sk = SKT && p.sk_dp >= 0;
   const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, wx = (int)gridDim.x >> 3;
   const int gpt = nt >> 1;                                                   // granules per tile
   const int sk_g = xcd * wx + idx, sk_T = n_tiles - p.sk_dp * (int)gridDim.x;
@@ -829,6 +831,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
     // written through (sc0 sc1), s_waitcnt vmcnt(0) = acknowledged, barrier, flag; the reader polls the flag with a device-scope
     // load and reads the image with loads that bypass the caches a stale copy could sit in.
     V3D_TL(tl4);
+    if constexpr (SKT) {
     if (seg_tail) {
       // a chunk c > 0: hand the accumulators to the tile's chunk-0 workgroup (f32, lane-major: the reader has the same layout)
       const float* img = p.sk_ws + (size_t)blockIdx.x * (32 * 512 * 4);
@@ -882,6 +885,8 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
         }
       }
     }
+
+    }   // SKT
 
     // Epilogue (r02b): each wave turns its own 128|96 x 64 part of the C tile around in a PRIVATE 6 KiB of LDS, 32 rows at a time -
     // no workgroup barrier, and whole 128-byte row segments (16 bytes per lane, 8 rows per instruction) go out.  The two earlier forms
@@ -1206,8 +1211,8 @@ static bool sk_pays(int n_tiles, int grid, int nt) {           // the time model
   int sp = 1;
   const int dp = sk_plan(n_tiles, grid, nt, &sp);
   if (dp < 0) return false;
-  const double ks = (double)nt, round = 22.0 + 1.25 * ks;
-  return dp * round + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
+  const double ks = (double)nt, round_sk = 22.0 + 1.25 * ks, round = 8.0 + 1.263 * ks;
+  return dp * round_sk + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
 }
 struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int slots = 0; };
 // One workspace per stream (launches on one stream are ordered; two streams must not share accumulator images).  Allocated on
@@ -1245,7 +1250,7 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
     int split = 1;
     const int slots = pp_slots() & ~7;
     const int mode = gemm_sk_mode(), dp = sk_plan(n_tiles, slots, p.K / BK, &split);
-    if (mode != 0 && dp >= 0 && (mode == 2 || (sk_allow < 0 ? sk_pays(n_tiles, slots, p.K / BK) : sk_allow != 0))) {
+    if (MT == 8 && mode != 0 && dp >= 0 && (mode == 2 || (sk_allow < 0 ? sk_pays(n_tiles, slots, p.K / BK) : sk_allow != 0))) {
       unsigned epoch = 0;
       if (SkWorkspace* w = sk_workspace(st, slots, &epoch)) {
         p.sk_dp = dp; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = epoch;
@@ -1254,9 +1259,9 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
       }
     }
   }
-#define V3D_GEMM4_CASE(E)                                                                                 \
-  case E: {                                                                                               \
-    auto k = gemm256pp_kernel<T, E, MT>;                                                                    \
+#define V3D_GEMM4_LAUNCH(E, SKT)                                                                          \
+  {                                                                                                       \
+    auto k = gemm256pp_kernel<T, E, MT, SKT>;                                                             \
     static bool attr_done = false;                                                                        \
     if (!attr_done) {                                                                                     \
       hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES); \
@@ -1264,6 +1269,11 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
       attr_done = true;                                                                                   \
     }                                                                                                     \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), PP_LDS_BYTES, st, p);                                    \
+  }
+#define V3D_GEMM4_CASE(E)                                                                                 \
+  case E: {                                                                                               \
+    if constexpr (MT == 8) { if (p.sk_dp >= 0) V3D_GEMM4_LAUNCH(E, true) else V3D_GEMM4_LAUNCH(E, false) } \
+    else V3D_GEMM4_LAUNCH(E, false)                                                                        \
   } break;
   switch (epi) {
     V3D_GEMM4_CASE(EPI_NONE)
@@ -1277,16 +1287,18 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
     default: set_error("v3d_gemm: unknown epilogue %d", epi); return V3D_E_INVALID;
   }
 #undef V3D_GEMM4_CASE
+#undef V3D_GEMM4_LAUNCH
   return check_launch("v3d_gemm (256-wide, ping-pong)");
 }
 
 // Tile choice (speed only), from a time model fitted on MI355X to the path's shapes (tools/time_gemm_ab.py; microseconds):
 //   a kernel takes  rounds x (fixed + K-steps x per-step),  rounds = ceil(tiles / workgroup slots of the chip)
-//   256 x 256 ping-pong (256 slots): fixed 22 (prologue DMA latency, epilogue, dispatch), 1.25 per K-step
-//   192 x 256 ping-pong (256 slots): fixed 8, 1.24 per K-step   (3/4 of the tile at the same step time: it only wins where
+//   256 x 256 ping-pong (256 slots): fixed 8 (epilogue, rendezvous, first DMA latency; 13 with SwiGLU), 1.26 per K-step
+//   192 x 256 ping-pong (256 slots): fixed 4.5, 1.22 per K-step   (3/4 of the tile at the same step time: it only wins where
 //                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
 //   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
-//   256 x 256 with the split-K tail: whole rounds as above + one round of (22 + step x K-steps / split + 40 for the exchange),
+//   256 x 256 with the split-K tail: its whole rounds cost 22 + 1.25 per K-step (the instantiation with the exchange code spills
+//                                    accumulators) + one round of (22 + step x K-steps / split + 40 for the exchange),
 //                                    step 1.3 when the launch is only the tail, 1.7 behind whole rounds (measured: 6794 x 3584 x 18944
 //                                    780 -> 685 us, 960 x 3584 x 18944 330 -> 152 us; no gain at K = 3584)
 struct GemmPlan { int kernel; int sk; int dp; int split; int tiles; };    // kernel: 1 = 128 x 128, 2 = 256 x 256, 3 = 192 x 256 (2, 3: ping-pong or v3)
@@ -1296,8 +1308,8 @@ static GemmPlan gemm_plan(int M, int N, int K, int slots, int var, bool pp_on, i
   const double ks = (double)(K / BK);
   const int tiles256 = ((M + 255) / 256) * (N / B3N), tiles192 = ((M + 191) / 192) * (N / B3N);
   const bool pp = pp_on && K >= 2 * BK;
-  double t256 = (double)((tiles256 + 255) / 256) * (pp ? 22.0 + 1.25 * ks : 9.0 + 1.36 * ks);
-  const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 8.0 + 1.24 * ks : 2.0 + 1.32 * ks);
+  double t256 = (double)((tiles256 + 255) / 256) * (pp ? 8.0 + 1.263 * ks : 9.0 + 1.36 * ks);
+  const double t192 = (double)((tiles192 + 255) / 256) * (pp ? 4.5 + 1.2225 * ks : 2.0 + 1.32 * ks);
   const int r1 = (g.tiles + 511 - 25) / 512;                     // (a last round under 5 % full is not felt)
   const double t1 = (double)(r1 > 0 ? r1 : 1) * (1.0 + 0.98 * ks);
   int sk_use = 0, sp = 1, dp = -1;
@@ -1306,7 +1318,7 @@ static GemmPlan gemm_plan(int M, int N, int K, int slots, int var, bool pp_on, i
     if (dp >= 0) {
       const double tsk = dp * (22.0 + 1.25 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
       const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
-      if (tsk < 0.95 * best || sk_mode == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 5 % margin: the model is coarse)
+      if (tsk < 0.98 * best || sk_mode == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 2 % margin: the model is coarse)
     }
   }
   if (var == 4) { g.kernel = 3; g.tiles = tiles192; g.sk = -1; return g; }       // forced tiles decide the split themselves (sk = -1)
