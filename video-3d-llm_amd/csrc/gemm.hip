@@ -62,6 +62,7 @@ struct GemmArgs {
   // sk_split K-chunks run by neighbouring workgroups of the XCD AT THE SAME TIME (all chunk-c workgroups walk the same k range in
   // lock step, so operand panels are still shared in L2 - a stream-K walk with staggered k offsets ran at half speed: HBM-bound);
   // the chunk-0 workgroup adds the others' accumulator images and runs the epilogue
+  int tile_base, tile_count;   // ping-pong kernel: the launch covers the logical tiles [tile_base, tile_base + tile_count) (count 0 = all)
   int sk_dp;          // -1: off
   int sk_split;       // 2 .. 4
   float* sk_ws;       // one accumulator image (32 x 512 x 16 bytes) per workgroup
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int n_tiles = p.tiles_m * p.tiles_n;
+  const int n_tiles = p.tile_count > 0 ? p.tile_count : p.tiles_m * p.tiles_n;      // tiles of THIS launch
 
   // PERSISTENT: the grid is one workgroup per CU (or per tile when there are fewer); workgroup b walks the logical tiles
   // b, b + grid, b + 2 grid, ... (the XCD-aware grouped order of tile_of_block: the stride is a multiple of 8, so a workgroup
@@ -615,12 +616,12 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   int k_begin = 0, k_end = nt;
   // next segment -> (L, k range); false when the list is exhausted
   auto next_segment = [&](int& L) -> bool {
-    if (!sk) { if (bid >= n_tiles) return false; L = xcd_first_logical(bid & 7, n_tiles) + (bid >> 3); bid += (int)gridDim.x; k_begin = 0; k_end = nt; return true; }
-    if (dp_round < p.sk_dp) { L = (xcd * p.sk_dp + dp_round) * wx + idx; ++dp_round; k_begin = 0; k_end = nt; return true; }
+    if (!sk) { if (bid >= n_tiles) return false; L = p.tile_base + xcd_first_logical(bid & 7, n_tiles) + (bid >> 3); bid += (int)gridDim.x; k_begin = 0; k_end = nt; return true; }
+    if (dp_round < p.sk_dp) { L = p.tile_base + (xcd * p.sk_dp + dp_round) * wx + idx; ++dp_round; k_begin = 0; k_end = nt; return true; }
     if (!sk_item) return false;
     sk_item = false;
     const int c = sk_g / sk_T;
-    L = p.sk_dp * (int)gridDim.x + (sk_g - c * sk_T);
+    L = p.tile_base + p.sk_dp * (int)gridDim.x + (sk_g - c * sk_T);
     k_begin = 2 * (c * gpt / p.sk_split); k_end = 2 * ((c + 1) * gpt / p.sk_split);
     return true;
   };
@@ -1211,8 +1212,8 @@ static bool sk_pays(int n_tiles, int grid, int nt) {           // the time model
   int sp = 1;
   const int dp = sk_plan(n_tiles, grid, nt, &sp);
   if (dp < 0) return false;
-  const double ks = (double)nt, round_sk = 22.0 + 1.25 * ks, round = 8.0 + 1.263 * ks;
-  return dp * round_sk + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
+  const double ks = (double)nt, round = 8.0 + 1.263 * ks;
+  return dp * round + (dp > 0 ? 5.0 : 0.0) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0 < (double)((n_tiles + grid - 1) / grid) * round;
 }
 struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned epoch = 0; int slots = 0; };
 // One workspace per stream (launches on one stream are ordered; two streams must not share accumulator images).  Allocated on
@@ -1241,7 +1242,9 @@ template <typename T, int MT>
 static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = -1) {   // sk_allow: -1 decide here (forced tile), 0 / 1 = the caller's model decided
   p.tiles_m = (p.M + MT * 32 - 1) / (MT * 32);
   p.tiles_n = p.N / B3N;
-  const int n_tiles = p.tiles_m * p.tiles_n;
+  const bool part = sk_allow == -2;                                 // a launch over the tile range the caller set (no split of its own)
+  if (!part) { p.tile_base = 0; p.tile_count = 0; }
+  const int n_tiles = part ? p.tile_count : p.tiles_m * p.tiles_n;
   int grid = n_tiles < pp_slots() ? n_tiles : pp_slots();           // persistent: one workgroup per CU walks its tiles
   { const char* e = getenv("V3D_GEMM_SKEW"); p.skew = e ? atoi(e) : 0; }
   if (n_tiles <= grid) p.skew = 0;                                  // a single round: nothing to spread
@@ -1250,10 +1253,19 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
     int split = 1;
     const int slots = pp_slots() & ~7;
     const int mode = gemm_sk_mode(), dp = sk_plan(n_tiles, slots, p.K / BK, &split);
-    if (MT == 8 && mode != 0 && dp >= 0 && (mode == 2 || (sk_allow < 0 ? sk_pays(n_tiles, slots, p.K / BK) : sk_allow != 0))) {
+    if (!part && MT == 8 && mode != 0 && dp >= 0 && (mode == 2 || (sk_allow < 0 ? sk_pays(n_tiles, slots, p.K / BK) : sk_allow != 0))) {
       unsigned epoch = 0;
       if (SkWorkspace* w = sk_workspace(st, slots, &epoch)) {
-        p.sk_dp = dp; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = epoch;
+        // The whole-tile rounds go out as a launch of their own with the instantiation that has no exchange code (no spills), the
+        // tail as a second launch: its chunks then all start together and stay in lock step (tail K-steps 1.3 us instead of 1.7).
+        if (dp > 0) {
+          GemmArgs pw = p;
+          pw.tile_base = 0; pw.tile_count = dp * slots;
+          const int rc = launch_gemm256pp<T, MT>(pw, epi, st, -2);
+          if (rc != V3D_OK) return rc;
+          p.tile_base = dp * slots; p.tile_count = n_tiles - dp * slots;
+        }
+        p.sk_dp = 0; p.sk_split = split; p.sk_ws = w->ws; p.sk_flags = w->flags; p.sk_epoch = epoch;
         p.skew = 0;
         grid = slots;                                               // (also when n_tiles < slots: the chunks fill the chip)
       }
@@ -1297,8 +1309,8 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
 //   192 x 256 ping-pong (256 slots): fixed 4.5, 1.22 per K-step   (3/4 of the tile at the same step time: it only wins where
 //                                    256-row tiles quantise badly against the 256 CUs, e.g. M = 6794, N = 3584, K = 3584)
 //   128 x 128           (512 slots): fixed 1, 0.98 per K-step     (many small tiles: small M, or N % 256 != 0)
-//   256 x 256 with the split-K tail: its whole rounds cost 22 + 1.25 per K-step (the instantiation with the exchange code spills
-//                                    accumulators) + one round of (22 + step x K-steps / split + 40 for the exchange),
+//   256 x 256 with the split-K tail: whole rounds as above (a launch of their own) + 5 for the second launch + one round of
+//                                    (22 + step x K-steps / split + 40 for the exchange),
 //                                    step 1.3 when the launch is only the tail, 1.7 behind whole rounds (measured: 6794 x 3584 x 18944
 //                                    780 -> 685 us, 960 x 3584 x 18944 330 -> 152 us; no gain at K = 3584)
 struct GemmPlan { int kernel; int sk; int dp; int split; int tiles; };    // kernel: 1 = 128 x 128, 2 = 256 x 256, 3 = 192 x 256 (2, 3: ping-pong or v3)
@@ -1316,7 +1328,7 @@ static GemmPlan gemm_plan(int M, int N, int K, int slots, int var, bool pp_on, i
   if (pp && sk_mode != 0) {
     dp = sk_plan(tiles256, slots & ~7, K / BK, &sp);
     if (dp >= 0) {
-      const double tsk = dp * (22.0 + 1.25 * ks) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
+      const double tsk = dp * (8.0 + 1.263 * ks) + (dp > 0 ? 5.0 : 0.0) + 22.0 + (dp > 0 ? 1.7 : 1.3) * ks / sp + 40.0;
       const double best = t256 < t192 ? (t256 < t1 ? t256 : t1) : (t192 < t1 ? t192 : t1);
       if (tsk < 0.98 * best || sk_mode == 2) { t256 = tsk < t256 ? tsk : t256; sk_use = 1; }    // (a 2 % margin: the model is coarse)
     }
@@ -1410,7 +1422,7 @@ extern "C" int v3d_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, 
   GemmArgs p;
   p.A = A; p.W = W; p.bias = need_bias ? bias : nullptr; p.res = need_res ? res : nullptr; p.out = out;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldr = ldr; p.ldo = ldo; p.res_mod = res_mod;
-  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = N / BN; p.skew = 0; p.dma_late = 0;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = N / BN; p.skew = 0; p.dma_late = 0; p.tile_base = 0; p.tile_count = 0;
   hipStream_t st = (hipStream_t)stream;
   if (M <= 8) return dtype == V3D_BF16 ? launch_gemv<bf16_t>(p, epilogue, st) : launch_gemv<f16_t>(p, epilogue, st);
   return dtype == V3D_BF16 ? launch_gemm<bf16_t>(p, epilogue, st) : launch_gemm<f16_t>(p, epilogue, st);
