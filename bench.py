@@ -375,11 +375,12 @@ def main():
         gemm_peak = 5000.0 if a.fp8 else 2500.0
         attn_us = stamps["attn"].mean_us()
         attn_flops = 2.0 * S * S * 128 * 28                                   # causal: half of 4*S^2*d*H
-        traffic, traffic_note, attn_busy = None, None, None
+        traffic, traffic_note, attn_busy, gemm_busy = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             pm = json.load(open(pmc))
             attn_busy = pm.get("attention_mfma_busy_frac")       # PMC: MFMA-busy share of SIMD cycles at the actual clock
+            gemm_busy = pm.get("gemm_gate_up_mfma_busy_frac")
             sha = kernel_source_sha("visual_tokens.hip")
             if pm.get("visual_tokens_source_sha") == sha:
                 traffic = pm.get("visual_tokens_hbm_bytes_per_launch")
@@ -403,7 +404,7 @@ def main():
                                    ("gemm_fp8_kernel" if a.fp8 else "gemm256pp_kernel", S), "bound": "mfma",
                          "achieved": gemm_flops / gemm_us / 1e6, "peak": gemm_peak, "unit": "TFLOP/s",
                          "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": None, "us_per_launch": gemm_us,
-                         "algorithmic_flops": gemm_flops},
+                         "algorithmic_flops": gemm_flops, "mfma_busy_frac_pmc": None if a.fp8 else gemm_busy},
             "roofline_north_star": {"kernel": "visual_tokens_kernel (bilinear pool + 3D-PE add + newline, K5-K8)", "bound": "hbm",
                                     "achieved": pe_bytes / pe_us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": pe_bytes / pe_us / 1e3 / 8000.0,
                                     "traffic": traffic, "traffic_note": traffic_note, "us_per_launch": pe_us, "algorithmic_bytes": pe_bytes},
