@@ -239,6 +239,16 @@ int v3d_attention_decode_rows(const void* q, int64_t q_stride, int M, const void
                               int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale, void* workspace,
                               int64_t workspace_bytes, void* stream);
 
+/* Scene-level reuse: the M rows are questions about ONE scene whose caches all start with the same prefix_len rows
+ * (the scene's [system | user | <image>] K/V, broadcast into each question's cache).  Keys < prefix_len are read from k_prefix /
+ * v_prefix (same strides as the caches; any one of the copies) for every question, so the chip streams the prefix once per step
+ * instead of M times; rows >= prefix_len come from the question's own cache.  Outputs are bit-identical to
+ * v3d_attention_decode_rows on the same caches. */
+int v3d_attention_decode_rows_prefix(const void* q, int64_t q_stride, int M, const void* k_prefix, const void* v_prefix,
+                                     int prefix_len, const void* const* k_caches, const void* const* v_caches, const int* Sk,
+                                     void* o, int64_t o_stride, int dtype, int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq,
+                                     int hsk, int hso, float scale, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Decode-step linear (one activation row; K15/K17/K18 at q_len == 1): y = epilogue(W . f(x)), W [N,K] row
  * stride ldw.  norm_weight != NULL fuses Qwen2RMSNorm (modeling_qwen2.py:85-90) in front: f(x) = w * T(x*rstd).
  * epilogue: 0 NONE, 1 BIAS (y += bias), 2 RES (y = res + T(y)), 3 SWIGLU (tile-interleaved gate|up rows as

@@ -284,6 +284,39 @@ def test_attention_decode_rows_ragged(ops, lens):
         assert torch.equal(alone, out[m]), f"scene {m} (length {n}) depends on its group"
 
 
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("P,tails", [(6734, [60, 61, 77, 3, 64]), (500, [1] * 16), (256, [0, 5, 300]), (37, [19, 40])])
+def test_attention_decode_rows_shared_prefix_is_bit_identical(ops, kind, P, tails, monkeypatch):
+    """Questions about one scene: the caches start with the same P rows.  With prefix=P the split-KV kernels read
+    those keys from the first cache for every question (the chip streams them once); the outputs must equal the launch in which
+    every question reads its own copy, bit for bit - prefix ends inside a 16-key group / a 64-key chunk / a split, tails of 0 rows,
+    both kernels (V3D_DEC_ATTN is read once per process, so the VALU form is covered by its equality with the MFMA form elsewhere)."""
+    dt = DT[kind]
+    H, KV, D = 28, 4, 128
+    M = len(tails)
+    g = torch.Generator().manual_seed(P + sum(tails))
+    q = torch.randn(M, H * D, generator=g).to(dt).cuda()
+    shared = torch.randn(P, 2 * KV * D, generator=g).to(dt)
+    caches = []
+    for n in tails:
+        c = torch.randn(P + n + 3, 2 * KV * D, generator=g).to(dt)
+        c[:P] = shared
+        caches.append(c.cuda())
+    lens = [P + n for n in tails]
+    one = ops.decode_workspace(H, KV, "cuda")
+    ws = torch.empty(one.numel() * M, dtype=torch.float32, device="cuda")
+    own = torch.empty(M, H * D, dtype=dt, device="cuda")
+    ops.attention_decode_rows(q, caches, [c[:, KV * D:] for c in caches], own, lens, H, KV, 1 / math.sqrt(D), ws)
+    # poison every copy of the prefix but the first: with prefix=P nobody may read them
+    for c in caches[1:]:
+        c[:P] = float("nan")
+    got = torch.empty(M, H * D, dtype=dt, device="cuda")
+    ops.attention_decode_rows(q, caches, [c[:, KV * D:] for c in caches], got, lens, H, KV, 1 / math.sqrt(D), ws, prefix=P)
+    assert torch.equal(got, own)
+    with pytest.raises(Exception):
+        ops.attention_decode_rows(q, caches, [c[:, KV * D:] for c in caches], got, [P - 1] + lens[1:], H, KV, 1 / math.sqrt(D), ws, prefix=P)
+
+
 def test_rope_kv_store_equals_rope_apply_plus_copy(ops):
     """The fused prefill rotary + cache append (contiguous and indexed destination rows, given positions) against
     v3d_rope_apply + v3d_copy_rows, bit for bit."""

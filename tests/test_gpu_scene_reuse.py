@@ -115,6 +115,16 @@ def test_answer_group_equals_answering_alone(dtype):
     same = sum(int(torch.equal(a, b)) for a, b in zip(alone, together))
     assert same >= len(questions) - 2, (alone, together)                  # near-ties may flip a token of a question or two
     assert all(t.shape == (steps,) for t in together)
+    # the decode attention reads the shared prefix rows from ONE copy for every question (default): same tokens as with every
+    # question reading its own copy of them
+    import os
+    os.environ["V3D_SHARED_PREFIX"] = "0"
+    try:
+        own = eng.answer_group(questions, max_new_tokens=steps)
+    finally:
+        del os.environ["V3D_SHARED_PREFIX"]
+    for a, b in zip(own, together):
+        assert torch.equal(a, b)
     eos = int(together[2][1])
     cut = eng.answer_group(questions, max_new_tokens=steps, eos_token_id=eos)
     for a, b in zip(cut, together):

@@ -1205,7 +1205,11 @@ struct DecRows {
   int64_t q_stride, o_stride;       // elements between the scenes' query / output rows
   int64_t ws_stride;                // floats between the scenes' workspace slices
   int kps, cap;                     // keys per split / most splits per scene: a scene's OWN split count min(cap, ceil(n_keys / kps))
-};                                  // decides its key partition, so its output does not depend on the other scenes of the launch
+                                    // decides its key partition, so its output does not depend on the other scenes of the launch
+  const void* kp;                   // shared prefix (scene-level reuse): keys < prefix are read HERE for every scene of the launch -
+  const void* vp;                   // the scenes' own copies of those rows hold the same bytes, so outputs do not change, but the
+  int prefix;                       // chip reads the prefix once (L2 / Infinity Cache hits for the other scenes) instead of M times
+};
 
 template <typename T, int G>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecRows rw, int n_split, float* __restrict__ ws) {
@@ -1229,6 +1233,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecR
   k_end = k_end < n_keys ? k_end : n_keys;
   const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * p.hsk;
   const uint16_t* V = (const uint16_t*)p.v + (int64_t)hk * p.hsk;
+  const uint16_t* Kp = rw.prefix > 0 ? (const uint16_t*)rw.kp + (int64_t)hk * p.hsk : K;
+  const uint16_t* Vp = rw.prefix > 0 ? (const uint16_t*)rw.vp + (int64_t)hk * p.hsk : V;
   float qv[G][8];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -1252,8 +1258,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecR
       const int key = kb + slot + 16 * it;
       ok[it] = key < k_end;
       const int kc = ok[it] ? key : k_begin;
-      k4[it] = *reinterpret_cast<const uint4*>(K + (int64_t)kc * p.ldk + cl * 8);
-      v4[it] = *reinterpret_cast<const uint4*>(V + (int64_t)kc * p.ldv + cl * 8);
+      k4[it] = *reinterpret_cast<const uint4*>((kc < rw.prefix ? Kp : K) + (int64_t)kc * p.ldk + cl * 8);
+      v4[it] = *reinterpret_cast<const uint4*>((kc < rw.prefix ? Vp : V) + (int64_t)kc * p.ldv + cl * 8);
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1346,6 +1352,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_mm_kernel(AttnArgs p, D
   k_end = k_end < n_keys ? k_end : n_keys;
   const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * p.hsk;
   const uint16_t* V = (const uint16_t*)p.v + (int64_t)hk * p.hsk;
+  const uint16_t* Kp = rw.prefix > 0 ? (const uint16_t*)rw.kp + (int64_t)hk * p.hsk : K;
+  const uint16_t* Vp = rw.prefix > 0 ? (const uint16_t*)rw.vp + (int64_t)hk * p.hsk : V;
   Frag16 qf[4];                                    // A operand: head hr (zero rows above G), dims 32t + 8 g4 ..
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -1367,12 +1375,12 @@ __global__ __launch_bounds__(256) void attn_decode_split_mm_kernel(AttnArgs p, D
       const int key = kw0 + hr;
       const int kc = key < k_end ? key : k_begin;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) kf[t].u = *reinterpret_cast<const uint4*>(K + (int64_t)kc * p.ldk + 32 * t + 8 * g4);
+      for (int t = 0; t < 4; ++t) kf[t].u = *reinterpret_cast<const uint4*>((kc < rw.prefix ? Kp : K) + (int64_t)kc * p.ldk + 32 * t + 8 * g4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kv = kw0 + 4 * r + g4;
         const int vc = kv < k_end ? kv : k_begin;
-        v4[r] = *reinterpret_cast<const uint4*>(V + (int64_t)vc * p.ldv + hr * 8);
+        v4[r] = *reinterpret_cast<const uint4*>((vc < rw.prefix ? Vp : V) + (int64_t)vc * p.ldv + hr * 8);
       }
     }
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -1597,7 +1605,8 @@ extern "C" int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits) 
 static int attention_decode_rows(const void* q, int64_t q_stride, int M, const void* const* k_caches, const void* const* v_caches,
                                  const int* Sk, void* o, int64_t o_stride, int dtype, int Hq, int Hkv, int64_t ldk, int64_t ldv,
                                  int hsq, int hsk, int hso, float scale, void* workspace, int64_t workspace_bytes, void* stream,
-                                 const char* who) {
+                                 const char* who, const void* k_prefix = nullptr, const void* v_prefix = nullptr, int prefix = 0) {
+  V3D_REQUIRE(prefix >= 0 && (prefix == 0 || (k_prefix && v_prefix && aligned16(k_prefix) && aligned16(v_prefix))), "%s: bad shared prefix", who);
   V3D_REQUIRE(q && k_caches && v_caches && Sk && o && workspace, "%s: null pointer", who);
   V3D_REQUIRE(M >= 1 && M <= DEC_MAXROWS, "%s: 1 to %d scenes (got %d)", who, DEC_MAXROWS, M);
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
@@ -1626,6 +1635,8 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
   V3D_REQUIRE(workspace_bytes >= ws_one * M, "%s: workspace too small for %d scenes x %d splits", who, M, n_split);
   rw.q_stride = q_stride; rw.o_stride = o_stride; rw.ws_stride = ws_one / (int64_t)sizeof(float);
   rw.kps = kps; rw.cap = cap;
+  rw.kp = k_prefix; rw.vp = v_prefix; rw.prefix = prefix;
+  for (int m = 0; m < M && prefix > 0; ++m) V3D_REQUIRE(Sk[m] >= prefix, "%s: scene %d is shorter than the shared prefix", who, m);
   AttnArgs p{};
   p.q = q; p.o = o;
   p.ldk = ldk; p.ldv = ldv; p.hsq = hsq; p.hsk = hsk; p.hso = hso;
@@ -1659,6 +1670,14 @@ extern "C" int v3d_attention_decode(const void* q, const void* k_cache, const vo
                                     void* workspace, int64_t workspace_bytes, void* stream) {
   return attention_decode_rows(q, 0, 1, &k_cache, &v_cache, &Sk, o, 0, dtype, Hq, Hkv, ldk, ldv, hsq, hsk, hso, scale, workspace,
                                workspace_bytes, stream, "v3d_attention_decode");
+}
+
+extern "C" int v3d_attention_decode_rows_prefix(const void* q, int64_t q_stride, int M, const void* k_prefix, const void* v_prefix,
+                                                int prefix_len, const void* const* k_caches, const void* const* v_caches, const int* Sk,
+                                                void* o, int64_t o_stride, int dtype, int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq,
+                                                int hsk, int hso, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+  return attention_decode_rows(q, q_stride, M, k_caches, v_caches, Sk, o, o_stride, dtype, Hq, Hkv, ldk, ldv, hsq, hsk, hso, scale,
+                               workspace, workspace_bytes, stream, "v3d_attention_decode_rows_prefix", k_prefix, v_prefix, prefix_len);
 }
 
 extern "C" int v3d_attention_decode_rows(const void* q, int64_t q_stride, int M, const void* const* k_caches,

@@ -70,6 +70,8 @@ SIGNATURES = {
     "v3d_rope_kv_append_rows": (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p]),
     "v3d_attention_decode_rows": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_l, c_l, c_i, c_i, c_i, c_f,
                                         c_p, c_l, c_p]),
+    "v3d_attention_decode_rows_prefix": (c_i, [c_p, c_l, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_l, c_l, c_i, c_i,
+                                               c_i, c_f, c_p, c_l, c_p]),
     "v3d_object_patch_mask": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p]),
     "v3d_masked_mean": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "v3d_ground_scores": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p]),

@@ -12,6 +12,7 @@ State-dict keys are the reference's (llava_qwen.py / siglip_encoder.py / builder
   model.norm.weight, lm_head.weight
 """
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -656,7 +657,8 @@ class Engine:
         ctxs = st.ctxs[:G]
         for c, n in zip(ctxs, lens):
             c.kv_len = P + n
-        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True)
+        share = 0 if os.environ.get("V3D_SHARED_PREFIX", "1") == "0" else P          # (0: every question reads its own copy - A/B and tests)
+        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True, shared_prefix=share)
         self.use(scene)
         eos = () if eos_token_id is None else ((eos_token_id,) if isinstance(eos_token_id, int) else tuple(eos_token_id))
         out = []
@@ -721,9 +723,10 @@ class Engine:
         g.amax_ws = torch.empty(256 * n_scenes, dtype=torch.float32, device=self.device)
         return g
 
-    def decode_forward_rows(self, g, ctxs, positions):
+    def decode_forward_rows(self, g, ctxs, positions, shared_prefix=0):
         """One new token for each of the M scenes (rows of g.x, in place) at its own position: per layer 4 weight-streaming
-        linears over all rows + one rotary/append and one split-KV attention launch pair covering all scenes."""
+        linears over all rows + one rotary/append and one split-KV attention launch pair covering all scenes.
+        shared_prefix > 0 (answer_group): the caches start with the same rows; the attention reads them once for all rows."""
         l = self.cfg.llm
         M = len(ctxs)
         hd, nh, nkv = self.hd, l.heads, l.kv_heads
@@ -742,7 +745,7 @@ class Engine:
             ops.rmsnorm(x, L["ln1"], l.eps, out=h)
             lin(h, L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
             ops.rope_kv_append_rows(qkv, nh, nkv, hd, self.rope, positions, [c[p] for c, p in zip(caches, positions)])
-            ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws)
+            ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws, prefix=shared_prefix)
             lin(att, L, "wo", x, res=x, epilogue=ops.DEC_RES)
             ops.rmsnorm(x, L["ln2"], l.eps, out=h)
             lin(h, L, "wgu", act, epilogue=ops.DEC_SWIGLU)
@@ -756,7 +759,7 @@ class Engine:
             ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
         return g.logits[:M, : l.vocab]
 
-    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False):
+    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False, shared_prefix=0):
         """Greedy decoding of M prefilled scenes together (their prefill logits are in ctx.logits[0], or already in g.logits
         with logits_ready); returns the token ids [M, max_new_tokens] (device).  No EOS stop: callers trim per scene."""
         l = self.cfg.llm
@@ -774,7 +777,7 @@ class Engine:
             if step + 1 == max_new_tokens:
                 break
             ops.embed_gather(self.embed, toks[step], out=g.x[:M])
-            logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens])
+            logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens], shared_prefix=shared_prefix)
         return toks.t()
 
     def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None, stopping=None):

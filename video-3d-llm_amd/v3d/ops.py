@@ -516,9 +516,19 @@ def rope_kv_append_rows(qkv, n_q, n_kv, hd, table, positions, cache_rows):
           "v3d_rope_kv_append_rows")
 
 
-def attention_decode_rows(q, k_caches, v_caches, out, sk, n_heads, n_kv_heads, scale, workspace):
-    """q / out [M, Hq*128]; k_caches / v_caches: per-scene cache views [>=Sk, ...] sharing strides; sk: lengths."""
+def attention_decode_rows(q, k_caches, v_caches, out, sk, n_heads, n_kv_heads, scale, workspace, prefix=0):
+    """q / out [M, Hq*128]; k_caches / v_caches: per-scene cache views [>=Sk, ...] sharing strides; sk: lengths.
+    prefix > 0: the caches all start with the same `prefix` rows (questions about one scene): those keys are read from the
+    first cache for every row, the rest from each row's own cache (bit-identical outputs, the prefix is streamed once)."""
     k0 = k_caches[0]
+    if prefix > 0:
+        if min(sk) < prefix:
+            raise V3DError("attention_decode_rows: a scene is shorter than the shared prefix")
+        check(lib().v3d_attention_decode_rows_prefix(_p(q), q.stride(0), q.shape[0], _p(k0), _p(v_caches[0]), int(prefix), _host_ptrs(k_caches),
+                                                     _host_ptrs(v_caches), _host_ints(sk), _p(out), out.stride(0), _code(q), n_heads, n_kv_heads,
+                                                     k0.stride(0), v_caches[0].stride(0), 128, 128, 128, float(scale), _p(workspace),
+                                                     workspace.numel() * workspace.element_size(), _stream()), "v3d_attention_decode_rows_prefix")
+        return out
     check(lib().v3d_attention_decode_rows(_p(q), q.stride(0), q.shape[0], _host_ptrs(k_caches), _host_ptrs(v_caches), _host_ints(sk),
                                           _p(out), out.stride(0), _code(q), n_heads, n_kv_heads, k0.stride(0), v_caches[0].stride(0),
                                           128, 128, 128, float(scale), _p(workspace), workspace.numel() * workspace.element_size(),
