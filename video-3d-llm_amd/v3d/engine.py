@@ -200,7 +200,9 @@ class Engine:
                 ln1_w=sd[p + "layer_norm1.weight"].contiguous(), ln1_b=sd[p + "layer_norm1.bias"].contiguous(),
                 ln2_w=sd[p + "layer_norm2.weight"].contiguous(), ln2_b=sd[p + "layer_norm2.bias"].contiguous(),
                 wqkv=wqkv, bqkv=bqkv,
-                wo=_pad2(sd[p + "self_attn.out_proj.weight"], Hp, Hk), bo=_pad1(sd[p + "self_attn.out_proj.bias"], Hp),
+                # out_proj writes the residual stream at ITS width (zero pad rows -> zero pad columns): N = 1280 runs on the 256-wide
+                # tile, N = 1152 only on the 128 x 128 one (91 -> ~70 us per layer)
+                wo=_pad2(sd[p + "self_attn.out_proj.weight"], self.v_Hx, Hk), bo=_pad1(sd[p + "self_attn.out_proj.bias"], self.v_Hx),
                 w1=_pad2(sd[p + "mlp.fc1.weight"], Ip, Hk), b1=_pad1(sd[p + "mlp.fc1.bias"], Ip),
                 w2=_pad2(sd[p + "mlp.fc2.weight"], self.v_Hx, Ip), b2=_pad1(sd[p + "mlp.fc2.bias"], self.v_Hx)))
         self.p_w0 = _pad2(sd["model.mm_projector.0.weight"], self.cfg.llm.hidden, Hk)
