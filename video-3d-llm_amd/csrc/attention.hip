@@ -106,11 +106,14 @@ template <int N> struct IntC { static constexpr int value = N; };
 // tile costs one max3 chain, 32 v_exp, 32 adds and 16 packs per lane and no cross-lane traffic at all.
 constexpr float AT_RAISE = 8.0f;
 
-template <typename T, int D, bool CAUSAL>
+// KSV: k-steps of QK^T that can be non-zero (head dims >= d_out are zeroed in Q): SigLIP's 72-wide heads on the 96-wide tile
+// need 5 of the 6 (the sixth multiplies zeros)
+template <typename T, int D, bool CAUSAL, int KSV = D / 16>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // 1 KiB: fragment addresses are formed by XOR
   using M = Mfma32<T>;
   constexpr int KS = D / 16;       // k-steps of QK^T
+  static_assert(KSV == KS || (KS == 6 && KSV == 5), "only the 96-wide tile has a short form");
   constexpr int DT = D / 32;       // 32-wide d tiles of O^T
   constexpr int CH = D / 8;        // 16-byte chunks per K/V row actually present
 
@@ -224,7 +227,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       V3D_KR(kc[0], 4, KB); V3D_KR(kc[1], 5, KB); V3D_KR(kc[2], 6, KB); V3D_KR(kc[3], 7, KB);
     } else {
       V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
-      V3D_KR(kc[0], 4, KB); V3D_KR(kc[1], 5, KB); V3D_KR(kc[2], 0, KB + 8192); V3D_KR(kc[3], 1, KB + 8192);
+      V3D_KR(kc[0], 4, KB);
+      if constexpr (KSV == 6) V3D_KR(kc[1], 5, KB);
+      V3D_KR(kc[2], 0, KB + 8192); V3D_KR(kc[3], 1, KB + 8192);
     }
   };
   auto qk_run = [&](auto kb_c, f32x16 (&s)[2]) {
@@ -242,11 +247,16 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       V3D_KR(kc[0], 4, KB + 8192); V3D_KR(kc[1], 5, KB + 8192); V3D_KR(kc[2], 6, KB + 8192); V3D_KR(kc[3], 7, KB + 8192);
       V3D_KW(4, ka); V3D_KM(ka, 0, 1, 0); V3D_KM(ka, 1, 1, 1); V3D_KM(ka, 2, 1, 2); V3D_KM(ka, 3, 1, 3);
       V3D_KW(0, kc); V3D_KM(kc, 0, 1, 4); V3D_KM(kc, 1, 1, 5); V3D_KM(kc, 2, 1, 6); V3D_KM(kc, 3, 1, 7);
-    } else {   // KS == 6 (head dim 96): 4 + 2 k-steps per key half
+    } else if constexpr (KSV == 6) {   // KS == 6 (head dim 96): 4 + 2 k-steps per key half
       V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
       V3D_KR(ka[0], 2, KB + 8192); V3D_KR(ka[1], 3, KB + 8192); V3D_KR(ka[2], 4, KB + 8192); V3D_KR(ka[3], 5, KB + 8192);
       V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 1, 0); V3D_KM(kc, 3, 1, 1);
       V3D_KW(0, ka); V3D_KM(ka, 0, 1, 2); V3D_KM(ka, 1, 1, 3); V3D_KM(ka, 2, 1, 4); V3D_KM(ka, 3, 1, 5);
+    } else {                           // five k-steps (dims < 80): the same ring without k-step 5's two reads and two MFMAs
+      V3D_KW(3, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
+      V3D_KR(ka[0], 2, KB + 8192); V3D_KR(ka[1], 3, KB + 8192); V3D_KR(ka[2], 4, KB + 8192);
+      V3D_KW(3, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 2, 1, 0); V3D_KM(kc, 3, 1, 1);
+      V3D_KW(0, ka); V3D_KM(ka, 0, 1, 2); V3D_KM(ka, 1, 1, 3); V3D_KM(ka, 2, 1, 4);
     }
   };
 
@@ -1545,9 +1555,9 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
     return check_launch("v3d_attention (64 queries per wave)");
   }
   const dim3 grid(p.Hq, (p.Sq + AT_BQ - 1) / AT_BQ, B), block(256);
-#define V3D_ATTN(DD, CC)                                                                                          \
+#define V3D_ATTN(DD, CC, KK)                                                                                      \
   {                                                                                                               \
-    auto k = attn_prefill_kernel<T, DD, CC>;                                                                      \
+    auto k = attn_prefill_kernel<T, DD, CC, KK>;                                                                  \
     static bool done = false;                                                                                     \
     if (!done) {                                                                                                  \
       hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);     \
@@ -1556,10 +1566,11 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
     }                                                                                                             \
     hipLaunchKernelGGL(k, grid, block, AT_LDS, st, p);                                                            \
   }
-  if (D == 128 && causal) V3D_ATTN(128, true)
-  else if (D == 128) V3D_ATTN(128, false)
-  else if (D == 96 && causal) V3D_ATTN(96, true)
-  else if (D == 96) V3D_ATTN(96, false)
+  if (D == 128 && causal) V3D_ATTN(128, true, 8)
+  else if (D == 128) V3D_ATTN(128, false, 8)
+  else if (D == 96 && causal) V3D_ATTN(96, true, 6)
+  else if (D == 96 && p.d_out <= 80 && !getenv("V3D_ATTN_KS6")) V3D_ATTN(96, false, 5)       // SigLIP: 72-wide heads (V3D_ATTN_KS6: A/B against the 6-step form)
+  else if (D == 96) V3D_ATTN(96, false, 6)
   else { set_error("v3d_attention: head dim %d unsupported (128 or 96)", D); return V3D_E_UNSUPPORTED; }
 #undef V3D_ATTN
   return check_launch("v3d_attention");
