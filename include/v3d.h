@@ -12,7 +12,9 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all entry points are
  *     asynchronous with respect to the host, allocate nothing, keep no pointer after return
- *     and are re-entrant;
+ *     and are re-entrant - with one exception: v3d_gemm keeps one 64 MiB device workspace per stream for the
+ *     split-K tail of its 256-wide kernel (accumulator images of cut tiles), allocated by the first launch that
+ *     takes that path and never during stream capture (V3D_GEMM_STREAMK=0 switches the path, and the allocation, off);
  *   - return value: 0 = ok, negative = error (V3D_E_*); the message for the calling thread is
  *     returned by v3d_last_error();
  *   - dtype codes: V3D_F32 / V3D_F16 / V3D_BF16.  16-bit tensors are raw IEEE half / bfloat16.
@@ -141,7 +143,11 @@ int v3d_embed_gather(const void* table, int64_t vocab, int C, const int64_t* ids
  *   BIAS_RES        out = res[m or m % res_mod, n] + (acc + bias)          (SigLIP out_proj/fc2, patch-embed + pos-emb)
  *   RES             out = res[m, n] + acc                                  (Qwen2 o_proj / down_proj)
  *   SWIGLU          out[m, j] = silu(gate_j) * up_j, N' = N/2; W rows are tile-interleaved: rows
- *                   [128t, 128t+64) = gate rows [64t, 64t+64), rows [128t+64, 128t+128) = the up rows. */
+ *                   [128t, 128t+64) = gate rows [64t, 64t+64), rows [128t+64, 128t+128) = the up rows.
+ * Summation order: every kernel sums k in ascending order in one run per output - except tiles the split-K tail cuts
+ * (M x N x K shapes whose 256 x 256 tiles leave the last round of the chip under half full, e.g. 6794 x 3584 x 18944),
+ * which are the f32 sum of 2..4 runs: such an output may differ from the one-run result by one rounding of the
+ * 16-bit value.  v3d_gemm_plan_host reports the plan; V3D_GEMM_STREAMK=0 keeps every output on one run. */
 enum {
   V3D_EPI_NONE = 0, V3D_EPI_BIAS = 1, V3D_EPI_BIAS_GELU_ERF = 2, V3D_EPI_BIAS_GELU_TANH = 3,
   V3D_EPI_BIAS_RES = 4, V3D_EPI_RES = 5, V3D_EPI_SWIGLU = 6,
