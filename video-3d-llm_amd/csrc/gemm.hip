@@ -563,8 +563,9 @@ __device__ unsigned long long g_pp_tl[256 * 8 * 8];     // [workgroup][wave][seg
 #define V3D_TL_ACC(i, a, b)
 #endif
 
-// SKT: the split-K tail's exchange code is compiled in (its register needs push accumulators of the 256-row tile to scratch in
-// EVERY tile, cut or not: launches without a split take the instantiation without it, which has no spills at all)
+// SKT: the split-K tail's exchange code is compiled in.  (With an early `break` / `continue` out of the image dump that code made
+// hipcc spill 40-90 accumulator registers in EVERY tile, cut or not - which is why it lives in an instantiation of its own; written
+// as straight-line flags neither instantiation spills.)
 template <typename T, int EPI, int MT, bool SKT>
 __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -850,43 +851,45 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(p.sk_flags + blockIdx.x, p.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!has_next) break;
-      continue;
-    }
-    if (seg_head) {
+    }                                              // (no early exit: a chunk c > 0 skips the epilogue below by the same flag -
+    if (seg_head && !seg_tail) {                   //  with break / continue here hipcc spilled accumulators in every tile;
+                                                   //  a MIDDLE chunk has both flags set and is a tail: it must never wait)
       for (int c = 1; c < p.sk_split; ++c) {
         const int fg = c * sk_T + sk_g;                                  // chunk c of this tile (this workgroup is chunk 0: sk_g = j)
         const unsigned from = (unsigned)((fg % wx) * 8 + fg / wx);
         if (tid == 0)
           while (__hip_atomic_load(p.sk_flags + from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.sk_epoch) __builtin_amdgcn_s_sleep(8);
         __syncthreads();
-        const float* img = p.sk_ws + (size_t)from * (32 * 512 * 4);
-        unsigned off = (unsigned)tid * 16u;
-        asm volatile("" : "+v"(off));
-        // four 16-byte loads in flight at a time (more of them push accumulators out to scratch for EVERY tile, not just the cut ones).
-        // Loads AND their wait are one asm statement: hipcc may spill or copy an asm output the moment the statement ends, which for a
-        // load still in flight stores stale bytes and lets the returning data land in whatever reuses the register.
+        // The image comes in through LDS (the ring is free: this is the workgroup's last segment): LDS-DMA needs no registers, and
+        // the adds then take one 16-byte LDS read at a time - with the image loaded into registers (even four vectors at a time)
+        // hipcc spilled 40-90 accumulator registers in every tile of this instantiation.  Two halves of sixteen vectors per lane
+        // (16 KiB per wave and half: the whole 128 KiB ring), device-scope loads (sc0 sc1: bypass what a stale copy could sit in).
+        const char* img = (const char*)(p.sk_ws + (size_t)from * (32 * 512 * 4)) + (size_t)tid * 16;
+        char* const lw = smem + wave * 16384;
 #pragma unroll
-        for (int u0 = 0; u0 < 4 * MT; u0 += 4) {
-          f32x4 part[4];
-          const unsigned o0 = off, o1 = off + 512u * 16u, o2 = off + 2u * 512u * 16u, o3 = off + 3u * 512u * 16u;
-          asm volatile("global_load_dwordx4 %0, %4, %8 sc0 sc1\n\t"
-                       "global_load_dwordx4 %1, %5, %8 sc0 sc1\n\t"
-                       "global_load_dwordx4 %2, %6, %8 sc0 sc1\n\t"
-                       "global_load_dwordx4 %3, %7, %8 sc0 sc1\n\t"
-                       "s_waitcnt vmcnt(0)"
-                       : "=&v"(part[0]), "=&v"(part[1]), "=&v"(part[2]), "=&v"(part[3])
-                       : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(img) : "memory");
-          off += 4u * 512u * 16u;
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            f32x4& a = acc[(u0 + u) / MT][(u0 + u) % MT];
-            a[0] += part[u][0]; a[1] += part[u][1]; a[2] += part[u][2]; a[3] += part[u][3];
+          for (int u = 0; u < 16; ++u) {
+            const int c = hf * 16 + u;
+            if (c < 4 * MT)
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (size_t)c * (512 * 16)),
+                                               (__attribute__((address_space(3))) void*)(lw + u * 1024), 16, 0, 17);
           }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int c = hf * 16 + u;
+            if (c < 4 * MT) {
+              const f32x4 part = *reinterpret_cast<const f32x4*>(lw + u * 1024 + lane * 16);
+              f32x4& a = acc[c / MT][c % MT];
+              a[0] += part[0]; a[1] += part[1]; a[2] += part[2]; a[3] += part[3];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next half's DMA lands on them
         }
       }
+      __syncthreads();       // the epilogue's wave-private regions lie inside other waves' bounce regions: everyone is done with those
     }
-
     }   // SKT
 
     // Epilogue (r02b): each wave turns its own 128|96 x 64 part of the C tile around in a PRIVATE 6 KiB of LDS, 32 rows at a time -
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(GemmArgs p) {
       if (sacc == 12345.678f) out[tid] = from_f32<T>(sacc);
     } else
 #endif
-    {
+    if (!(SKT && seg_tail)) {
       int ln = lane;
       asm volatile("" : "+v"(ln));             // (as in setup: keep the epilogue's lane constants out of the K loop's registers)
       const int l15 = ln & 15, l4 = ln >> 4;
