@@ -2,7 +2,8 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "video-3d-llm_amd"))
-from v3d import ops
+from v3d import ops, _native
+if len(sys.argv) > 1: _native.LIB_PATH = os.path.abspath(sys.argv[1])      # A/B against another build of the library
 dt = torch.bfloat16
 def run(M, N, K, epi, iters=30):
     a = torch.randn(M, K, device="cuda", dtype=dt) * 0.5
