@@ -359,6 +359,29 @@ int v3d_cross_entropy_grad(const void* logits, int64_t ld, int dtype, int64_t po
 int v3d_visual_tokens_grad(const void* dout, int64_t dout_stride, void* dfeat, float* dnewline, int dtype, int V, int side, int n,
                            int C, int flags, void* stream);
 
+/* Backward of the decoder's dense blocks (r02).  With y = x . W^T (nn.Linear), dx = dy . W and dW = dy^T . x are v3d_gemm calls on
+ * transposed operands (v3d/train.py: linear_backward), so the data movement the backward adds is this transpose:
+ * out[c, r] = x[r, c] for x [rows, cols] (16-bit; cols % 8 == 0); columns [rows, out_cols) of out are zero-filled (out_cols % 8 == 0:
+ * the k padding of the dW product, whose k runs over token rows). */
+int v3d_transpose(const void* x, int64_t ldx, int64_t rows, int cols, void* out, int64_t ldo, int64_t out_cols, int dtype,
+                  void* stream);
+/* Column sums in f32 with a fixed summation order (32-row partials in `workspace`, then the partials in order): the bias gradient
+ * of nn.Linear (sum over token rows of dy).  workspace: v3d_colsum_workspace_bytes(rows, cols) bytes; out [cols] in out_dtype. */
+int64_t v3d_colsum_workspace_bytes(int64_t rows, int cols);
+int v3d_colsum(const void* x, int64_t ldx, int64_t rows, int cols, int dtype, float* workspace, void* out, int out_dtype, void* stream);
+/* Backward of v3d_rmsnorm (Qwen2RMSNorm, modeling_qwen2.py:76-90): with r = rsqrt(mean(x^2) + eps), n = T(x r), g = dy * weight:
+ * dx = r (g - n mean(g n)), dweight = sum over rows of dy n (f32, fixed order; workspace as v3d_colsum's).  `add` (may be null):
+ * a 16-bit gradient of the same shape added to dx - the residual branch that by-passes the norm (modeling_qwen2.py:771-789). */
+int v3d_rmsnorm_grad(const void* x, int64_t ldx, const void* weight, const void* dy, int64_t ldy, const void* add, int64_t lda,
+                     void* dx, int64_t ldd, float* workspace, void* dweight, int dw_dtype, int64_t rows, int cols, float eps, int dtype,
+                     void* stream);
+/* Qwen2MLP's act_fn(gate_proj(x)) * up_proj(x) (modeling_qwen2.py:177-189) on planar rows gu = [gate (inter) | up (inter)]
+ * (the training forward keeps gate / up for the backward; the inference path forms the product in v3d_gemm's SWIGLU epilogue):
+ * out = T(T(silu(g)) * u); the gradient dgu = [dh u silu'(g) | dh silu(g)]. */
+int v3d_swiglu(const void* gu, int64_t ld, void* out, int64_t ldo, int64_t rows, int inter, int dtype, void* stream);
+int v3d_swiglu_grad(const void* gu, int64_t ld, const void* dh, int64_t ldh, void* dgu, int64_t ldg, int64_t rows, int inter,
+                    int dtype, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;

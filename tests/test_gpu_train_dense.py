@@ -1,0 +1,153 @@
+"""Backward of the decoder's dense blocks (BASELINE configs[4]) against torch autograd on the CPU in f32:
+  * nn.Linear's dx / dW / db through v3d_gemm on transposed operands (v3d/train.py: linear_backward);
+  * Qwen2RMSNorm (modeling_qwen2.py:76-90), Qwen2MLP (:177-189) and the second half of Qwen2DecoderLayer.forward (:783-789).
+The reference side is the reference's own formulae restated with torch ops in f32 on the SAME 16-bit inputs, differentiated by
+autograd; the device side rounds every tensor it stores to 16 bits (as bf16 training does), so the comparison is by tolerance,
+stated per test: a norm-wise relative error and an element-wise bound relative to the largest reference magnitude."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from v3d import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def train():
+    from v3d import train as t
+    return t
+
+
+def _close(got, ref, rel, elem, what):
+    got, ref = got.float().cpu(), ref.float()
+    err = (got - ref).norm() / ref.norm().clamp_min(1e-30)
+    worst = (got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)
+    assert err < rel and worst < elem, f"{what}: norm-wise {err:.3e} (bound {rel}), element-wise {worst:.3e} of max |ref| (bound {elem})"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,cols,pad", [(5, 8, 8), (70, 136, 128), (6794, 3584, 6848), (129, 64, 192)])
+def test_transpose_is_exact_and_zero_pads(ops, dt, rows, cols, pad):
+    x = torch.randn(rows, cols, dtype=dt, device="cuda")
+    out = torch.full((cols, pad), 7.0, dtype=dt, device="cuda")
+    ops.transpose(x, out_cols=pad, out=out)
+    assert torch.equal(out[:, :rows], x.t())
+    assert not bool(out[:, rows:].any())
+
+
+def test_transpose_strided_source_and_destination(ops):
+    big = torch.randn(100, 256, dtype=torch.bfloat16, device="cuda")
+    x = big[:, 64:192]                                   # row stride 256, 128 columns
+    dst = torch.zeros(128, 160, dtype=torch.bfloat16, device="cuda")
+    ops.transpose(x, out_cols=104, out=dst[:, :104])
+    assert torch.equal(dst[:, :100], x.t()) and not bool(dst[:, 100:].any())
+
+
+def test_transpose_rejects_unaligned_shapes(ops):
+    from v3d._native import V3DError
+    with pytest.raises(V3DError):
+        ops.transpose(torch.zeros(8, 12, dtype=torch.bfloat16, device="cuda"))          # cols % 8
+    with pytest.raises(V3DError):
+        ops.transpose(torch.zeros(8, 16, dtype=torch.float32, device="cuda"))           # 16-bit only
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 8), (33, 4608), (6794, 3584)])
+def test_colsum_matches_f64_and_is_deterministic(ops, rows, cols):
+    x = torch.randn(rows, cols, dtype=torch.bfloat16, device="cuda")
+    a = ops.colsum(x, dtype=torch.float32)
+    b = ops.colsum(x, dtype=torch.float32)
+    assert torch.equal(a, b)
+    ref = x.double().sum(0).cpu()
+    assert float((a.double().cpu() - ref).abs().max()) <= 1e-5 * float(x.double().abs().sum(0).max())       # f32 accumulation
+    assert torch.equal(ops.colsum(x), a.to(torch.bfloat16))                                                  # 16-bit output = one rounding
+
+
+def _rmsnorm_ref(x, w, eps):
+    # Qwen2RMSNorm.forward, modeling_qwen2.py:85-90 (f32 inside; the reference's cast to the input dtype is the device side's rounding)
+    var = x.pow(2).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(var + eps))
+
+
+@pytest.mark.parametrize("rows,cols,with_add", [(70, 256, False), (33, 3584, True), (300, 3584, False)])
+def test_rmsnorm_grad_matches_autograd(ops, rows, cols, with_add):
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1.5).to(torch.bfloat16)
+    w = (1 + 0.2 * torch.randn(cols, generator=g)).to(torch.bfloat16)
+    dy = torch.randn(rows, cols, generator=g).to(torch.bfloat16)
+    add = torch.randn(rows, cols, generator=g).to(torch.bfloat16) if with_add else None
+    xr, wr = x.float().requires_grad_(), w.float().requires_grad_()
+    _rmsnorm_ref(xr, wr, 1e-6).backward(dy.float())
+    ref_dx = xr.grad + (add.float() if with_add else 0)
+    dx, dw = ops.rmsnorm_grad(x.cuda(), w.cuda(), dy.cuda(), 1e-6, add=add.cuda() if with_add else None, dw_dtype=torch.float32)
+    _close(dx, ref_dx, 6e-3, 1.5e-2, "dx")               # 16-bit output: 2^-9 per element
+    _close(dw, wr.grad, 4e-3, 6e-3, "dweight")           # f32 sums of products with the 16-bit normalised row
+    dx2, dw2 = ops.rmsnorm_grad(x.cuda(), w.cuda(), dy.cuda(), 1e-6, add=add.cuda() if with_add else None, dw_dtype=torch.float32)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2)                                # fixed summation order
+
+
+def test_swiglu_forward_and_gradient(ops):
+    g = torch.Generator().manual_seed(3)
+    rows, inter = 77, 1192                                # inter % 8 == 0, not a multiple of 64
+    gu = (torch.randn(rows, 2 * inter, generator=g) * 2).to(torch.bfloat16)
+    dh = torch.randn(rows, inter, generator=g).to(torch.bfloat16)
+    # Qwen2MLP.forward, modeling_qwen2.py:188: act_fn(gate) * up, each a bf16 tensor
+    ref_h = (F.silu(gu[:, :inter].float()).to(torch.bfloat16).float() * gu[:, inter:].float()).to(torch.bfloat16)
+    h = ops.swiglu(gu.cuda())
+    ulp = (h.cpu().view(torch.int16).int() - ref_h.view(torch.int16).int()).abs().max()
+    assert int(ulp) <= 1                                  # exp is the only inexact step
+    gr = gu.float().requires_grad_()
+    (F.silu(gr[:, :inter]) * gr[:, inter:]).backward(dh.float())
+    dgu = ops.swiglu_grad(gu.cuda(), dh.cuda())
+    _close(dgu, gr.grad, 6e-3, 1.5e-2, "dgu")
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 384), (520, 3584, 4608), (64, 18944, 3584)])
+def test_linear_backward_matches_f32_products(ops, train, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    dx, dw, db = train.linear_backward(x.cuda(), w.cuda(), dy.cuda(), res=res.cuda(), need_db=True)
+    _close(dx, dy.float() @ w.float() + res.float(), 5e-3, 1.5e-2, "dx")
+    _close(dw, dy.float().t() @ x.float(), 5e-3, 1.5e-2, "dW")
+    _close(db, dy.float().sum(0), 5e-3, 1e-2, "db")
+    dx_only, none_w, none_b = train.linear_backward(x.cuda(), w.cuda(), dy.cuda(), need_dw=False)
+    assert none_w is None and none_b is None
+    _close(dx_only, dy.float() @ w.float(), 5e-3, 1.5e-2, "dx without residual")
+
+
+def _mlp_block_ref(h, ln_w, w_gu, w_down, eps):
+    # Qwen2DecoderLayer.forward, modeling_qwen2.py:783-789, with Qwen2MLP :188 and Qwen2RMSNorm :85-90
+    inter = w_gu.shape[0] // 2
+    n = _rmsnorm_ref(h, ln_w, eps)
+    gu = n @ w_gu.t()
+    a = F.silu(gu[:, :inter]) * gu[:, inter:]
+    return h + a @ w_down.t()
+
+
+@pytest.mark.parametrize("S,H,I", [(200, 256, 512), (300, 3584, 18944)])
+def test_mlp_block_forward_and_backward_match_autograd(train, S, H, I):
+    """The MLP half of a Qwen2 decoder layer, forward and backward, at a small width and at the 7B model's true width."""
+    g = torch.Generator().manual_seed(S + H)
+    h = torch.randn(S, H, generator=g).to(torch.bfloat16)
+    ln_w = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+    w_gu = (torch.randn(2 * I, H, generator=g) * H ** -0.5).to(torch.bfloat16)
+    w_down = (torch.randn(H, I, generator=g) * I ** -0.5).to(torch.bfloat16)
+    dout = torch.randn(S, H, generator=g).to(torch.bfloat16)
+    leaves = [t.float().requires_grad_() for t in (h, ln_w, w_gu, w_down)]
+    ref_out = _mlp_block_ref(*leaves, 1e-6)
+    ref_out.backward(dout.float())
+    dev = [t.cuda() for t in (h, ln_w, w_gu, w_down)]
+    out, saved = train.mlp_block_forward(*dev)
+    _close(out, ref_out.detach(), 6e-3, 2e-2, "forward")
+    dh, grads = train.mlp_block_backward(dout.cuda(), saved, dev[1], dev[2], dev[3])
+    _close(dh, leaves[0].grad, 1e-2, 3e-2, "dh")
+    _close(grads["ln"], leaves[1].grad, 1e-2, 3e-2, "d ln weight")
+    _close(grads["gate_up"], leaves[2].grad, 1e-2, 3e-2, "d gate/up weight")
+    _close(grads["down"], leaves[3].grad, 1e-2, 3e-2, "d down weight")

@@ -159,6 +159,195 @@ __global__ __launch_bounds__(256) void newline_grad_kernel(const T* __restrict__
   dnl[c] = s;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the decoder's dense blocks (r02).  The matrix products of the backward pass run on v3d_gemm (out = A . W^T): with
+// y = x . W^T,  dx = dy . (W^T)^T  and  dW = dy^T . (x^T)^T,  so the only new data movement is a 2-D transpose; everything else here
+// is an HBM-bound row pass.
+//   v3d_transpose       out[c, r] = x[r, c] (16-bit), columns [rows, out_cols) of out zero-filled (the k padding of the dW product)
+//   v3d_colsum          bias gradients: column sums of dy in f32, fixed summation order (32-row partials, then the partials in order)
+//   v3d_rmsnorm_grad    Qwen2RMSNorm (modeling_qwen2.py:76-90): dx (+ the residual branch's gradient) and dweight
+//   v3d_swiglu / _grad  Qwen2MLP (modeling_qwen2.py:177-189): act_fn(gate) * up on a planar [gate | up] row, and its backward
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int TG_RPB = 32;         // rows per partial of the column reductions
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int cols, T* __restrict__ out,
+                                                        int64_t ldo, int64_t out_cols) {
+  __shared__ uint16_t tile[64][64 + 2];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, r = idx >> 3, ch = idx & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(x + (r0 + r) * ldx + c0 + ch * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { tile[r][ch * 8 + 2 * j] = (uint16_t)(w[j] & 0xffffu); tile[r][ch * 8 + 2 * j + 1] = (uint16_t)(w[j] >> 16); }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + 256 * i, c = idx >> 3, ch = idx & 7;          // output row c0 + c, output columns r0 + 8 ch ..
+    if (c0 + c < cols && r0 + ch * 8 < out_cols) {
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[ch * 8 + 2 * j][c] | ((uint32_t)tile[ch * 8 + 2 * j + 1][c] << 16);
+      *reinterpret_cast<uint4*>(out + (int64_t)(c0 + c) * ldo + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+// partial[b, c] = sum over rows [32 b, 32 b + 32) of x[r, c]   (f32, rows in order)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                             float* __restrict__ partial) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch * 8 >= cols) return;
+  const int64_t rb = (int64_t)blockIdx.y * TG_RPB;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < TG_RPB && rb + i < rows; ++i) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (rb + i) * ldx + ch * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += vec_get<T>(v, j);
+  }
+  float* o = partial + (int64_t)blockIdx.y * cols + ch * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = s[j];
+}
+
+// out[c] = sum over the partials in order
+template <typename TO>
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_part, int cols, TO* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < n_part; ++b) s += partial[b * cols + c];
+  out[c] = from_f32<TO>(s);
+}
+
+// y = w * T(x r), r = rsqrt(mean(x^2) + eps).  With n = x r and g = dy w:  dx = r (g - n mean(g n)) [+ add],  dw = sum_rows dy n.
+// A workgroup takes 32 rows (a wave per row, eight rounds); the dw contributions of its rows are summed per lane in f32 (rows in
+// order within a wave, the four waves through LDS in order) and leave as one partial row.
+constexpr int TG_MAXV = 7;
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_grad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, const T* __restrict__ dy,
+                                                           int64_t ldy, const T* __restrict__ add, int64_t lda, T* __restrict__ dx, int64_t ldd,
+                                                           float* __restrict__ partial, int64_t rows, int cols, float eps) {
+  extern __shared__ float red[];              // [4][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = cols / 8;
+  float dwp[TG_MAXV][8];
+#pragma unroll
+  for (int i = 0; i < TG_MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwp[i][j] = 0.f;
+  for (int round = 0; round < TG_RPB / 4; ++round) {
+    const int64_t row = (int64_t)blockIdx.x * TG_RPB + round * 4 + wave;
+    if (row >= rows) break;
+    uint4 xv[TG_MAXV], gv[TG_MAXV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < TG_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+        xv[i] = *reinterpret_cast<const uint4*>(x + row * ldx + k * 8);
+        gv[i] = *reinterpret_cast<const uint4*>(dy + row * ldy + k * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(xv[i], j); ss = fmaf(f, f, ss); }
+      }
+    }
+    ss = wave_sum_f(ss);
+    const float r = 1.0f / sqrtf(ss / (float)cols + eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < TG_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float n = round_to<T>(vec_get<T>(xv[i], j) * r), d = vec_get<T>(gv[i], j);
+          dot = fmaf(d * vec_get<T>(wv, j), n, dot);
+          dwp[i][j] = fmaf(d, n, dwp[i][j]);
+        }
+      }
+    }
+    dot = wave_sum_f(dot) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < TG_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
+        uint4 av = make_uint4(0, 0, 0, 0);
+        if (add) av = *reinterpret_cast<const uint4*>(add + row * lda + k * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float n = round_to<T>(vec_get<T>(xv[i], j) * r);
+          const float g = vec_get<T>(gv[i], j) * vec_get<T>(wv, j);
+          o[j] = r * (g - n * dot);
+          if (add) o[j] = round_to<T>(o[j]) + vec_get<T>(av, j);        // the two branches' gradients are 16-bit tensors that torch adds
+        }
+        *reinterpret_cast<uint4*>(dx + row * ldd + k * 8) = vec_pack<T>(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TG_MAXV; ++i) {
+    const int k = i * 64 + lane;
+    if (k < nv)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[wave * cols + k * 8 + j] = dwp[i][j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256)
+    partial[(int64_t)blockIdx.x * cols + c] = ((red[c] + red[cols + c]) + red[2 * cols + c]) + red[3 * cols + c];
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// h = T(T(silu(g)) * u)  on rows [g (inter) | u (inter)]
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gu, int64_t ld, T* __restrict__ out, int64_t ldo, int64_t rows, int inter) {
+  const int nv = inter / 8;
+  const int64_t total = rows * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / nv;
+    const int k = (int)(idx - r * nv);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + r * ld + k * 8), u = *reinterpret_cast<const uint4*>(gu + r * ld + inter + k * 8);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float x = vec_get<T>(g, j); o[j] = round_to<T>(x * sigmoid_f(x)) * vec_get<T>(u, j); }
+    *reinterpret_cast<uint4*>(out + r * ldo + k * 8) = vec_pack<T>(o);
+  }
+}
+
+// dg = dh u silu'(g),  du = dh silu(g);  silu'(g) = s (1 + g (1 - s)), s = sigmoid(g)
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_grad_kernel(const T* __restrict__ gu, int64_t ld, const T* __restrict__ dh, int64_t ldh,
+                                                          T* __restrict__ dgu, int64_t ldg, int64_t rows, int inter) {
+  const int nv = inter / 8;
+  const int64_t total = rows * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / nv;
+    const int k = (int)(idx - r * nv);
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + r * ld + k * 8), u = *reinterpret_cast<const uint4*>(gu + r * ld + inter + k * 8);
+    const uint4 d = *reinterpret_cast<const uint4*>(dh + r * ldh + k * 8);
+    float og[8], ou[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = vec_get<T>(g, j), s = sigmoid_f(x), dd = vec_get<T>(d, j);
+      ou[j] = dd * round_to<T>(x * s);
+      og[j] = round_to<T>(dd * vec_get<T>(u, j)) * (s * (1.0f + x * (1.0f - s)));
+    }
+    *reinterpret_cast<uint4*>(dgu + r * ldg + k * 8) = vec_pack<T>(og);
+    *reinterpret_cast<uint4*>(dgu + r * ldg + inter + k * 8) = vec_pack<T>(ou);
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -210,4 +399,91 @@ extern "C" int v3d_visual_tokens_grad(const void* dout, int64_t dout_stride, voi
     else hipLaunchKernelGGL(newline_grad_kernel<f16_t>, dim3((C + 255) / 256), dim3(256), 0, st, (const f16_t*)dout, dout_stride, dnewline, V, n, C);
   }
   return check_launch("v3d_visual_tokens_grad");
+}
+
+#define V3D_DISPATCH_HALF(dtype, ...)                                         \
+  switch (dtype) {                                                            \
+    case V3D_F16: { using T = v3d::f16_t; __VA_ARGS__; } break;               \
+    case V3D_BF16: { using T = v3d::bf16_t; __VA_ARGS__; } break;             \
+    default: v3d::set_error("16-bit dtypes only (got code %d)", (int)(dtype)); return V3D_E_INVALID; \
+  }
+
+extern "C" int v3d_transpose(const void* x, int64_t ldx, int64_t rows, int cols, void* out, int64_t ldo, int64_t out_cols, int dtype,
+                             void* stream) {
+  V3D_REQUIRE(x && out, "v3d_transpose: null pointer");
+  V3D_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldx >= cols, "v3d_transpose: the source needs cols %% 8 == 0 and a row stride that is a multiple of 8");
+  V3D_REQUIRE(out_cols >= rows && out_cols % 8 == 0 && ldo % 8 == 0 && ldo >= out_cols, "v3d_transpose: out_cols must cover the source rows and be a multiple of 8 (so must ldo)");
+  V3D_REQUIRE(aligned16(x) && aligned16(out), "v3d_transpose: pointers must be 16-byte aligned");
+  V3D_REQUIRE((out_cols + 63) / 64 < (1ll << 31) && (cols + 63) / 64 <= 65535, "v3d_transpose: too large");
+  const dim3 grid((unsigned)((out_cols + 63) / 64), (unsigned)((cols + 63) / 64));
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, rows, cols, (T*)out, ldo, out_cols));
+  return check_launch("v3d_transpose");
+}
+
+extern "C" int64_t v3d_colsum_workspace_bytes(int64_t rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return ((rows + TG_RPB - 1) / TG_RPB) * (int64_t)cols * 4;
+}
+
+static int colsum_final(const float* partial, int64_t n_part, int cols, void* out, int out_dtype, hipStream_t st, const char* what) {
+  const dim3 grid((cols + 255) / 256);
+  switch (out_dtype) {
+    case V3D_F32: hipLaunchKernelGGL(colsum_final_kernel<float>, grid, dim3(256), 0, st, partial, n_part, cols, (float*)out); break;
+    case V3D_F16: hipLaunchKernelGGL(colsum_final_kernel<f16_t>, grid, dim3(256), 0, st, partial, n_part, cols, (f16_t*)out); break;
+    case V3D_BF16: hipLaunchKernelGGL(colsum_final_kernel<bf16_t>, grid, dim3(256), 0, st, partial, n_part, cols, (bf16_t*)out); break;
+    default: set_error("%s: unknown output dtype %d", what, out_dtype); return V3D_E_INVALID;
+  }
+  return check_launch(what);
+}
+
+extern "C" int v3d_colsum(const void* x, int64_t ldx, int64_t rows, int cols, int dtype, float* workspace, void* out, int out_dtype,
+                          void* stream) {
+  V3D_REQUIRE(x && workspace && out, "v3d_colsum: null pointer");
+  V3D_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldx >= cols && aligned16(x), "v3d_colsum: cols and the row stride must be multiples of 8");
+  const int64_t n_part = (rows + TG_RPB - 1) / TG_RPB;
+  V3D_REQUIRE(n_part <= 65535, "v3d_colsum: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((cols / 8 + 255) / 256, (unsigned)n_part);
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(colsum_partial_kernel<T>, grid, dim3(256), 0, st, (const T*)x, ldx, rows, cols, workspace));
+  if (int e = check_launch("v3d_colsum")) return e;
+  return colsum_final(workspace, n_part, cols, out, out_dtype, st, "v3d_colsum");
+}
+
+extern "C" int v3d_rmsnorm_grad(const void* x, int64_t ldx, const void* weight, const void* dy, int64_t ldy, const void* add, int64_t lda,
+                                void* dx, int64_t ldd, float* workspace, void* dweight, int dw_dtype, int64_t rows, int cols, float eps,
+                                int dtype, void* stream) {
+  V3D_REQUIRE(x && weight && dy && dx && workspace && dweight, "v3d_rmsnorm_grad: null pointer");
+  V3D_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= TG_MAXV * 512, "v3d_rmsnorm_grad: cols=%d unsupported", cols);
+  V3D_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldd % 8 == 0 && (!add || lda % 8 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) &&
+              aligned16(weight) && aligned16(add), "v3d_rmsnorm_grad: alignment");
+  const int64_t n_part = (rows + TG_RPB - 1) / TG_RPB;
+  V3D_REQUIRE(n_part < (1ll << 31), "v3d_rmsnorm_grad: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * cols * sizeof(float);
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(rmsnorm_grad_kernel<T>, dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight,
+                                              (const T*)dy, ldy, (const T*)add, lda, (T*)dx, ldd, workspace, rows, cols, eps));
+  if (int e = check_launch("v3d_rmsnorm_grad")) return e;
+  return colsum_final(workspace, n_part, cols, dweight, dw_dtype, st, "v3d_rmsnorm_grad");
+}
+
+extern "C" int v3d_swiglu(const void* gu, int64_t ld, void* out, int64_t ldo, int64_t rows, int inter, int dtype, void* stream) {
+  V3D_REQUIRE(gu && out, "v3d_swiglu: null pointer");
+  V3D_REQUIRE(rows > 0 && inter > 0 && inter % 8 == 0 && ld % 8 == 0 && ld >= 2 * (int64_t)inter && ldo % 8 == 0 && ldo >= inter && aligned16(gu) && aligned16(out),
+              "v3d_swiglu: rows are [gate (inter) | up (inter)], inter %% 8 == 0");
+  int64_t blocks = (rows * (inter / 8) + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(swiglu_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)gu, ld, (T*)out, ldo, rows, inter));
+  return check_launch("v3d_swiglu");
+}
+
+extern "C" int v3d_swiglu_grad(const void* gu, int64_t ld, const void* dh, int64_t ldh, void* dgu, int64_t ldg, int64_t rows, int inter,
+                               int dtype, void* stream) {
+  V3D_REQUIRE(gu && dh && dgu, "v3d_swiglu_grad: null pointer");
+  V3D_REQUIRE(rows > 0 && inter > 0 && inter % 8 == 0 && ld % 8 == 0 && ld >= 2 * (int64_t)inter && ldg % 8 == 0 && ldg >= 2 * (int64_t)inter && ldh % 8 == 0 &&
+              ldh >= inter && aligned16(gu) && aligned16(dh) && aligned16(dgu), "v3d_swiglu_grad: rows are [gate (inter) | up (inter)], inter %% 8 == 0");
+  int64_t blocks = (rows * (inter / 8) + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(swiglu_grad_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)gu, ld, (const T*)dh, ldh,
+                                              (T*)dgu, ldg, rows, inter));
+  return check_launch("v3d_swiglu_grad");
 }

@@ -83,6 +83,12 @@ SIGNATURES = {
     "v3d_cross_entropy": (c_i, [c_p, c_l, c_i, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_p]),
     "v3d_cross_entropy_grad": (c_i, [c_p, c_l, c_i, c_l, c_i, c_p, c_l, c_p, c_p, c_f, c_p, c_l, c_i, c_p]),
     "v3d_visual_tokens_grad": (c_i, [c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_transpose": (c_i, [c_p, c_l, c_l, c_i, c_p, c_l, c_l, c_i, c_p]),
+    "v3d_colsum_workspace_bytes": (c_l, [c_l, c_i]),
+    "v3d_colsum": (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "v3d_rmsnorm_grad": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_i, c_l, c_i, c_f, c_i, c_p]),
+    "v3d_swiglu": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p]),
+    "v3d_swiglu_grad": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),
     "v3d_gemm_plan_host": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "v3d_voxel_keys_f32": (c_i, [c_p, c_l, c_f, c_p, c_p]),

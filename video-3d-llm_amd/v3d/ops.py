@@ -677,3 +677,70 @@ def visual_tokens_grad(dout, V, side=27, n=14, newline=True):
     flags = VT_POOL | VT_PE | (VT_NEWLINE if newline else 0)
     check(lib().v3d_visual_tokens_grad(_p(g), g.stride(0), _p(dfeat), _p(dnl), _code(g), V, side, n, C, flags, _stream()), "v3d_visual_tokens_grad")
     return dfeat, dnl
+
+
+# ------------------------------------------------------------------------------ backward of the dense blocks (configs[4])
+
+
+def transpose(x, out_cols=None, out=None):
+    """out[c, r] = x[r, c] for a 16-bit x [rows, cols]; out is [cols, out_cols] with columns >= rows zero (out_cols % 8 == 0)."""
+    x = _dev(x, "x")
+    rows, cols = x.shape
+    out_cols = out_cols or (rows + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((cols, out_cols), dtype=x.dtype, device=x.device)
+    _rows_fit(out, cols, out_cols, x.dtype, "transpose")
+    check(lib().v3d_transpose(_p(x), x.stride(0), rows, cols, _p(out), out.stride(0), out_cols, _code(x), _stream()), "v3d_transpose")
+    return out
+
+
+def _colsum_ws(rows, cols, device):
+    return torch.empty(max(1, lib().v3d_colsum_workspace_bytes(rows, cols) // 4), dtype=torch.float32, device=device)
+
+
+def colsum(x, dtype=None):
+    """Sum over the rows of a 16-bit x [rows, cols] (f32 accumulation in a fixed order) -> [cols] in `dtype` (default x's)."""
+    x = _dev(x, "x")
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=dtype or x.dtype, device=x.device)
+    check(lib().v3d_colsum(_p(x), x.stride(0), rows, cols, _code(x), _p(_colsum_ws(rows, cols, x.device)), _p(out), _DT[out.dtype], _stream()),
+          "v3d_colsum")
+    return out
+
+
+def rmsnorm_grad(x, weight, dy, eps=1e-6, add=None, dw_dtype=None):
+    """Backward of rmsnorm: returns (dx [rows, cols] (+ add), dweight [cols])."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    rows, cols = x.shape
+    if tuple(dy.shape) != (rows, cols) or (add is not None and tuple(add.shape) != (rows, cols)):
+        raise V3DError("rmsnorm_grad: dy / add must have x's shape")
+    dx = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    dw = torch.empty(cols, dtype=dw_dtype or x.dtype, device=x.device)
+    check(lib().v3d_rmsnorm_grad(_p(x), x.stride(0), _p(weight), _p(dy), dy.stride(0), _p(add), add.stride(0) if add is not None else 0,
+                                 _p(dx), dx.stride(0), _p(_colsum_ws(rows, cols, x.device)), _p(dw), _DT[dw.dtype], rows, cols, eps,
+                                 _code(x), _stream()), "v3d_rmsnorm_grad")
+    return dx, dw
+
+
+def swiglu(gu, out=None):
+    """act_fn(gate) * up on planar rows gu = [gate | up] -> [rows, inter]."""
+    gu = _dev(gu, "gu")
+    rows, two = gu.shape
+    inter = two // 2
+    if out is None:
+        out = torch.empty((rows, inter), dtype=gu.dtype, device=gu.device)
+    check(lib().v3d_swiglu(_p(gu), gu.stride(0), _p(out), out.stride(0), rows, inter, _code(gu), _stream()), "v3d_swiglu")
+    return out
+
+
+def swiglu_grad(gu, dh):
+    """Gradient of swiglu with respect to gu, planar [dgate | dup]."""
+    gu, dh = _dev(gu, "gu"), _dev(dh, "dh")
+    rows, two = gu.shape
+    inter = two // 2
+    if tuple(dh.shape) != (rows, inter):
+        raise V3DError("swiglu_grad: dh must be [rows, inter]")
+    dgu = torch.empty((rows, two), dtype=gu.dtype, device=gu.device)
+    check(lib().v3d_swiglu_grad(_p(gu), gu.stride(0), _p(dh), dh.stride(0), _p(dgu), dgu.stride(0), rows, inter, _code(gu), _stream()),
+          "v3d_swiglu_grad")
+    return dgu
