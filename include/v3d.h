@@ -382,6 +382,16 @@ int v3d_swiglu(const void* gu, int64_t ld, void* out, int64_t ldo, int64_t rows,
 int v3d_swiglu_grad(const void* gu, int64_t ld, const void* dh, int64_t ldh, void* dgu, int64_t ldg, int64_t rows, int inter,
                     int dtype, void* stream);
 
+/* Attention backward, first form: one head's probabilities are materialised (16-bit [queries, keys], the rounding points of the
+ * reference's eager attention, modeling_qwen2.py:248-327) and the five products run on v3d_gemm (v3d/train.py: attention_backward);
+ * these are the two row passes between them.  cols = the padded key count (% 8 == 0, <= 8192).
+ * v3d_causal_softmax_rows: p[i, j] = softmax over the keys j <= i + offset, j < n_keys of T(s[i, j] * scale); 0 for the other j < cols.
+ * v3d_softmax_grad_rows:   ds[i, j] = T(p (dp - sum_j p dp)) * scale (rounded to T). */
+int v3d_causal_softmax_rows(const void* s, int64_t lds, void* p, int64_t ldp, int64_t rows, int n_keys, int cols, int offset,
+                            float scale, int dtype, void* stream);
+int v3d_softmax_grad_rows(const void* p, int64_t ldp, const void* dp, int64_t ldd, void* ds, int64_t lds, int64_t rows, int cols,
+                          float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;

@@ -1,6 +1,8 @@
 """Backward of the decoder's dense blocks (BASELINE configs[4]) against torch autograd on the CPU in f32:
   * nn.Linear's dx / dW / db through v3d_gemm on transposed operands (v3d/train.py: linear_backward);
-  * Qwen2RMSNorm (modeling_qwen2.py:76-90), Qwen2MLP (:177-189) and the second half of Qwen2DecoderLayer.forward (:783-789).
+  * Qwen2RMSNorm (modeling_qwen2.py:76-90), Qwen2MLP (:177-189) and the second half of Qwen2DecoderLayer.forward (:783-789);
+  * causal GQA attention backward in its first, materialised form (eager Qwen2Attention, :236-327), the rotary's transpose, and one
+    whole Qwen2DecoderLayer (:727-801) forward + every gradient, at a small width and at the 7B model's true width.
 The reference side is the reference's own formulae restated with torch ops in f32 on the SAME 16-bit inputs, differentiated by
 autograd; the device side rounds every tensor it stores to 16 bits (as bf16 training does), so the comparison is by tolerance,
 stated per test: a norm-wise relative error and an element-wise bound relative to the largest reference magnitude."""
@@ -151,3 +153,83 @@ def test_mlp_block_forward_and_backward_match_autograd(train, S, H, I):
     _close(grads["ln"], leaves[1].grad, 1e-2, 3e-2, "d ln weight")
     _close(grads["gate_up"], leaves[2].grad, 1e-2, 3e-2, "d gate/up weight")
     _close(grads["down"], leaves[3].grad, 1e-2, 3e-2, "d down weight")
+
+
+# ------------------------------------------------------------------------------ attention block, whole decoder layer
+
+
+def _rope_ref(x, n_heads, hd, base=1e6):
+    # Qwen2RotaryEmbedding + apply_rotary_pos_emb, modeling_qwen2.py:93-173 (positions 0..S-1), f32
+    S = x.shape[0]
+    inv = 1.0 / (base ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+    ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = torch.cat([ang, ang], -1).cos()[:, None, :], torch.cat([ang, ang], -1).sin()[:, None, :]
+    xh = x.view(S, n_heads, hd)
+    rot = torch.cat([-xh[..., hd // 2:], xh[..., :hd // 2]], -1)
+    return (xh * cos + rot * sin).reshape(S, n_heads * hd)
+
+
+def _attention_ref(q, k, v, n_q, n_kv, hd):
+    # eager Qwen2Attention.forward, modeling_qwen2.py:248-327: repeat_kv (:236-245), causal mask, softmax in f32
+    S = q.shape[0]
+    qh = q.view(S, n_q, hd).transpose(0, 1)
+    kh = k.view(S, n_kv, hd).transpose(0, 1).repeat_interleave(n_q // n_kv, 0)
+    vh = v.view(S, n_kv, hd).transpose(0, 1).repeat_interleave(n_q // n_kv, 0)
+    s = qh @ kh.transpose(1, 2) / hd ** 0.5
+    s = s + torch.full((S, S), float("-inf")).triu(1)
+    return (torch.softmax(s, -1) @ vh).transpose(0, 1).reshape(S, n_q * hd)
+
+
+@pytest.mark.parametrize("S", [150, 257])
+def test_attention_backward_matches_autograd(ops, train, S):
+    n_q, n_kv, hd = 4, 2, 128
+    g = torch.Generator().manual_seed(S)
+    width = (n_q + 2 * n_kv) * hd
+    qkv = torch.randn(S, width, generator=g).to(torch.bfloat16)
+    do = torch.randn(S, n_q * hd, generator=g).to(torch.bfloat16)
+    ref = qkv.float().requires_grad_()
+    _attention_ref(ref[:, :n_q * hd], ref[:, n_q * hd:(n_q + n_kv) * hd], ref[:, (n_q + n_kv) * hd:], n_q, n_kv, hd).backward(do.float())
+    Sp = (S + 127) // 128 * 128
+    dev = torch.zeros(Sp, width, dtype=torch.bfloat16, device="cuda")
+    dev[:S] = qkv.cuda()
+    dqkv = torch.full((S, width), float("nan"), dtype=torch.bfloat16, device="cuda")
+    train.attention_backward(dev, do.cuda(), dqkv, S, n_q, n_kv, hd, hd ** -0.5)
+    for name, sl in (("dq", slice(0, n_q * hd)), ("dk", slice(n_q * hd, (n_q + n_kv) * hd)), ("dv", slice((n_q + n_kv) * hd, width))):
+        _close(dqkv[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name)          # p, dp, ds are 16-bit tensors (2^-9 each)
+
+
+def _layer_ref(h, p, n_q, n_kv, hd, eps):
+    # Qwen2DecoderLayer.forward, modeling_qwen2.py:727-801
+    n = _rmsnorm_ref(h, p["ln1"], eps)
+    qkv = n @ p["qkv"].t() + p["qkv_bias"]
+    q = _rope_ref(qkv[:, :n_q * hd], n_q, hd)
+    k = _rope_ref(qkv[:, n_q * hd:(n_q + n_kv) * hd], n_kv, hd)
+    o = _attention_ref(q, k, qkv[:, (n_q + n_kv) * hd:], n_q, n_kv, hd)
+    mid = h + o @ p["o"].t()
+    return _mlp_block_ref(mid, p["ln2"], p["gate_up"], p["down"], eps)
+
+
+@pytest.mark.parametrize("S,H,I,n_q,n_kv", [(200, 512, 1024, 4, 2), (333, 512, 1024, 4, 2), (300, 3584, 18944, 28, 4)])
+def test_decoder_layer_forward_and_backward_match_autograd(train, S, H, I, n_q, n_kv):
+    """One Qwen2 decoder layer, forward and every gradient, against autograd in f32: GQA 4/2 heads of 128, hidden 512, MLP 1024, and
+    the 7B model's own layer (hidden 3584, 28/4 heads, MLP 18944)."""
+    hd = 128
+    g = torch.Generator().manual_seed(S)
+    width = (n_q + 2 * n_kv) * hd
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
+    p = {"ln1": (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.5),
+         "o": mk(H, n_q * hd, s=(n_q * hd) ** -0.5), "ln2": (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16),
+         "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)}
+    h, dout = mk(S, H), mk(S, H)
+    leaves = {k: v.float().requires_grad_() for k, v in p.items()}
+    hr = h.float().requires_grad_()
+    ref_out = _layer_ref(hr, leaves, n_q, n_kv, hd, 1e-6)
+    ref_out.backward(dout.float())
+    rope = train.RopeTables(hd, 512, 1e6, torch.bfloat16, "cuda")
+    dev = {k: v.cuda() for k, v in p.items()}
+    out, saved = train.decoder_layer_forward(h.cuda(), dev, rope, n_q, n_kv, hd)
+    _close(out, ref_out.detach(), 8e-3, 3e-2, "forward")
+    dh, grads = train.decoder_layer_backward(dout.cuda(), saved, dev, rope, n_q, n_kv, hd)
+    _close(dh, hr.grad, 1.5e-2, 4e-2, "dh")
+    for k in p:
+        _close(grads[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)

@@ -348,6 +348,99 @@ __global__ __launch_bounds__(256) void swiglu_grad_kernel(const T* __restrict__ 
   }
 }
 
+
+// Attention backward, first form (r02): the score matrix of one head is MATERIALISED ([queries, keys] 16-bit, the rounding points of the
+// reference's eager attention, modeling_qwen2.py:248-327) so that all five products of the backward run on v3d_gemm; these two row
+// passes are what is left.  One workgroup per query row, the row (<= 8192 keys) held in registers.
+//   causal_softmax_rows   p[i, j] = softmax_j( T(s[i, j] * scale) ) over the keys j <= i + off, j < n_keys; 0 elsewhere in [0, cols)
+//   softmax_grad_rows     ds[i, j] = T( T(p (dp - sum_j p dp)) * scale )
+constexpr int SM_MAXV = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void causal_softmax_rows_kernel(const T* __restrict__ s, int64_t lds, T* __restrict__ p, int64_t ldp, int n_keys,
+                                                                  int cols, int off, float scale) {
+  __shared__ float sm[4];
+  const int64_t row = blockIdx.x;
+  const int64_t lim = row + off + 1;
+  const int valid = (int)(lim < n_keys ? lim : n_keys);         // keys [0, valid) are visible (>= 1 for off >= 0)
+  const int nv = cols / 8, tid = threadIdx.x;
+  float x[SM_MAXV][8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SM_MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv) {
+      const uint4 v = *reinterpret_cast<const uint4*>(s + row * lds + k * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x[i][j] = k * 8 + j < valid ? round_to<T>(vec_get<T>(v, j) * scale) : -INFINITY;
+        m = fmaxf(m, x[i][j]);
+      }
+    }
+  }
+  m = wave_max_f(m);
+  if ((tid & 63) == 0) sm[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { x[i][j] = m == -INFINITY ? 0.f : __expf(x[i][j] - m); sum += x[i][j]; }
+  }
+  sum = wave_sum_f(sum);
+  if ((tid & 63) == 0) sm[tid >> 6] = sum;
+  __syncthreads();
+  sum = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = x[i][j] * inv;
+      *reinterpret_cast<uint4*>(p + row * ldp + k * 8) = vec_pack<T>(o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_grad_rows_kernel(const T* __restrict__ p, int64_t ldp, const T* __restrict__ dp, int64_t ldd,
+                                                                T* __restrict__ ds, int64_t lds, int cols, float scale) {
+  __shared__ float sm[4];
+  const int64_t row = blockIdx.x;
+  const int nv = cols / 8, tid = threadIdx.x;
+  uint4 pv[SM_MAXV], dv[SM_MAXV];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv) {
+      pv[i] = *reinterpret_cast<const uint4*>(p + row * ldp + k * 8);
+      dv[i] = *reinterpret_cast<const uint4*>(dp + row * ldd + k * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot = fmaf(vec_get<T>(pv[i], j), vec_get<T>(dv[i], j), dot);
+    }
+  }
+  dot = wave_sum_f(dot);
+  if ((tid & 63) == 0) sm[tid >> 6] = dot;
+  __syncthreads();
+  dot = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+#pragma unroll
+  for (int i = 0; i < SM_MAXV; ++i) {
+    const int k = i * 256 + tid;
+    if (k < nv) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = round_to<T>(vec_get<T>(pv[i], j) * (vec_get<T>(dv[i], j) - dot)) * scale;
+      *reinterpret_cast<uint4*>(ds + row * lds + k * 8) = vec_pack<T>(o);
+    }
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -486,4 +579,26 @@ extern "C" int v3d_swiglu_grad(const void* gu, int64_t ld, const void* dh, int64
   V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(swiglu_grad_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const T*)gu, ld, (const T*)dh, ldh,
                                               (T*)dgu, ldg, rows, inter));
   return check_launch("v3d_swiglu_grad");
+}
+
+extern "C" int v3d_causal_softmax_rows(const void* s, int64_t lds, void* p, int64_t ldp, int64_t rows, int n_keys, int cols, int offset,
+                                       float scale, int dtype, void* stream) {
+  V3D_REQUIRE(s && p, "v3d_causal_softmax_rows: null pointer");
+  V3D_REQUIRE(rows > 0 && rows < (1ll << 31) && n_keys > 0 && cols >= n_keys && cols % 8 == 0 && cols <= SM_MAXV * 2048 && offset >= 0,
+              "v3d_causal_softmax_rows: cols %% 8 == 0, n_keys <= cols <= %d, offset >= 0", SM_MAXV * 2048);
+  V3D_REQUIRE(lds % 8 == 0 && ldp % 8 == 0 && lds >= cols && ldp >= cols && aligned16(s) && aligned16(p), "v3d_causal_softmax_rows: alignment");
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(causal_softmax_rows_kernel<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)s, lds,
+                                              (T*)p, ldp, n_keys, cols, offset, scale));
+  return check_launch("v3d_causal_softmax_rows");
+}
+
+extern "C" int v3d_softmax_grad_rows(const void* p, int64_t ldp, const void* dp, int64_t ldd, void* ds, int64_t lds, int64_t rows, int cols,
+                                     float scale, int dtype, void* stream) {
+  V3D_REQUIRE(p && dp && ds, "v3d_softmax_grad_rows: null pointer");
+  V3D_REQUIRE(rows > 0 && rows < (1ll << 31) && cols > 0 && cols % 8 == 0 && cols <= SM_MAXV * 2048, "v3d_softmax_grad_rows: cols %% 8 == 0, cols <= %d", SM_MAXV * 2048);
+  V3D_REQUIRE(ldp % 8 == 0 && ldd % 8 == 0 && lds % 8 == 0 && ldp >= cols && ldd >= cols && lds >= cols && aligned16(p) && aligned16(dp) && aligned16(ds),
+              "v3d_softmax_grad_rows: alignment");
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(softmax_grad_rows_kernel<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)p, ldp,
+                                              (const T*)dp, ldd, (T*)ds, lds, cols, scale));
+  return check_launch("v3d_softmax_grad_rows");
 }

@@ -744,3 +744,25 @@ def swiglu_grad(gu, dh):
     check(lib().v3d_swiglu_grad(_p(gu), gu.stride(0), _p(dh), dh.stride(0), _p(dgu), dgu.stride(0), rows, inter, _code(gu), _stream()),
           "v3d_swiglu_grad")
     return dgu
+
+
+def causal_softmax_rows(s, n_keys, scale, offset=0, out=None):
+    """p[i, j] = softmax over the keys j <= i + offset (j < n_keys) of s[i, j] * scale, zero in the other columns of s's width."""
+    s = _dev(s, "s")
+    rows, cols = s.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=s.dtype, device=s.device)
+    check(lib().v3d_causal_softmax_rows(_p(s), s.stride(0), _p(out), out.stride(0), rows, n_keys, cols, offset, float(scale), _code(s), _stream()),
+          "v3d_causal_softmax_rows")
+    return out
+
+
+def softmax_grad_rows(p, dp, scale, out=None):
+    """ds = p * (dp - rowsum(p * dp)) * scale."""
+    p, dp = _dev(p, "p"), _dev(dp, "dp")
+    rows, cols = p.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=p.dtype, device=p.device)
+    check(lib().v3d_softmax_grad_rows(_p(p), p.stride(0), _p(dp), dp.stride(0), _p(out), out.stride(0), rows, cols, float(scale), _code(p), _stream()),
+          "v3d_softmax_grad_rows")
+    return out

@@ -8,7 +8,13 @@ Qwen2MLP (llava/model/language_model/qwen2/modeling_qwen2.py:76-90, 177-189, 771
 so the backward costs two more products of the forward's size and three transposes.  Weights are in the checkpoint's layout
 (gate_proj / up_proj stacked as planar [gate | up] rows), not the inference engine's tile-interleaved one: the training forward has
 to keep gate and up for the backward, so SwiGLU is a pass of its own here (v3d_swiglu) instead of the GEMM epilogue.
-Not here yet: attention backward, the SigLIP tower's backward, the optimizer."""
+Attention backward is in its FIRST form: one head's probability matrix is materialised (the reference's eager attention,
+modeling_qwen2.py:248-327, rounds there too) so that its five products also run on v3d_gemm; a tiled kernel that never writes the
+[S, S] matrices is the next step.  Not here yet: the SigLIP tower's backward, the optimizer."""
+import math
+
+import torch
+
 from . import ops
 
 
@@ -53,3 +59,102 @@ def mlp_block_backward(dout, saved, ln_w, w_gate_up, w_down, eps=1e-6):
     dn, dw_gu, _ = linear_backward(n, w_gate_up, dgu)
     dh, dln = ops.rmsnorm_grad(h, ln_w, dn, eps, add=dout)            # + the residual branch's gradient
     return dh, {"ln": dln, "gate_up": dw_gu, "down": dw_down}
+
+
+# ------------------------------------------------------------------------------ attention block
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def attention_backward(qkv, do, dqkv, S, n_q, n_kv, hd, scale):
+    """Causal GQA attention backward over one sequence.  qkv [>= pad128(S), (n_q + 2 n_kv) hd]: rotated q | rotated k | v, rows
+    >= S zero (the keys' padding); do [S, n_q hd]; writes dq | dk | dv (gradients of the ROTATED q / k) into dqkv [S, same width].
+    Per kv head: for each of its query heads  s = q k^T, p = softmax(causal, s scale), dp = do v^T, ds = p (dp - rowsum(p dp)) scale,
+    dq = ds k;  then  dv = [p_h^T ...] [do_h ; ...]  and  dk = [ds_h^T ...] [q_h ; ...]  as ONE product each over the group's heads
+    (one f32 accumulation, the sum autograd takes over repeat_kv's copies, modeling_qwen2.py:236-245)."""
+    Sp, Sq = _pad(S, 128), _pad(S, 64)
+    if qkv.shape[0] < Sp:
+        raise ops.V3DError(f"attention_backward: qkv needs {Sp} rows (keys zero-padded to a multiple of 128)")
+    grp = n_q // n_kv
+    dev, dt = qkv.device, qkv.dtype
+    buf_s = torch.empty((S, Sp), dtype=dt, device=dev)
+    buf_p = torch.empty((S, Sp), dtype=dt, device=dev)
+    pt = torch.empty((Sp, grp * Sq), dtype=dt, device=dev)
+    dst = torch.empty((Sp, grp * Sq), dtype=dt, device=dev)
+    dot = torch.empty((hd, grp * Sq), dtype=dt, device=dev)
+    qt = torch.empty((hd, grp * Sq), dtype=dt, device=dev)
+    for g in range(n_kv):
+        k_g = qkv[:Sp, (n_q + g) * hd:(n_q + g + 1) * hd]
+        v_g = qkv[:Sp, (n_q + n_kv + g) * hd:(n_q + n_kv + g + 1) * hd]
+        kgt = ops.transpose(k_g)                                                  # [hd, Sp]
+        for j in range(grp):
+            h = g * grp + j
+            q_h, do_h = qkv[:S, h * hd:(h + 1) * hd], do[:, h * hd:(h + 1) * hd]
+            ops.gemm(q_h, k_g, out=buf_s)
+            ops.causal_softmax_rows(buf_s, S, scale, out=buf_p)
+            ops.gemm(do_h, v_g, out=buf_s)                                        # dp
+            ops.softmax_grad_rows(buf_p, buf_s, scale, out=buf_s)                 # ds (a row is read whole before it is written)
+            ops.gemm(buf_s, kgt, out=dqkv[:, h * hd:(h + 1) * hd])
+            blk = slice(j * Sq, (j + 1) * Sq)
+            ops.transpose(buf_p, out_cols=Sq, out=pt[:, blk])
+            ops.transpose(buf_s, out_cols=Sq, out=dst[:, blk])
+            ops.transpose(do_h, out_cols=Sq, out=dot[:, blk])
+            ops.transpose(q_h, out_cols=Sq, out=qt[:, blk])
+        ops.gemm(dst[:S], qt, out=dqkv[:, (n_q + g) * hd:(n_q + g + 1) * hd])
+        ops.gemm(pt[:S], dot, out=dqkv[:, (n_q + n_kv + g) * hd:(n_q + n_kv + g + 1) * hd])
+    return dqkv
+
+
+class RopeTables:
+    """The rotary table and its inverse (rotation by -theta: the same kernel on a table built from -inv_freq)."""
+
+    def __init__(self, head_dim, n_pos, base, dtype, device):
+        self.fwd = ops.RopeTable(head_dim, n_pos, base, dtype, device)
+        self.inv = ops.RopeTable(head_dim, n_pos, base, dtype, device, inv_freq=-ops.reference_inv_freq(head_dim, base))
+
+
+def attn_block_forward(h, ln_w, w_qkv, b_qkv, w_o, rope, n_q, n_kv, hd, eps=1e-6):
+    """The first half of Qwen2DecoderLayer.forward (modeling_qwen2.py:771-781): out = h + o_proj(attention(rotary(qkv(norm(h))))).
+    w_qkv [(n_q + 2 n_kv) hd, H] = q_proj | k_proj | v_proj rows."""
+    S = h.shape[0]
+    width = (n_q + 2 * n_kv) * hd
+    n = ops.rmsnorm(h, ln_w, eps)
+    qkv = torch.zeros((_pad(S, 128), width), dtype=h.dtype, device=h.device)      # rows >= S stay zero: the backward's key padding
+    ops.gemm(n, w_qkv, bias=b_qkv, epilogue=ops.EPI_BIAS, out=qkv[:S])
+    ops.rope_apply(qkv[:S], n_q + n_kv, hd, rope.fwd)
+    o = torch.empty((S, n_q * hd), dtype=h.dtype, device=h.device)
+    ops.attention(qkv, qkv[:, n_q * hd:], qkv[:, (n_q + n_kv) * hd:], o, 1, S, S, n_q, n_kv, hd, hd, width, width, width, n_q * hd,
+                  0, 0, 0, hd, hd, hd, True, 0, 1.0 / math.sqrt(hd))
+    out = ops.gemm(o, w_o, res=h, epilogue=ops.EPI_RES)
+    return out, (h, n, qkv, o)
+
+
+def attn_block_backward(dout, saved, ln_w, w_qkv, w_o, rope, n_q, n_kv, hd, eps=1e-6):
+    """Gradients of attn_block_forward: (dh, {"ln", "qkv", "qkv_bias", "o"})."""
+    h, n, qkv, o = saved
+    S = h.shape[0]
+    do, dw_o, _ = linear_backward(o, w_o, dout)
+    dqkv = torch.empty((S, qkv.shape[1]), dtype=h.dtype, device=h.device)
+    attention_backward(qkv, do, dqkv, S, n_q, n_kv, hd, 1.0 / math.sqrt(hd))
+    ops.rope_apply(dqkv, n_q + n_kv, hd, rope.inv)                                # the rotation's transpose
+    dn, dw_qkv, db_qkv = linear_backward(n, w_qkv, dqkv, need_db=True)
+    dh, dln = ops.rmsnorm_grad(h, ln_w, dn, eps, add=dout)
+    return dh, {"ln": dln, "qkv": dw_qkv, "qkv_bias": db_qkv, "o": dw_o}
+
+
+def decoder_layer_forward(h, p, rope, n_q, n_kv, hd, eps=1e-6):
+    """Qwen2DecoderLayer.forward (modeling_qwen2.py:727-801) for one sequence; p: dict of the layer's weights (ln1, qkv, qkv_bias, o,
+    ln2, gate_up, down)."""
+    mid, s1 = attn_block_forward(h, p["ln1"], p["qkv"], p["qkv_bias"], p["o"], rope, n_q, n_kv, hd, eps)
+    out, s2 = mlp_block_forward(mid, p["ln2"], p["gate_up"], p["down"], eps)
+    return out, (s1, s2)
+
+
+def decoder_layer_backward(dout, saved, p, rope, n_q, n_kv, hd, eps=1e-6):
+    s1, s2 = saved
+    dmid, g2 = mlp_block_backward(dout, s2, p["ln2"], p["gate_up"], p["down"], eps)
+    dh, g1 = attn_block_backward(dmid, s1, p["ln1"], p["qkv"], p["o"], rope, n_q, n_kv, hd, eps)
+    return dh, {"ln1": g1["ln"], "qkv": g1["qkv"], "qkv_bias": g1["qkv_bias"], "o": g1["o"], "ln2": g2["ln"], "gate_up": g2["gate_up"],
+                "down": g2["down"]}
