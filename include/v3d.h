@@ -392,6 +392,21 @@ int v3d_causal_softmax_rows(const void* s, int64_t lds, void* p, int64_t ldp, in
 int v3d_softmax_grad_rows(const void* p, int64_t ldp, const void* dp, int64_t ldd, void* ds, int64_t lds, int64_t rows, int cols,
                           float scale, int dtype, void* stream);
 
+/* Attention backward as tiled kernels (the [S, S] matrices never reach HBM): v3d_attention_train is v3d_attention (causal, head
+ * dim 128, outputs bit-identical) that also writes lse [B, Hq, Sq] f32, the row log-sum-exp in the kernel's scaled log2 units;
+ * v3d_attention_backward (one sequence, Sq = Sk = S, heads 128 columns apart inside a token row) recomputes the probabilities
+ * from q, k and lse and writes dq [S, Hq 128], dk, dv [S, Hkv 128] (the sum over a kv group's query heads is taken in f32, in a
+ * fixed order: no atomics).  q / k are the ROTATED projections, o the forward's output, dout its gradient.  workspace:
+ * v3d_attention_backward_workspace_bytes(S, Hq) bytes.  Differentiates modeling_qwen2.py:248-482. */
+int v3d_attention_train(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int Sq, int Sk, int Hq,
+                        int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bso, int hsq,
+                        int hsk, int hso, int q_pos0, float scale, void* stream);
+int64_t v3d_attention_backward_workspace_bytes(int S, int Hq);
+int v3d_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                           void* dk, void* dv, int dtype, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                           int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;

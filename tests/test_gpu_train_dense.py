@@ -180,7 +180,7 @@ def _attention_ref(q, k, v, n_q, n_kv, hd):
     return (torch.softmax(s, -1) @ vh).transpose(0, 1).reshape(S, n_q * hd)
 
 
-@pytest.mark.parametrize("S", [150, 257])
+@pytest.mark.parametrize("S", [150, 257, 700])
 def test_attention_backward_matches_autograd(ops, train, S):
     n_q, n_kv, hd = 4, 2, 128
     g = torch.Generator().manual_seed(S)
@@ -193,9 +193,28 @@ def test_attention_backward_matches_autograd(ops, train, S):
     dev = torch.zeros(Sp, width, dtype=torch.bfloat16, device="cuda")
     dev[:S] = qkv.cuda()
     dqkv = torch.full((S, width), float("nan"), dtype=torch.bfloat16, device="cuda")
-    train.attention_backward(dev, do.cuda(), dqkv, S, n_q, n_kv, hd, hd ** -0.5)
-    for name, sl in (("dq", slice(0, n_q * hd)), ("dk", slice(n_q * hd, (n_q + n_kv) * hd)), ("dv", slice((n_q + n_kv) * hd, width))):
-        _close(dqkv[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name)          # p, dp, ds are 16-bit tensors (2^-9 each)
+    train.attention_backward_materialised(dev, do.cuda(), dqkv, S, n_q, n_kv, hd, hd ** -0.5)
+    parts = (("dq", slice(0, n_q * hd)), ("dk", slice(n_q * hd, (n_q + n_kv) * hd)), ("dv", slice((n_q + n_kv) * hd, width)))
+    for name, sl in parts:
+        _close(dqkv[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name + " (materialised)")          # p, dp, ds are 16-bit tensors (2^-9 each)
+    # the tiled kernels: forward with the row log-sum-exp, then the backward that recomputes the probabilities
+    o = torch.empty(S, n_q * hd, dtype=torch.bfloat16, device="cuda")
+    lse = ops.attention_train(dev, o, S, n_q, n_kv, hd ** -0.5)
+    o_plain = torch.empty_like(o)
+    ops.attention(dev, dev[:, n_q * hd:], dev[:, (n_q + n_kv) * hd:], o_plain, 1, S, S, n_q, n_kv, hd, hd, width, width, width, n_q * hd,
+                  0, 0, 0, hd, hd, hd, True, 0, hd ** -0.5)
+    assert torch.equal(o, o_plain)                                                       # same kernel, one more store
+    s_ref = (qkv[:, :n_q * hd].float().view(S, n_q, hd).transpose(0, 1) @
+             qkv[:, n_q * hd:(n_q + n_kv) * hd].float().view(S, n_kv, hd).transpose(0, 1).repeat_interleave(n_q // n_kv, 0).transpose(1, 2)) * hd ** -0.5
+    lse_ref = torch.logsumexp(s_ref + torch.full((S, S), float("-inf")).triu(1), -1) * 1.4426950408889634
+    assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2                               # scaled log2 units; c q is rounded to 16 bit
+    dq2 = torch.full((S, width), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.attention_backward(dev, o, do.cuda(), lse, dq2, S, n_q, n_kv, hd ** -0.5)
+    for name, sl in parts:
+        _close(dq2[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name + " (tiled)")
+    dq3 = torch.empty_like(dq2)
+    ops.attention_backward(dev, o, do.cuda(), lse, dq3, S, n_q, n_kv, hd ** -0.5)
+    assert torch.equal(dq2, dq3)                                                         # no atomics: run-to-run identical
 
 
 def _layer_ref(h, p, n_q, n_kv, hd, eps):
@@ -229,7 +248,8 @@ def test_decoder_layer_forward_and_backward_match_autograd(train, S, H, I, n_q, 
     dev = {k: v.cuda() for k, v in p.items()}
     out, saved = train.decoder_layer_forward(h.cuda(), dev, rope, n_q, n_kv, hd)
     _close(out, ref_out.detach(), 8e-3, 3e-2, "forward")
-    dh, grads = train.decoder_layer_backward(dout.cuda(), saved, dev, rope, n_q, n_kv, hd)
-    _close(dh, hr.grad, 1.5e-2, 4e-2, "dh")
-    for k in p:
-        _close(grads[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)
+    for materialised in (False, True):           # attention backward as tiled kernels (default) and in its materialised first form
+        dh, grads = train.decoder_layer_backward(dout.cuda(), saved, dev, rope, n_q, n_kv, hd, materialised=materialised)
+        _close(dh, hr.grad, 1.5e-2, 4e-2, "dh")
+        for k in p:
+            _close(grads[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)

@@ -77,6 +77,7 @@ struct AttnArgs {
   int d_out;                         // valid head dim written to o (<= D)
   int q_pos0;                        // causal: query i sits at key position q_pos0 + i
   float scale_log2;                  // softmax scale * log2(e)
+  float* lse;                        // training only (v3d_attention_train): [B, Hq, Sq] row log-sum-exp in scaled log2 units, or null
 };
 
 #ifdef V3D_ATTN_PROF   // tools/probes/attn_prof.hip only: per-wave cycle split of the tile loop (never in the product build)
@@ -108,7 +109,7 @@ constexpr float AT_RAISE = 8.0f;
 
 // KSV: k-steps of QK^T that can be non-zero (head dims >= d_out are zeroed in Q): SigLIP's 72-wide heads on the 96-wide tile
 // need 5 of the 6 (the sixth multiplies zeros)
-template <typename T, int D, bool CAUSAL, int KSV = D / 16>
+template <typename T, int D, bool CAUSAL, int KSV = D / 16, bool LSE = false>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // 1 KiB: fragment addresses are formed by XOR
   using M = Mfma32<T>;
@@ -446,6 +447,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   // ---- normalise, transpose through LDS, store whole rows ----
   float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+  if constexpr (LSE) {      // what the backward needs to recompute the probabilities: p = exp2(c q.k - lse)
+    if (h == 0 && qi < p.Sq) p.lse[((int64_t)b * p.Hq + head) * p.Sq + qi] = l_tot > 0.f ? m_run + __log2f(l_tot) : -INFINITY;
+  }
   constexpr int OROW = D * 2 + 16;
   char* so = smem + wave * 32 * OROW;
 #pragma unroll
@@ -1537,7 +1541,7 @@ static int attn64_mode() {
 
 template <typename T>
 static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t st) {
-  if (D == 128 && p.Sq >= 64 && attn64_mode() != 0) {
+  if (D == 128 && p.Sq >= 64 && attn64_mode() != 0 && !p.lse) {
     const dim3 grid64(p.Hq, (p.Sq + A2_BQ - 1) / A2_BQ, B);
 #define V3D_ATTN64(CC)                                                                                            \
     {                                                                                                             \
@@ -1555,9 +1559,9 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
     return check_launch("v3d_attention (64 queries per wave)");
   }
   const dim3 grid(p.Hq, (p.Sq + AT_BQ - 1) / AT_BQ, B), block(256);
-#define V3D_ATTN(DD, CC, KK)                                                                                      \
+#define V3D_ATTN(DD, CC, KK, LL)                                                                                    \
   {                                                                                                               \
-    auto k = attn_prefill_kernel<T, DD, CC, KK>;                                                                  \
+    auto k = attn_prefill_kernel<T, DD, CC, KK, LL>;                                                              \
     static bool done = false;                                                                                     \
     if (!done) {                                                                                                  \
       hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);     \
@@ -1566,11 +1570,13 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
     }                                                                                                             \
     hipLaunchKernelGGL(k, grid, block, AT_LDS, st, p);                                                            \
   }
-  if (D == 128 && causal) V3D_ATTN(128, true, 8)
-  else if (D == 128) V3D_ATTN(128, false, 8)
-  else if (D == 96 && causal) V3D_ATTN(96, true, 6)
-  else if (D == 96 && p.d_out <= 80 && !getenv("V3D_ATTN_KS6")) V3D_ATTN(96, false, 5)       // SigLIP: 72-wide heads (V3D_ATTN_KS6: A/B against the 6-step form)
-  else if (D == 96) V3D_ATTN(96, false, 6)
+  if (p.lse && !(D == 128 && causal)) { set_error("v3d_attention_train: causal attention with head dim 128 only"); return V3D_E_UNSUPPORTED; }
+  if (D == 128 && causal && p.lse) V3D_ATTN(128, true, 8, true)
+  else if (D == 128 && causal) V3D_ATTN(128, true, 8, false)
+  else if (D == 128) V3D_ATTN(128, false, 8, false)
+  else if (D == 96 && causal) V3D_ATTN(96, true, 6, false)
+  else if (D == 96 && p.d_out <= 80 && !getenv("V3D_ATTN_KS6")) V3D_ATTN(96, false, 5, false)       // SigLIP: 72-wide heads (V3D_ATTN_KS6: A/B against the 6-step form)
+  else if (D == 96) V3D_ATTN(96, false, 6, false)
   else { set_error("v3d_attention: head dim %d unsupported (128 or 96)", D); return V3D_E_UNSUPPORTED; }
 #undef V3D_ATTN
   return check_launch("v3d_attention");
@@ -1580,10 +1586,10 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
 
 using namespace v3d;
 
-extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int Sq, int Sk,
-                             int Hq, int Hkv, int D, int d_out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                             int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0,
-                             float scale, void* stream) {
+static int attention_entry(const void* q, const void* k, const void* v, void* o, int dtype, int B, int Sq, int Sk,
+                           int Hq, int Hkv, int D, int d_out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                           int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0,
+                           float scale, void* stream, float* lse) {
   V3D_REQUIRE(q && k && v && o, "v3d_attention: null pointer");
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_attention: dtype must be f16 or bf16");
   V3D_REQUIRE(B > 0 && Sq > 0 && Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "v3d_attention: bad shape");
@@ -1599,8 +1605,9 @@ extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* 
   p.hsq = hsq; p.hsk = hsk; p.hso = hso; p.Sq = Sq; p.Sk = Sk; p.Hq = Hq; p.group = Hq / Hkv;
   p.d_out = d_out; p.q_pos0 = causal ? q_pos0 : 0;
   p.scale_log2 = scale * 1.44269504088896340736f;
+  p.lse = lse;
   hipStream_t st = (hipStream_t)stream;
-  if (Sq <= 8 && B == 1 && D == 128 && causal) {   // decode: stream the cache
+  if (Sq <= 8 && B == 1 && D == 128 && causal && !p.lse) {   // decode: stream the cache
     if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(Sq, Hq), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_decode_kernel<f16_t, 128>), dim3(Sq, Hq), dim3(256), 0, st, p);
     return check_launch("v3d_attention (decode)");
@@ -1608,6 +1615,23 @@ extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* 
   return dtype == V3D_BF16 ? launch_attn<bf16_t>(p, D, causal, B, st) : launch_attn<f16_t>(p, D, causal, B, st);
 }
 
+extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* o, int dtype, int B, int Sq, int Sk,
+                             int Hq, int Hkv, int D, int d_out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                             int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0,
+                             float scale, void* stream) {
+  return attention_entry(q, k, v, o, dtype, B, Sq, Sk, Hq, Hkv, D, d_out, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, causal, q_pos0,
+                         scale, stream, nullptr);
+}
+
+// The training forward: v3d_attention (causal, head dim 128) that also writes the row log-sum-exp the backward recomputes the
+// probabilities from (same kernel with one more store after the tile loop; outputs bit-identical to v3d_attention's).
+extern "C" int v3d_attention_train(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int Sq, int Sk,
+                                   int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
+                                   int64_t bso, int hsq, int hsk, int hso, int q_pos0, float scale, void* stream) {
+  V3D_REQUIRE(lse, "v3d_attention_train: null lse");
+  return attention_entry(q, k, v, o, dtype, B, Sq, Sk, Hq, Hkv, 128, 128, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, 1, q_pos0, scale,
+                         stream, lse);
+}
 
 extern "C" int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits) {
   return (int64_t)max_splits * Hq * (128 + 2) * (int64_t)sizeof(float);

@@ -766,3 +766,27 @@ def softmax_grad_rows(p, dp, scale, out=None):
     check(lib().v3d_softmax_grad_rows(_p(p), p.stride(0), _p(dp), dp.stride(0), _p(out), out.stride(0), rows, cols, float(scale), _code(p), _stream()),
           "v3d_softmax_grad_rows")
     return out
+
+
+def attention_train(qkv, out, S, n_q, n_kv, scale):
+    """Causal GQA attention (head dim 128) over one sequence whose rotated q | k | v sit side by side in qkv [>= S, (n_q + 2 n_kv) 128];
+    out [S, n_q 128].  Returns the row log-sum-exp [n_q, S] f32 (scaled log2 units) that attention_backward needs."""
+    qkv = _dev(qkv, "qkv")
+    w = qkv.stride(0)
+    lse = torch.empty((n_q, S), dtype=torch.float32, device=qkv.device)
+    check(lib().v3d_attention_train(_p(qkv), _p(qkv[:, n_q * 128:]), _p(qkv[:, (n_q + n_kv) * 128:]), _p(out), _p(lse), _code(qkv), 1, S, S,
+                                    n_q, n_kv, w, w, w, out.stride(0), 0, 0, 0, 128, 128, 128, 0, float(scale), _stream()), "v3d_attention_train")
+    return lse
+
+
+def attention_backward(qkv, out, dout, lse, dqkv, S, n_q, n_kv, scale):
+    """Gradients of attention_train with respect to the rotated q | k | v, written side by side into dqkv [S, (n_q + 2 n_kv) 128]."""
+    qkv, dout = _dev(qkv, "qkv"), _dev(dout, "dout")
+    w, dw = qkv.stride(0), dqkv.stride(0)
+    nbytes = lib().v3d_attention_backward_workspace_bytes(S, n_q)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
+    check(lib().v3d_attention_backward(_p(qkv), _p(qkv[:, n_q * 128:]), _p(qkv[:, (n_q + n_kv) * 128:]), _p(out), _p(dout), _p(lse),
+                                       _p(dqkv), _p(dqkv[:, n_q * 128:]), _p(dqkv[:, (n_q + n_kv) * 128:]), _code(qkv), S, n_q, n_kv,
+                                       w, w, w, out.stride(0), dout.stride(0), dw, dw, dw, float(scale), _p(ws), nbytes, _stream()),
+          "v3d_attention_backward")
+    return dqkv

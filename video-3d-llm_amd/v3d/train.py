@@ -8,9 +8,10 @@ Qwen2MLP (llava/model/language_model/qwen2/modeling_qwen2.py:76-90, 177-189, 771
 so the backward costs two more products of the forward's size and three transposes.  Weights are in the checkpoint's layout
 (gate_proj / up_proj stacked as planar [gate | up] rows), not the inference engine's tile-interleaved one: the training forward has
 to keep gate and up for the backward, so SwiGLU is a pass of its own here (v3d_swiglu) instead of the GEMM epilogue.
-Attention backward is in its FIRST form: one head's probability matrix is materialised (the reference's eager attention,
-modeling_qwen2.py:248-327, rounds there too) so that its five products also run on v3d_gemm; a tiled kernel that never writes the
-[S, S] matrices is the next step.  Not here yet: the SigLIP tower's backward, the optimizer."""
+Attention backward exists in two forms: tiled kernels that recompute the probabilities from the forward's row log-sum-exp and never
+write an [S, S] matrix (v3d_attention_backward, csrc/attention_bwd.hip - the default), and the first, MATERIALISED form below
+(one head's probability matrix in HBM with the rounding points of the reference's eager attention, modeling_qwen2.py:248-327, all five
+products on v3d_gemm), kept as an independent cross-check.  Not here yet: the SigLIP tower's backward, the optimizer."""
 import math
 
 import torch
@@ -68,7 +69,7 @@ def _pad(n, m):
     return (n + m - 1) // m * m
 
 
-def attention_backward(qkv, do, dqkv, S, n_q, n_kv, hd, scale):
+def attention_backward_materialised(qkv, do, dqkv, S, n_q, n_kv, hd, scale):
     """Causal GQA attention backward over one sequence.  qkv [>= pad128(S), (n_q + 2 n_kv) hd]: rotated q | rotated k | v, rows
     >= S zero (the keys' padding); do [S, n_q hd]; writes dq | dk | dv (gradients of the ROTATED q / k) into dqkv [S, same width].
     Per kv head: for each of its query heads  s = q k^T, p = softmax(causal, s scale), dp = do v^T, ds = p (dp - rowsum(p dp)) scale,
@@ -76,7 +77,7 @@ def attention_backward(qkv, do, dqkv, S, n_q, n_kv, hd, scale):
     (one f32 accumulation, the sum autograd takes over repeat_kv's copies, modeling_qwen2.py:236-245)."""
     Sp, Sq = _pad(S, 128), _pad(S, 64)
     if qkv.shape[0] < Sp:
-        raise ops.V3DError(f"attention_backward: qkv needs {Sp} rows (keys zero-padded to a multiple of 128)")
+        raise ops.V3DError(f"attention_backward_materialised: qkv needs {Sp} rows (keys zero-padded to a multiple of 128)")
     grp = n_q // n_kv
     dev, dt = qkv.device, qkv.dtype
     buf_s = torch.empty((S, Sp), dtype=dt, device=dev)
@@ -125,19 +126,21 @@ def attn_block_forward(h, ln_w, w_qkv, b_qkv, w_o, rope, n_q, n_kv, hd, eps=1e-6
     ops.gemm(n, w_qkv, bias=b_qkv, epilogue=ops.EPI_BIAS, out=qkv[:S])
     ops.rope_apply(qkv[:S], n_q + n_kv, hd, rope.fwd)
     o = torch.empty((S, n_q * hd), dtype=h.dtype, device=h.device)
-    ops.attention(qkv, qkv[:, n_q * hd:], qkv[:, (n_q + n_kv) * hd:], o, 1, S, S, n_q, n_kv, hd, hd, width, width, width, n_q * hd,
-                  0, 0, 0, hd, hd, hd, True, 0, 1.0 / math.sqrt(hd))
+    lse = ops.attention_train(qkv, o, S, n_q, n_kv, 1.0 / math.sqrt(hd))
     out = ops.gemm(o, w_o, res=h, epilogue=ops.EPI_RES)
-    return out, (h, n, qkv, o)
+    return out, (h, n, qkv, o, lse)
 
 
-def attn_block_backward(dout, saved, ln_w, w_qkv, w_o, rope, n_q, n_kv, hd, eps=1e-6):
+def attn_block_backward(dout, saved, ln_w, w_qkv, w_o, rope, n_q, n_kv, hd, eps=1e-6, materialised=False):
     """Gradients of attn_block_forward: (dh, {"ln", "qkv", "qkv_bias", "o"})."""
-    h, n, qkv, o = saved
+    h, n, qkv, o, lse = saved
     S = h.shape[0]
     do, dw_o, _ = linear_backward(o, w_o, dout)
     dqkv = torch.empty((S, qkv.shape[1]), dtype=h.dtype, device=h.device)
-    attention_backward(qkv, do, dqkv, S, n_q, n_kv, hd, 1.0 / math.sqrt(hd))
+    if materialised:
+        attention_backward_materialised(qkv, do, dqkv, S, n_q, n_kv, hd, 1.0 / math.sqrt(hd))
+    else:
+        ops.attention_backward(qkv, o, do, lse, dqkv, S, n_q, n_kv, 1.0 / math.sqrt(hd))
     ops.rope_apply(dqkv, n_q + n_kv, hd, rope.inv)                                # the rotation's transpose
     dn, dw_qkv, db_qkv = linear_backward(n, w_qkv, dqkv, need_db=True)
     dh, dln = ops.rmsnorm_grad(h, ln_w, dn, eps, add=dout)
@@ -152,9 +155,9 @@ def decoder_layer_forward(h, p, rope, n_q, n_kv, hd, eps=1e-6):
     return out, (s1, s2)
 
 
-def decoder_layer_backward(dout, saved, p, rope, n_q, n_kv, hd, eps=1e-6):
+def decoder_layer_backward(dout, saved, p, rope, n_q, n_kv, hd, eps=1e-6, materialised=False):
     s1, s2 = saved
     dmid, g2 = mlp_block_backward(dout, s2, p["ln2"], p["gate_up"], p["down"], eps)
-    dh, g1 = attn_block_backward(dmid, s1, p["ln1"], p["qkv"], p["o"], rope, n_q, n_kv, hd, eps)
+    dh, g1 = attn_block_backward(dmid, s1, p["ln1"], p["qkv"], p["o"], rope, n_q, n_kv, hd, eps, materialised)
     return dh, {"ln1": g1["ln"], "qkv": g1["qkv"], "qkv_bias": g1["qkv_bias"], "o": g1["o"], "ln2": g2["ln"], "gate_up": g2["gate_up"],
                 "down": g2["down"]}
