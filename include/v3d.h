@@ -407,6 +407,17 @@ int v3d_attention_backward(const void* q, const void* k, const void* v, const vo
                            int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
+/* One AdamW update of a flat parameter tensor (torch.optim.AdamW's single-tensor form = the reference's HF Trainer optimizer; ZeRO
+ * runs the same update on its f32 master partition): p32 / m / v [n] f32 in place, grad [n] in grad_dtype (f32 / f16 / bf16) times
+ * grad_scale, p16 (may be null) the 16-bit copy the next forward reads.  step counts from 1 (bias correction). */
+int v3d_adamw_step(float* p32, float* m, float* v, const void* grad, int grad_dtype, void* p16, int p16_dtype, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* Gradient of the embedding lookup for the text rows of a sample (llava_arch.py:650-700 embeds them with embed_tokens):
+ * dE[ids[i], :] = sum over the j with ids[j] == ids[i], in order, of dh[rows[j], :] (f32 sums, one rounding); rows / ids: device
+ * int64 [n].  Rows of dE that no id names are not touched (the caller zero-fills). */
+int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde, int dtype,
+                   void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;

@@ -253,3 +253,75 @@ def test_decoder_layer_forward_and_backward_match_autograd(train, S, H, I, n_q, 
         _close(dh, hr.grad, 1.5e-2, 4e-2, "dh")
         for k in p:
             _close(grads[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)
+
+
+# ------------------------------------------------------------------------------ optimizer, embedding gradient, the language model's step
+
+
+def test_adamw_step_matches_torch_adamw(ops):
+    g = torch.Generator().manual_seed(11)
+    n = 5000
+    p0 = torch.randn(n, generator=g)
+    ref_p = p0.clone().requires_grad_()
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    p32, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g).to(torch.bfloat16)
+        ref_p.grad = grad.float() * 0.5
+        opt.step()
+        ops.adamw_step(p32, m, v, grad.cuda(), p16=p16, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05, step=step, grad_scale=0.5)
+        assert torch.allclose(p32.cpu(), ref_p.detach(), rtol=2e-6, atol=2e-7), step          # f32 arithmetic in the same order
+        assert torch.equal(p16, p32.to(torch.bfloat16))
+    assert torch.allclose(m.cpu(), opt.state[ref_p]["exp_avg"], rtol=2e-6, atol=1e-7)
+    assert torch.allclose(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=2e-6, atol=1e-9)
+
+
+def test_embed_grad_sums_repeated_tokens(ops):
+    g = torch.Generator().manual_seed(5)
+    S, H, V = 40, 264, 50
+    dh = torch.randn(S, H, generator=g).to(torch.bfloat16)
+    rows = torch.tensor([0, 1, 2, 30, 31, 32, 33, 39])
+    ids = torch.tensor([7, 3, 7, 7, 49, 0, 3, 12])
+    ref = torch.zeros(V, H).index_add_(0, ids, dh[rows].float()).to(torch.bfloat16)
+    dE = torch.zeros(V, H, dtype=torch.bfloat16, device="cuda")
+    ops.embed_grad(dh.cuda(), rows.cuda(), ids.cuda(), dE)
+    assert torch.equal(dE.cpu(), ref)                      # f32 sums of at most three 16-bit rows, one rounding: exact against index_add_
+
+
+def test_llm_step_loss_and_gradients_match_autograd(ops, train):
+    """Qwen2ForCausalLM.forward with labels + backward (modeling_qwen2.py:1145-1217) on a 2-layer model, then one AdamW update."""
+    H, I, n_q, n_kv, hd, V, S, L = 512, 1024, 4, 2, 128, 1024, 200, 2
+    g = torch.Generator().manual_seed(21)
+    width = (n_q + 2 * n_kv) * hd
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
+    ln = lambda: (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16)
+    layers = [{"ln1": ln(), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.3), "o": mk(H, n_q * hd, s=(n_q * hd) ** -0.5),
+               "ln2": ln(), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    params = {"layers": layers, "norm": ln(), "lm_head": mk(V, H, s=H ** -0.5)}
+    x = mk(S, H)
+    labels = torch.full((S,), -100, dtype=torch.int64)
+    labels[150:] = torch.randint(0, V, (50,), generator=g)
+    ref = train._tree_map(lambda t: t.float().requires_grad_(), params)
+    xr = x.float().requires_grad_()
+    h = xr
+    for p in ref["layers"]:
+        h = _layer_ref(h, p, n_q, n_kv, hd, 1e-6)
+    logits = _rmsnorm_ref(h, ref["norm"], 1e-6) @ ref["lm_head"].t()
+    ref_loss = F.cross_entropy(logits[:-1], labels[1:], ignore_index=-100)       # modeling_qwen2.py:1195-1205
+    ref_loss.backward()
+    rope = train.RopeTables(hd, 512, 1e6, torch.bfloat16, "cuda")
+    dev = train._tree_map(lambda t: t.cuda(), params)
+    loss, dx, grads = train.llm_forward_backward(dev, x.cuda(), labels.cuda(), rope, n_q, n_kv, hd)
+    assert abs(float(loss) - float(ref_loss.detach())) < 2e-2 * float(ref_loss.detach())
+    _close(dx, xr.grad, 2.5e-2, 6e-2, "d inputs_embeds")
+    _close(grads["norm"], ref["norm"].grad, 2.5e-2, 6e-2, "d norm")
+    _close(grads["lm_head"], ref["lm_head"].grad, 2.5e-2, 6e-2, "d lm_head")
+    for i in range(L):
+        for k in layers[i]:
+            _close(grads["layers"][i][k], ref["layers"][i][k].grad, 2.5e-2, 6e-2, f"layer {i} d {k}")
+    opt = train.AdamW(dev, lr=1e-3)
+    before = dev["layers"][0]["down"].clone()
+    opt.step(dev, grads)
+    moved = (dev["layers"][0]["down"].float() - before.float()).abs()
+    assert float(moved.max()) > 0 and float(moved.max()) < 4e-3           # |update| <= lr on the first step (+ one 16-bit rounding)

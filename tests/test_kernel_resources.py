@@ -35,8 +35,8 @@ def _report(src, extra=()):
 def reports():
     if not shutil.which(HIPCC):
         pytest.skip("hipcc not available")
-    jobs = {"gemm.hip": (), "gemm_fp8.hip": (), "attention.hip": ("-fno-slp-vectorize",), "decode.hip": ()}
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    jobs = {"gemm.hip": (), "gemm_fp8.hip": (), "attention.hip": ("-fno-slp-vectorize",), "decode.hip": (), "attention_bwd.hip": ()}
+    with ThreadPoolExecutor(max_workers=5) as ex:
         futs = {k: ex.submit(_report, k, v) for k, v in jobs.items()}
         return {k: f.result() for k, f in futs.items()}
 
@@ -52,6 +52,10 @@ def test_gemm_kernels_without_the_split_k_exchange_do_not_spill(reports):
 
 def test_attention_and_decode_kernels_do_not_spill_in_their_loops(reports):
     att = reports["attention.hip"]
+    train_fwd = {k: v for k, v in att.items() if "attn_prefill_kernel" in k and k.endswith("ELb1EEEvNS_8AttnArgsE")}      # LSE = true: v3d_attention_train
+    assert len(train_fwd) == 2 and all(v <= 4 for v in train_fwd.values()), train_fwd       # + the running maximum kept for the log-sum-exp
+    att = {k: v for k, v in att.items() if k not in train_fwd}
     assert all(v <= 2 for v in att.values()), {k: v for k, v in att.items() if v > 2}       # two scalars outside the tile loop (prefill, D = 128)
+    assert all(v == 0 for v in reports["attention_bwd.hip"].values()), reports["attention_bwd.hip"]
     assert all(v == 0 for k, v in att.items() if "attn_prefill64_kernel" in k)
     assert all(v == 0 for v in reports["decode.hip"].values()), reports["decode.hip"]

@@ -441,6 +441,43 @@ __global__ __launch_bounds__(256) void softmax_grad_rows_kernel(const T* __restr
   }
 }
 
+
+// torch.optim.AdamW's single-tensor update (the optimizer of the reference's HF Trainer; DeepSpeed's FusedAdam in adam_w_mode computes the
+// same thing on the f32 master partition of ZeRO): decoupled weight decay, bias-corrected moments, all in f32, and the 16-bit copy
+// of the parameter the next forward reads.
+template <typename TG, typename TP>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p32, float* __restrict__ m, float* __restrict__ v, const TG* __restrict__ g,
+                                                    TP* __restrict__ p16, int64_t n, float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float grad_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gr = to_f32(g[i]) * grad_scale;
+    float p = p32[i] * (1.0f - lr * wd);
+    const float mi = m[i] + (gr - m[i]) * (1.0f - beta1);            // lerp, as torch: exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gr * gr;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p = p - (lr / bc1) * (mi / denom);
+    m[i] = mi; v[i] = vi; p32[i] = p;
+    if (p16) p16[i] = from_f32<TP>(p);
+  }
+}
+
+// Gradient of the token-embedding lookup: dE[ids[i], :] = T(sum over the j with ids[j] == ids[i], in order, of dh[rows[j], :]); one
+// workgroup per listed row, only the first occurrence of an id writes (n is the handful of text tokens of a sample).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_grad_kernel(const T* __restrict__ dh, int64_t ld, const int64_t* __restrict__ rows, const int64_t* __restrict__ ids,
+                                                         int n, int H, T* __restrict__ dE, int64_t lde) {
+  const int i = blockIdx.x;
+  const int64_t id = ids[i];
+  for (int j = 0; j < i; ++j)
+    if (ids[j] == id) return;                                        // an earlier workgroup owns this id (uniform branch)
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float s = 0.f;
+    for (int j = i; j < n; ++j)
+      if (ids[j] == id) s += to_f32(dh[rows[j] * ld + c]);
+    dE[id * lde + c] = from_f32<T>(s);
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -601,4 +638,35 @@ extern "C" int v3d_softmax_grad_rows(const void* p, int64_t ldp, const void* dp,
   V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(softmax_grad_rows_kernel<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const T*)p, ldp,
                                               (const T*)dp, ldd, (T*)ds, lds, cols, scale));
   return check_launch("v3d_softmax_grad_rows");
+}
+
+extern "C" int v3d_adamw_step(float* p32, float* m, float* v, const void* grad, int grad_dtype, void* p16, int p16_dtype, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  V3D_REQUIRE(p32 && m && v && grad, "v3d_adamw_step: null pointer");
+  V3D_REQUIRE(n > 0 && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "v3d_adamw_step: bad arguments");
+  V3D_REQUIRE(!p16 || p16_dtype == V3D_F16 || p16_dtype == V3D_BF16, "v3d_adamw_step: the parameter copy is f16 or bf16");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+#define V3D_ADAMW(TG, TP) hipLaunchKernelGGL((adamw_kernel<TG, TP>), dim3((unsigned)blocks), dim3(256), 0, st, p32, m, v, (const TG*)grad, (TP*)p16, n, lr, \
+                                             beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale)
+#define V3D_ADAMW_G(TG) { if (p16_dtype == V3D_F16 && p16) { V3D_ADAMW(TG, f16_t); } else { V3D_ADAMW(TG, bf16_t); } }
+  switch (grad_dtype) {
+    case V3D_F32: V3D_ADAMW_G(float) break;
+    case V3D_F16: V3D_ADAMW_G(f16_t) break;
+    case V3D_BF16: V3D_ADAMW_G(bf16_t) break;
+    default: set_error("v3d_adamw_step: unknown gradient dtype %d", grad_dtype); return V3D_E_INVALID;
+  }
+#undef V3D_ADAMW_G
+#undef V3D_ADAMW
+  return check_launch("v3d_adamw_step");
+}
+
+extern "C" int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde, int dtype,
+                              void* stream) {
+  V3D_REQUIRE(dh && rows && ids && dE, "v3d_embed_grad: null pointer");
+  V3D_REQUIRE(n > 0 && n <= 65535 && H > 0 && ld >= H && lde >= H, "v3d_embed_grad: bad shape");
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(embed_grad_kernel<T>, dim3(n), dim3(256), 0, (hipStream_t)stream, (const T*)dh, ld, rows, ids, n, H, (T*)dE, lde));
+  return check_launch("v3d_embed_grad");
 }

@@ -790,3 +790,29 @@ def attention_backward(qkv, out, dout, lse, dqkv, S, n_q, n_kv, scale):
                                        w, w, w, out.stride(0), dout.stride(0), dw, dw, dw, float(scale), _p(ws), nbytes, _stream()),
           "v3d_attention_backward")
     return dqkv
+
+
+def adamw_step(p32, m, v, grad, p16=None, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step=1, grad_scale=1.0):
+    """torch.optim.AdamW's update on flat f32 state (in place) from a gradient of any float dtype; p16: the 16-bit parameter copy."""
+    n = p32.numel()
+    if m.numel() != n or v.numel() != n or grad.numel() != n or (p16 is not None and p16.numel() != n):
+        raise V3DError("adamw_step: p32 / m / v / grad / p16 must have the same number of elements")
+    for t, name in ((p32, "p32"), (m, "m"), (v, "v")):
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise V3DError(f"adamw_step: {name} must be a contiguous f32 tensor in HBM")
+    g = _dev(grad, "grad")
+    if not g.is_contiguous() or (p16 is not None and not p16.is_contiguous()):
+        raise V3DError("adamw_step: grad / p16 must be contiguous")
+    check(lib().v3d_adamw_step(_p(p32), _p(m), _p(v), _p(g), _DT[g.dtype], _p(p16), _DT[p16.dtype] if p16 is not None else 0, n, float(lr),
+                               float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream()),
+          "v3d_adamw_step")
+
+
+def embed_grad(dh, rows, ids, dE):
+    """dE[ids[i]] = sum of dh[rows[j]] over the j with the same id (text rows of a sample); dE [vocab, H] pre-zeroed by the caller."""
+    dh = _dev(dh, "dh")
+    if rows.dtype != torch.int64 or ids.dtype != torch.int64 or rows.numel() != ids.numel() or not rows.is_cuda or not ids.is_cuda:
+        raise V3DError("embed_grad: rows / ids must be device int64 tensors of one length")
+    check(lib().v3d_embed_grad(_p(dh), dh.stride(0), _p(rows), _p(ids), rows.numel(), dh.shape[1], _p(dE), dE.stride(0), _code(dh), _stream()),
+          "v3d_embed_grad")
+    return dE

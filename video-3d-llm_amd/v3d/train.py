@@ -161,3 +161,63 @@ def decoder_layer_backward(dout, saved, p, rope, n_q, n_kv, hd, eps=1e-6, materi
     dh, g1 = attn_block_backward(dmid, s1, p["ln1"], p["qkv"], p["o"], rope, n_q, n_kv, hd, eps, materialised)
     return dh, {"ln1": g1["ln"], "qkv": g1["qkv"], "qkv_bias": g1["qkv_bias"], "o": g1["o"], "ln2": g2["ln"], "gate_up": g2["gate_up"],
                 "down": g2["down"]}
+
+
+# ------------------------------------------------------------------------------ the language model's step
+
+
+def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6):
+    """Qwen2ForCausalLM.forward with labels (modeling_qwen2.py:1145-1217: decoder layers, final norm, LM head, shifted cross-entropy)
+    and its backward for one sequence given as inputs_embeds x [S, H] (what prepare_inputs_labels_for_multimodal hands the LLM,
+    llava_qwen.py:121-170).  params: {"layers": [layer dicts of decoder_layer_forward], "norm": [H], "lm_head": [V, H]}; labels [S]
+    int64 on the device (-100 = ignored).  Returns (loss (f32 scalar tensor), dx [S, H], grads in params' structure).  All layers'
+    activations are kept (about 1 GB per 7B layer at S = 6.8 k: 28 GB of the 288), where the reference re-computes them under
+    gradient checkpointing (train_multi.sh:72) - same numbers, less work."""
+    saved, h = [], x
+    for p in params["layers"]:
+        h, s = decoder_layer_forward(h, p, rope, n_q, n_kv, hd, eps)
+        saved.append(s)
+    n = ops.rmsnorm(h, params["norm"], eps)
+    logits = ops.gemm(n, params["lm_head"])
+    loss, st = ops.cross_entropy(logits, labels)
+    dlogits = ops.cross_entropy_grad(st)
+    dn, dw_head, _ = linear_backward(n, params["lm_head"], dlogits)
+    dh, dnorm = ops.rmsnorm_grad(h, params["norm"], dn, eps)
+    layer_grads = [None] * len(saved)
+    for i in range(len(saved) - 1, -1, -1):
+        dh, layer_grads[i] = decoder_layer_backward(dh, saved[i], params["layers"][i], rope, n_q, n_kv, hd, eps)
+        saved[i] = None                                               # the layer's activations are no longer needed
+    return loss, dh, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
+
+
+class AdamW:
+    """f32 master weights and moments for a dict / list tree of 16-bit parameter tensors; step(grads) updates the tree in place
+    (one v3d_adamw_step per tensor).  Hyper-parameters as train_multi.sh gives them to the HF Trainer (lr 1e-5, weight decay 0)."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.lr, self.betas, self.eps, self.weight_decay, self.t = lr, betas, eps, weight_decay, 0
+        self.state = _tree_map(lambda p: (p.detach().float().contiguous(), torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)), params)
+
+    def step(self, params, grads, grad_scale=1.0):
+        self.t += 1
+        _tree_zip(lambda p, g, st: ops.adamw_step(st[0], st[1], st[2], g.contiguous(), p16=p, lr=self.lr, betas=self.betas, eps=self.eps,
+                                                  weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale), params, grads, self.state)
+
+
+def _tree_map(fn, tree):
+    if isinstance(tree, dict):
+        return {k: _tree_map(fn, v) for k, v in tree.items()}
+    if isinstance(tree, list):
+        return [_tree_map(fn, v) for v in tree]
+    return fn(tree)
+
+
+def _tree_zip(fn, a, b, c):
+    if isinstance(a, dict):
+        for k in a:
+            _tree_zip(fn, a[k], b[k], c[k])
+    elif isinstance(a, list):
+        for x, y, z in zip(a, b, c):
+            _tree_zip(fn, x, y, z)
+    else:
+        fn(a, b, c)
