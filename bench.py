@@ -11,6 +11,7 @@ in HBM before the timed region).  Every scene runs the complete path; scenes are
 (--decode-group, default 16) that share each pass over the weights.
 The default N = 1 line also carries `roofline` (the dominant kernel: the Qwen2 gate/up GEMM, MFMA), `roofline_north_star` (3D-PE +
 fusion kernel, HBM), `roofline_attention`, `fp8_config3` (the same step with e4m3 LLM weights, BASELINE configs[3]),
+`train_config4` (the language model's training step on one GPU: forward with labels + backward + AdamW, v3d/train.py),
 `cached_questions` (scene-level reuse, SURVEY 8 f1: further questions about an already prefilled scene), `ground_config2`
 (the ScanRefer / Multi3DRefer grounding forward at 32 frames / 50 proposals, BASELINE configs[2], one GPU) and `cpu_baseline`.
 
@@ -246,6 +247,53 @@ def measure_grounding(eng, ops, scenes, dev, steps):
     return steps / (time.perf_counter() - t0)
 
 
+def measure_train_step(dev, steps=2, S=TEXT_PRE + FRAMES * 210 + TEXT_POST, answer_tokens=64):
+    """BASELINE configs[4], the language model's part on ONE GPU (no ZeRO exchange): Qwen2-7B forward with labels + backward + AdamW
+    (v3d/train.py) over one sequence of the path's length, random-init bf16 weights, f32 master weights and moments."""
+    from v3d import train
+    L, H, I, n_q, n_kv, hd, V = 28, 3584, 18944, 28, 4, 128, 152064
+    width = (n_q + 2 * n_kv) * hd
+    dt = torch.bfloat16
+
+    def mk(*shape, s=1.0):
+        return torch.empty(*shape, device=dev, dtype=dt).normal_(0.0, s)
+
+    ones = lambda: torch.ones(H, device=dev, dtype=dt)
+    layers = [{"ln1": ones(), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.1), "o": mk(H, n_q * hd, s=H ** -0.5),
+               "ln2": ones(), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    params = {"layers": layers, "norm": ones(), "lm_head": mk(V, H, s=H ** -0.5)}
+    rope = train.RopeTables(hd, 8192, 1e6, dt, dev)
+    opt = train.AdamW(params, lr=1e-5)
+    x = torch.empty(S, H, device=dev, dtype=dt).normal_()
+    labels = torch.full((S,), -100, dtype=torch.int64, device=dev)
+    labels[S - answer_tokens:] = torch.randint(0, V, (answer_tokens,), device=dev)
+    fb, ad, first_loss = [], [], None
+    for i in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, dx, grads = train.llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        opt.step(params, grads)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if first_loss is None:
+            first_loss = float(loss)
+        del grads, dx
+        if i:
+            fb.append(t1 - t0)
+            ad.append(t2 - t1)
+    n_par = sum(p.numel() for l in layers for p in l.values()) + H + V * H
+    ms = (sum(fb) + sum(ad)) / len(fb) * 1e3
+    flops = 6.0 * S * n_par + 3.5 * 2.0 * S * S * hd * n_q * L      # 6 N S for the linears; attention: 2 forward + 5 backward products, causal half
+    return {"what": "BASELINE configs[4], language-model part on one GPU (not the headline; no ZeRO exchange, no vision tower): Qwen2-7B forward "
+                    "with labels + backward + AdamW over one sequence of S=%d (%d answer tokens carry labels), random-init bf16 weights, "
+                    "f32 master weights / moments, all activations kept (no re-computation)" % (S, answer_tokens),
+            "value": S / (ms * 1e-3), "unit": "tokens/s", "ms_per_step": ms, "ms_forward_backward": sum(fb) / len(fb) * 1e3,
+            "ms_adamw": sum(ad) / len(ad) * 1e3, "model_tflops": flops / (ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0,
+            "first_loss": first_loss, "params": n_par, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +305,7 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[3]: e4m3 linears in the Qwen2 prefill; the headline line becomes that run")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements appended to the default N=1 line (fp8, cached questions, grounding)")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip only the configs[3] extra")
+    ap.add_argument("--no-train-extra", action="store_true", help="skip only the configs[4] (language-model training step) extra")
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes resident in HBM, cycled over the steps")
     a = ap.parse_args()
 
@@ -365,6 +414,14 @@ def main():
                 "gate_up_gemm_us": g8, "gate_up_gemm_tflops": 2.0 * (TEXT_PRE + FRAMES * 210 + TEXT_POST) * 37888 * 3584 / g8 / 1e6,
                 "mfma_peak_tflops": 5000.0}
             del eng8
+        if not a.no_train_extra:
+            eng = None
+            torch.cuda.empty_cache()
+            try:
+                extras["train_config4"] = measure_train_step(dev)
+            except Exception as e:                      # an extra must never take the headline line down with it
+                extras["train_config4"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
 
     if rank == 0:
         S = TEXT_PRE + FRAMES * 210 + TEXT_POST
