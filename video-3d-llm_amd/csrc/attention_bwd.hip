@@ -12,7 +12,9 @@
 //       S = Q K^T      P = exp2(c S - L)      dP = dO V^T      dS = P (dP - delta)      dV^T += dO^T P      dK^T += Q^T dS
 //       -> f32 partials per query head; attn_bwd_reduce_kernel sums the heads of a kv group in a fixed order (no atomics).
 // Seven products instead of the minimal five (S and dP are formed in both kernels): that buys a dQ without atomics and a
-// deterministic result.  This is a first, unpipelined form (single LDS buffer, compiler-scheduled reads): correctness first.
+// deterministic result.  The images are double-buffered (the next tile's LDS-DMA flies under the current tile's MFMAs) and every
+// fragment read is an asm statement with its own wait: hipcc puts a vmcnt(0) in front of LDS reads it can see, which would drain the
+// prefetch.  One workgroup per CU (the accumulators of both gradients live in AGPRs); no finer software pipeline yet.
 #include "v3d_common.h"
 
 namespace v3d {
@@ -38,8 +40,9 @@ template <> struct Mfma32<f16_t> {
 
 constexpr int BW_ROW = 256;                 // LDS row bytes (128 x 16 bit)
 constexpr int BW_TILE = 64 * BW_ROW;        // one 64-row image
-constexpr int BW_LDS = 36 * 1024;           // two images + 2 x 64 floats (row statistics of the dK/dV kernel); the dQ kernel's output
-                                            // transpose needs 4 waves x 32 rows x 272 B = 34 KiB
+constexpr int BW_BUF = 2 * BW_TILE;         // one stage: two images
+constexpr int BW_STAT = 2 * BW_BUF;         // 2 x (64 L + 64 delta) floats: row statistics of the dK/dV kernel's query tiles
+constexpr int BW_LDS = BW_STAT + 1024;      // 65 KiB (the dQ kernel's output transpose, 34 KiB, re-uses the stages)
 
 struct BwdArgs {
   const void* q; const void* k; const void* v; const void* o; const void* dout;
@@ -71,10 +74,31 @@ __device__ __forceinline__ void stage_image(const uint16_t* src, unsigned ld_byt
   }
 }
 
-// A-operand fragment of image row (32 half + (lane & 31)), d = 16 ks + 8 (lane >> 5) .. + 8
-__device__ __forceinline__ v4i row_frag(const char* image, int lane, int half, int ks) {
+// A-operand fragments f[ks] of image row (32 half + (lane & 31)), d = 16 ks + 8 (lane >> 5) .. + 8, ks = 0..7: the k-step toggles address
+// bits 5..7 (chunk (2 ks + h) ^ swz = 2 ks ^ (h ^ swz)).  One asm statement with its wait (see the header).
+__device__ __forceinline__ void row_frags(unsigned image_lds, int lane, int half, v4i (&f)[8]) {
   const int r = lane & 31, h = lane >> 5;
-  return *reinterpret_cast<const v4i*>(image + (32 * half + r) * BW_ROW + ((((2 * ks + h) ^ swz(r))) << 4));
+  const unsigned b = image_lds + (32 * half + r) * BW_ROW + ((h ^ swz(r)) << 4);
+  asm volatile(
+      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+      "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+      : "v"(b), "v"(b ^ 32u), "v"(b ^ 64u), "v"(b ^ 96u), "v"(b ^ 128u), "v"(b ^ 160u), "v"(b ^ 192u), "v"(b ^ 224u)
+      : "memory");
+}
+
+// Row statistics of the accumulator registers' rows: x[4 qh + g][j] = stat[32 qh + 8 g + 4 h + j] (register r = 4 g + j of row block qh)
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void stat_frags(unsigned stat_lds, int lane, f32x4 (&x)[8]) {
+  const unsigned b = stat_lds + 16u * (unsigned)(lane >> 5);
+  asm volatile(
+      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
+      "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+      : "v"(b)
+      : "memory");
 }
 
 // A-operand fragments of the image's TRANSPOSE for the 32 columns d = 32 dt ..: f[2 s4 + {0,1}] cover the 16 rows of block s4 in the
@@ -148,31 +172,37 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   const int last_q = q0 + 127 < p.S ? q0 + 127 : p.S - 1;
   const int n_tiles = last_q / 64 + 1;
   const int n_wave = min((q0 + wave * 32 + 31) / 64 + 1, n_tiles);
-  char* img_k = smem;
-  char* img_v = smem + BW_TILE;
-  const unsigned lds_k = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   f32x16 acc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  stage_image(K, (unsigned)p.ldk * 2u, smem, 0, p.S, wave, lane);
+  stage_image(V, (unsigned)p.ldv * 2u, smem + BW_TILE, 0, p.S, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (int t = 0; t < n_tiles; ++t) {
-    stage_image(K, (unsigned)p.ldk * 2u, img_k, t * 64, p.S, wave, lane);
-    stage_image(V, (unsigned)p.ldv * 2u, img_v, t * 64, p.S, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const int buf = t & 1;
+    if (t + 1 < n_tiles) {            // the next tile flies under this tile's MFMAs (its stage was last read two barriers ago)
+      stage_image(K, (unsigned)p.ldk * 2u, smem + (buf ^ 1) * BW_BUF, (t + 1) * 64, p.S, wave, lane);
+      stage_image(V, (unsigned)p.ldv * 2u, smem + (buf ^ 1) * BW_BUF + BW_TILE, (t + 1) * 64, p.S, wave, lane);
+    }
+    const unsigned lds_k = lds0 + buf * BW_BUF, lds_v = lds_k + BW_TILE;
     if (t < n_wave) {
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[kt][r] = -L; dp[kt][r] = 0.f; }
+        v4i fa[8];
+        row_frags(lds_k, lane, kt, fa);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          s[kt] = M::run(row_frag(img_k, lane, kt, ks), qf[ks], s[kt]);
-          dp[kt] = M::run(row_frag(img_v, lane, kt, ks), dof[ks], dp[kt]);
-        }
+        for (int ks = 0; ks < 8; ++ks) s[kt] = M::run(fa[ks], qf[ks], s[kt]);
+        row_frags(lds_v, lane, kt, fa);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) dp[kt] = M::run(fa[ks], dof[ks], dp[kt]);
       }
       const int limit = (qi < p.S - 1 ? qi : p.S - 1) - t * 64 - 4 * h;       // visible iff tile-local key offset <= limit
       v4i pf[4];
@@ -199,7 +229,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
         }
       }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                  // the next tile has landed and is visible; everyone is done with this one
   }
   // dQ = scale * acc, transposed through LDS, whole rows out
   constexpr int OROW = 128 * 2 + 16;
@@ -246,10 +277,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     kf[ks] = *reinterpret_cast<const v4i*>(K + (int64_t)key_ld * p.ldk + ks * 16 + h * 8);
     vf[ks] = *reinterpret_cast<const v4i*>(V + (int64_t)key_ld * p.ldv + ks * 16 + h * 8);
   }
-  char* img_q = smem;
-  char* img_do = smem + BW_TILE;
-  float* stat = reinterpret_cast<float*>(smem + 2 * BW_TILE);       // [0, 64): L, [64, 128): delta of the tile's queries
-  const unsigned lds_q = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* stat = reinterpret_cast<float*>(smem + BW_STAT);           // per stage: [0, 64) L, [64, 128) delta of the tile's queries
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   f32x16 dk[4], dv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -257,28 +286,47 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
   const int n_qt = (p.S + 63) / 64;
   const int wave_first_key = k0 + wave * 32;
-  for (int t = k0 / 64; t < n_qt; ++t) {
-    stage_image(Q, (unsigned)p.ldq * 2u, img_q, t * 64, p.S, wave, lane);
-    stage_image(DO, (unsigned)p.lddo * 2u, img_do, t * 64, p.S, wave, lane);
-    if (tid < 128) {
-      const int qrow = t * 64 + (tid & 63);
-      const float* src = tid < 64 ? p.lse : p.delta;
-      stat[tid] = qrow < p.S ? src[(int64_t)head * p.S + qrow] : 0.f;
-    }
+  const int t0 = k0 / 64;
+  auto stat_load = [&](int t) -> float {                            // threads 0..127: L or delta of one query of tile t
+    const int qrow = t * 64 + (tid & 63);
+    const float* src = tid < 64 ? p.lse : p.delta;
+    return (tid < 128 && qrow < p.S) ? src[(int64_t)head * p.S + qrow] : 0.f;
+  };
+  {
+    const float sv = stat_load(t0);
+    stage_image(Q, (unsigned)p.ldq * 2u, smem + (t0 & 1) * BW_BUF, t0 * 64, p.S, wave, lane);
+    stage_image(DO, (unsigned)p.lddo * 2u, smem + (t0 & 1) * BW_BUF + BW_TILE, t0 * 64, p.S, wave, lane);
+    if (tid < 128) stat[(t0 & 1) * 128 + tid] = sv;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  for (int t = t0; t < n_qt; ++t) {
+    const int buf = t & 1;
+    float sv = 0.f;
+    const bool more = t + 1 < n_qt;
+    if (more) {
+      sv = stat_load(t + 1);                                        // (older than the DMAs below: its wait does not cover them)
+      stage_image(Q, (unsigned)p.ldq * 2u, smem + (buf ^ 1) * BW_BUF, (t + 1) * 64, p.S, wave, lane);
+      stage_image(DO, (unsigned)p.lddo * 2u, smem + (buf ^ 1) * BW_BUF + BW_TILE, (t + 1) * 64, p.S, wave, lane);
+    }
+    const unsigned lds_q = lds0 + buf * BW_BUF, lds_do = lds_q + BW_TILE;
     if (t * 64 + 63 >= wave_first_key) {            // some query of the tile sees some key of this wave
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[qh][r] = 0.f; dp[qh][r] = 0.f; }
+        v4i fa[8];
+        row_frags(lds_q, lane, qh, fa);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          s[qh] = M::run(row_frag(img_q, lane, qh, ks), kf[ks], s[qh]);
-          dp[qh] = M::run(row_frag(img_do, lane, qh, ks), vf[ks], dp[qh]);
-        }
+        for (int ks = 0; ks < 8; ++ks) s[qh] = M::run(fa[ks], kf[ks], s[qh]);
+        row_frags(lds_do, lane, qh, fa);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) dp[qh] = M::run(fa[ks], vf[ks], dp[qh]);
       }
+      f32x4 Lr[8], Dr[8];
+      stat_frags(lds0 + BW_STAT + buf * 512, lane, Lr);
+      stat_frags(lds0 + BW_STAT + buf * 512 + 256, lane, Dr);
       v4i pfp[4], pfs[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -289,9 +337,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
           const int row = (i >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;        // query within the tile
           const int qidx = t * 64 + row;
           const bool vis = key <= qidx && qidx < p.S;
-          const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(s[i >> 1][r], p.scale_log2, -stat[row])) : 0.f;
+          const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(s[i >> 1][r], p.scale_log2, -Lr[4 * (i >> 1) + (r >> 2)][r & 3])) : 0.f;
           ep[j] = pr;
-          es[j] = pr * (dp[i >> 1][r] - stat[64 + row]);
+          es[j] = pr * (dp[i >> 1][r] - Dr[4 * (i >> 1) + (r >> 2)][r & 3]);
         }
         pfp[i] = pack8<T>(ep);
         pfs[i] = pack8<T>(es);
@@ -299,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         v2i f[8];
-        tr_frags(lds_q + BW_TILE, lane, dt, f);        // dO^T
+        tr_frags(lds_do, lane, dt, f);                 // dO^T
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
@@ -313,6 +361,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
         }
       }
     }
+    if (more && tid < 128) stat[(buf ^ 1) * 128 + tid] = sv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (key < p.S) {
