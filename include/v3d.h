@@ -418,6 +418,13 @@ int v3d_adamw_step(float* p32, float* m, float* v, const void* grad, int grad_dt
 int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde, int dtype,
                    void* stream);
 
+/* GELU as a pass of its own for the training forward (which keeps the pre-activation z) and its gradient dz = dy * gelu'(z):
+ * tanh_form 0 = nn.GELU() of the mm_projector (multimodal_projector/builder.py:41-48), 1 = gelu_pytorch_tanh of the SigLIP MLP
+ * (siglip_encoder.py:253-262).  f32 inside, one rounding. */
+int v3d_gelu(const void* z, int64_t ldz, void* out, int64_t ldo, int64_t rows, int cols, int tanh_form, int dtype, void* stream);
+int v3d_gelu_grad(const void* z, int64_t ldz, const void* dy, int64_t ldy, void* dz, int64_t ldo, int64_t rows, int cols, int tanh_form,
+                  int dtype, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;

@@ -325,3 +325,55 @@ def test_llm_step_loss_and_gradients_match_autograd(ops, train):
     opt.step(dev, grads)
     moved = (dev["layers"][0]["down"].float() - before.float()).abs()
     assert float(moved.max()) > 0 and float(moved.max()) < 4e-3           # |update| <= lr on the first step (+ one 16-bit rounding)
+
+
+# ------------------------------------------------------------------------------ projector, splice
+
+
+@pytest.mark.parametrize("tanh_form", [False, True])
+def test_gelu_forward_and_gradient(ops, tanh_form):
+    g = torch.Generator().manual_seed(9)
+    z = (torch.randn(90, 1160, generator=g) * 2).to(torch.bfloat16)
+    dy = torch.randn(90, 1160, generator=g).to(torch.bfloat16)
+    zr = z.float().requires_grad_()
+    ref = F.gelu(zr, approximate="tanh" if tanh_form else "none")
+    ref.backward(dy.float())
+    out = ops.gelu(z.cuda(), tanh_form)
+    diff = (out.float().cpu() - ref.detach()).abs()
+    assert bool((diff <= 2.0 ** -8 * ref.detach().abs() + 1e-6).all())      # one 16-bit rounding; 1 + erf(x) cancels for x << 0 (values < 1e-5)
+    _close(ops.gelu_grad(z.cuda(), dy.cuda(), tanh_form), zr.grad, 4e-3, 1e-2, "dz")
+
+
+def test_projector_forward_and_backward_match_autograd(train):
+    """mlp2x_gelu at its true widths (1152 -> 3584 -> 3584, multimodal_projector/builder.py:41-48) on two frames of patch features."""
+    g = torch.Generator().manual_seed(13)
+    rows, C, H = 2 * 729, 1152, 3584
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
+    x, w1, b1, w2, b2, dy = mk(rows, C), mk(H, C, s=C ** -0.5), mk(H, s=0.2), mk(H, H, s=H ** -0.5), mk(H, s=0.2), mk(rows, H)
+    leaves = [t.float().requires_grad_() for t in (x, w1, b1, w2, b2)]
+    ref = F.gelu(leaves[0] @ leaves[1].t() + leaves[2]) @ leaves[3].t() + leaves[4]
+    ref.backward(dy.float())
+    dev = [t.cuda() for t in (x, w1, b1, w2, b2)]
+    y, saved = train.projector_forward(*dev)
+    _close(y, ref.detach(), 6e-3, 2e-2, "forward")
+    dx, grads = train.projector_backward(dy.cuda(), saved, dev[1], dev[3])
+    _close(dx, leaves[0].grad, 1e-2, 3e-2, "dx")
+    for k, leaf in (("w1", leaves[1]), ("b1", leaves[2]), ("w2", leaves[3]), ("b2", leaves[4])):
+        _close(grads[k], leaf.grad, 1e-2, 3e-2, "d " + k)
+
+
+def test_inputs_embeds_backward_routes_rows(ops, train):
+    """The splice's backward: visual rows -> v3d_visual_tokens_grad, text rows -> embedding rows summed per token id."""
+    frames, H, n_pre, n_post, vocab = 2, 256, 5, 7, 64
+    n_vis = frames * 14 * 15
+    S = n_pre + n_vis + n_post
+    g = torch.Generator().manual_seed(2)
+    dx = torch.randn(S, H, generator=g).to(torch.bfloat16).cuda()
+    rows = torch.cat([torch.arange(n_pre), torch.arange(n_pre + n_vis, S)]).cuda()
+    ids = torch.tensor([3, 9, 3, 1, 0, 9, 9, 5, 63, 2, 3, 7]).cuda()
+    dE = torch.zeros(vocab, H, dtype=torch.bfloat16, device="cuda")
+    dfeat, dnl = train.inputs_embeds_backward(dx, n_pre, frames, rows, ids, dE)
+    ref_feat, ref_nl = ops.visual_tokens_grad(dx[n_pre:n_pre + n_vis].contiguous(), frames)
+    assert torch.equal(dfeat, ref_feat) and torch.equal(dnl, ref_nl)           # (that kernel's own parity: tests/test_gpu_train_kernels.py)
+    ref_E = torch.zeros(vocab, H).index_add_(0, ids.cpu(), dx[rows].float().cpu()).to(torch.bfloat16)
+    assert torch.equal(dE.cpu(), ref_E)

@@ -218,14 +218,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   for (int j = 0; j < 8; ++j) o[j] = s[j];
 }
 
-// out[c] = sum over the partials in order
+// out[c] = sum of the partials: thread (c, g) of a 64-column workgroup sums the partials b = g, g + 4, ... in order, the four
+// group sums are added in order (a fixed tree: run-to-run identical)
 template <typename TO>
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_part, int cols, TO* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   float s = 0.f;
-  for (int64_t b = 0; b < n_part; ++b) s += partial[b * cols + c];
-  out[c] = from_f32<TO>(s);
+  if (c < cols)
+    for (int64_t b = g; b < n_part; b += 4) s += partial[b * cols + c];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) out[c] = from_f32<TO>(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
 }
 
 // y = w * T(x r), r = rsqrt(mean(x^2) + eps).  With n = x r and g = dy w:  dx = r (g - n mean(g n)) [+ add],  dw = sum_rows dy n.
@@ -478,6 +482,41 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const T* __restrict__ d
   }
 }
 
+
+// nn.GELU() of the mm_projector (erf form, multimodal_projector/builder.py:41-48) and the SigLIP MLP's gelu_pytorch_tanh
+// (siglip_encoder.py:253-262) as passes of their own for the training forward (which keeps the pre-activation), and their gradients.
+template <int TANH> __device__ __forceinline__ float gelu_f(float x) {
+  if (TANH) { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.0f + tanhf(u)); }
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+template <int TANH> __device__ __forceinline__ float gelu_df(float x) {
+  if (TANH) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x), t = tanhf(u);
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+  }
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+template <typename T, int TANH, bool GRAD>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ z, int64_t ldz, const T* __restrict__ dy, int64_t ldy, T* __restrict__ out,
+                                                   int64_t ldo, int64_t rows, int cols) {
+  const int nv = cols / 8;
+  const int64_t total = rows * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / nv;
+    const int k = (int)(idx - r * nv);
+    const uint4 zv = *reinterpret_cast<const uint4*>(z + r * ldz + k * 8);
+    uint4 dv = make_uint4(0, 0, 0, 0);
+    if (GRAD) dv = *reinterpret_cast<const uint4*>(dy + r * ldy + k * 8);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = vec_get<T>(zv, j);
+      o[j] = GRAD ? vec_get<T>(dv, j) * gelu_df<TANH>(x) : gelu_f<TANH>(x);
+    }
+    *reinterpret_cast<uint4*>(out + r * ldo + k * 8) = vec_pack<T>(o);
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -556,7 +595,7 @@ extern "C" int64_t v3d_colsum_workspace_bytes(int64_t rows, int cols) {
 }
 
 static int colsum_final(const float* partial, int64_t n_part, int cols, void* out, int out_dtype, hipStream_t st, const char* what) {
-  const dim3 grid((cols + 255) / 256);
+  const dim3 grid((cols + 63) / 64);
   switch (out_dtype) {
     case V3D_F32: hipLaunchKernelGGL(colsum_final_kernel<float>, grid, dim3(256), 0, st, partial, n_part, cols, (float*)out); break;
     case V3D_F16: hipLaunchKernelGGL(colsum_final_kernel<f16_t>, grid, dim3(256), 0, st, partial, n_part, cols, (f16_t*)out); break;
@@ -669,4 +708,31 @@ extern "C" int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, c
   V3D_REQUIRE(n > 0 && n <= 65535 && H > 0 && ld >= H && lde >= H, "v3d_embed_grad: bad shape");
   V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(embed_grad_kernel<T>, dim3(n), dim3(256), 0, (hipStream_t)stream, (const T*)dh, ld, rows, ids, n, H, (T*)dE, lde));
   return check_launch("v3d_embed_grad");
+}
+
+static int gelu_launch(const void* z, int64_t ldz, const void* dy, int64_t ldy, void* out, int64_t ldo, int64_t rows, int cols, int tanh_form,
+                       int dtype, void* stream, const char* what) {
+  V3D_REQUIRE(z && out, "%s: null pointer", what);
+  V3D_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0 && ldz >= cols && ldo >= cols && (!dy || (ldy % 8 == 0 && ldy >= cols)) &&
+              aligned16(z) && aligned16(out) && aligned16(dy), "%s: cols and strides must be multiples of 8", what);
+  int64_t blocks = (rows * (cols / 8) + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipStream_t st = (hipStream_t)stream;
+#define V3D_GELU(TH, GR) hipLaunchKernelGGL((gelu_kernel<T, TH, GR>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)z, ldz, (const T*)dy, ldy, (T*)out, ldo, rows, cols)
+  V3D_DISPATCH_HALF(dtype, {
+    if (dy) { if (tanh_form) { V3D_GELU(1, true); } else { V3D_GELU(0, true); } }
+    else { if (tanh_form) { V3D_GELU(1, false); } else { V3D_GELU(0, false); } }
+  });
+#undef V3D_GELU
+  return check_launch(what);
+}
+
+extern "C" int v3d_gelu(const void* z, int64_t ldz, void* out, int64_t ldo, int64_t rows, int cols, int tanh_form, int dtype, void* stream) {
+  return gelu_launch(z, ldz, nullptr, 0, out, ldo, rows, cols, tanh_form, dtype, stream, "v3d_gelu");
+}
+
+extern "C" int v3d_gelu_grad(const void* z, int64_t ldz, const void* dy, int64_t ldy, void* dz, int64_t ldo, int64_t rows, int cols, int tanh_form,
+                             int dtype, void* stream) {
+  V3D_REQUIRE(dy, "v3d_gelu_grad: null pointer");
+  return gelu_launch(z, ldz, dy, ldy, dz, ldo, rows, cols, tanh_form, dtype, stream, "v3d_gelu_grad");
 }

@@ -816,3 +816,20 @@ def embed_grad(dh, rows, ids, dE):
     check(lib().v3d_embed_grad(_p(dh), dh.stride(0), _p(rows), _p(ids), rows.numel(), dh.shape[1], _p(dE), dE.stride(0), _code(dh), _stream()),
           "v3d_embed_grad")
     return dE
+
+
+def gelu(z, tanh_form=False):
+    z = _dev(z, "z")
+    out = torch.empty_like(z)
+    check(lib().v3d_gelu(_p(z), z.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], 1 if tanh_form else 0, _code(z), _stream()), "v3d_gelu")
+    return out
+
+
+def gelu_grad(z, dy, tanh_form=False):
+    z, dy = _dev(z, "z"), _dev(dy, "dy")
+    if z.shape != dy.shape:
+        raise V3DError("gelu_grad: dy must have z's shape")
+    out = torch.empty_like(z)
+    check(lib().v3d_gelu_grad(_p(z), z.stride(0), _p(dy), dy.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], 1 if tanh_form else 0,
+                              _code(z), _stream()), "v3d_gelu_grad")
+    return out

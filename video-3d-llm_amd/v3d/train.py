@@ -221,3 +221,32 @@ def _tree_zip(fn, a, b, c):
             _tree_zip(fn, x, y, z)
     else:
         fn(a, b, c)
+
+
+# ------------------------------------------------------------------------------ the path from the LLM's input rows back to the projector
+
+
+def projector_forward(x, w1, b1, w2, b2):
+    """mlp2x_gelu (multimodal_projector/builder.py:41-48): Linear, nn.GELU(), Linear on the SigLIP patch features x [rows, 1152]."""
+    z = ops.gemm(x, w1, bias=b1, epilogue=ops.EPI_BIAS)
+    a = ops.gelu(z)
+    return ops.gemm(a, w2, bias=b2, epilogue=ops.EPI_BIAS), (x, z, a)
+
+
+def projector_backward(dy, saved, w1, w2, need_dx=True):
+    x, z, a = saved
+    da, dw2, db2 = linear_backward(a, w2, dy, need_db=True)
+    dz = ops.gelu_grad(z, da)
+    dx, dw1, db1 = linear_backward(x, w1, dz, need_dx=need_dx, need_db=True)
+    return dx, {"w1": dw1, "b1": db1, "w2": dw2, "b2": db2}
+
+
+def inputs_embeds_backward(dx, n_pre, frames, text_rows, text_ids, embed_grad_out, side=27, n=14):
+    """Backward of the splice (llava_arch.py:650-836, one sample, one <image>): dx [S, H] = gradient of inputs_embeds
+    [n_pre text rows | frames * n * (n + 1) visual rows | text rows].  The visual rows go back through newline / PE add / bilinear pool
+    (v3d_visual_tokens_grad) to the projector's output [frames, side * side, H] and to image_newline; the text rows are summed per
+    token id into embed_tokens' gradient (embed_grad_out [vocab, H], pre-zeroed).  Returns (dfeat, dnewline)."""
+    n_vis = frames * n * (n + 1)
+    dfeat, dnl = ops.visual_tokens_grad(dx[n_pre:n_pre + n_vis], frames, side=side, n=n, newline=True)
+    ops.embed_grad(dx, text_rows, text_ids, embed_grad_out)
+    return dfeat, dnl
