@@ -25,10 +25,10 @@ def train():
     return t
 
 
-def _close(got, ref, rel, elem, what):
+def _close(got, ref, rel, elem, what, floor=1e-30):
     got, ref = got.float().cpu(), ref.float()
-    err = (got - ref).norm() / ref.norm().clamp_min(1e-30)
-    worst = (got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)
+    err = (got - ref).norm() / ref.norm().clamp_min(floor)
+    worst = (got - ref).abs().max() / ref.abs().max().clamp_min(floor)
     assert err < rel and worst < elem, f"{what}: norm-wise {err:.3e} (bound {rel}), element-wise {worst:.3e} of max |ref| (bound {elem})"
 
 
@@ -180,38 +180,41 @@ def _attention_ref(q, k, v, n_q, n_kv, hd):
     return (torch.softmax(s, -1) @ vh).transpose(0, 1).reshape(S, n_q * hd)
 
 
-@pytest.mark.parametrize("S", [150, 257, 700])
-def test_attention_backward_matches_autograd(ops, train, S):
+@pytest.mark.parametrize("S,dt", [(150, torch.bfloat16), (257, torch.bfloat16), (700, torch.bfloat16), (40, torch.bfloat16), (64, torch.bfloat16),
+                                  (128, torch.bfloat16), (1, torch.bfloat16), (300, torch.float16)])
+def test_attention_backward_matches_autograd(ops, train, S, dt):
     n_q, n_kv, hd = 4, 2, 128
     g = torch.Generator().manual_seed(S)
     width = (n_q + 2 * n_kv) * hd
-    qkv = torch.randn(S, width, generator=g).to(torch.bfloat16)
-    do = torch.randn(S, n_q * hd, generator=g).to(torch.bfloat16)
+    qkv = torch.randn(S, width, generator=g).to(dt)
+    do = torch.randn(S, n_q * hd, generator=g).to(dt)
     ref = qkv.float().requires_grad_()
     _attention_ref(ref[:, :n_q * hd], ref[:, n_q * hd:(n_q + n_kv) * hd], ref[:, (n_q + n_kv) * hd:], n_q, n_kv, hd).backward(do.float())
     Sp = (S + 127) // 128 * 128
-    dev = torch.zeros(Sp, width, dtype=torch.bfloat16, device="cuda")
+    dev = torch.zeros(Sp, width, dtype=dt, device="cuda")
     dev[:S] = qkv.cuda()
-    dqkv = torch.full((S, width), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dqkv = torch.full((S, width), float("nan"), dtype=dt, device="cuda")
     train.attention_backward_materialised(dev, do.cuda(), dqkv, S, n_q, n_kv, hd, hd ** -0.5)
+    floor = 1.0 if S == 1 else 1e-30           # one key: dq = dk = 0 exactly in the reference, compare absolutely
     parts = (("dq", slice(0, n_q * hd)), ("dk", slice(n_q * hd, (n_q + n_kv) * hd)), ("dv", slice((n_q + n_kv) * hd, width)))
     for name, sl in parts:
-        _close(dqkv[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name + " (materialised)")          # p, dp, ds are 16-bit tensors (2^-9 each)
+        _close(dqkv[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name + " (materialised)", floor)          # p, dp, ds are 16-bit tensors (2^-9 each)
     # the tiled kernels: forward with the row log-sum-exp, then the backward that recomputes the probabilities
-    o = torch.empty(S, n_q * hd, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(S, n_q * hd, dtype=dt, device="cuda")
     lse = ops.attention_train(dev, o, S, n_q, n_kv, hd ** -0.5)
     o_plain = torch.empty_like(o)
     ops.attention(dev, dev[:, n_q * hd:], dev[:, (n_q + n_kv) * hd:], o_plain, 1, S, S, n_q, n_kv, hd, hd, width, width, width, n_q * hd,
                   0, 0, 0, hd, hd, hd, True, 0, hd ** -0.5)
-    assert torch.equal(o, o_plain)                                                       # same kernel, one more store
+    if S > 8:                                                                            # (v3d_attention sends <= 8 rows to its decode kernel)
+        assert torch.equal(o, o_plain)                                                   # same kernel, one more store
     s_ref = (qkv[:, :n_q * hd].float().view(S, n_q, hd).transpose(0, 1) @
              qkv[:, n_q * hd:(n_q + n_kv) * hd].float().view(S, n_kv, hd).transpose(0, 1).repeat_interleave(n_q // n_kv, 0).transpose(1, 2)) * hd ** -0.5
     lse_ref = torch.logsumexp(s_ref + torch.full((S, S), float("-inf")).triu(1), -1) * 1.4426950408889634
     assert float((lse.cpu() - lse_ref).abs().max()) < 2e-2                               # scaled log2 units; c q is rounded to 16 bit
-    dq2 = torch.full((S, width), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dq2 = torch.full((S, width), float("nan"), dtype=dt, device="cuda")
     ops.attention_backward(dev, o, do.cuda(), lse, dq2, S, n_q, n_kv, hd ** -0.5)
     for name, sl in parts:
-        _close(dq2[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name + " (tiled)")
+        _close(dq2[:, sl], ref.grad[:, sl], 1.2e-2, 3e-2, name + " (tiled)", floor)
     dq3 = torch.empty_like(dq2)
     ops.attention_backward(dev, o, do.cuda(), lse, dq3, S, n_q, n_kv, hd ** -0.5)
     assert torch.equal(dq2, dq3)                                                         # no atomics: run-to-run identical
