@@ -392,21 +392,23 @@ int v3d_causal_softmax_rows(const void* s, int64_t lds, void* p, int64_t ldp, in
 int v3d_softmax_grad_rows(const void* p, int64_t ldp, const void* dp, int64_t ldd, void* ds, int64_t lds, int64_t rows, int cols,
                           float scale, int dtype, void* stream);
 
-/* Attention backward as tiled kernels (the [S, S] matrices never reach HBM): v3d_attention_train is v3d_attention (causal, head
- * dim 128, outputs bit-identical) that also writes lse [B, Hq, Sq] f32, the row log-sum-exp in the kernel's scaled log2 units;
- * v3d_attention_backward (one sequence, Sq = Sk = S, heads 128 columns apart inside a token row) recomputes the probabilities
- * from q, k and lse and writes dq [S, Hq 128], dk, dv [S, Hkv 128] (the sum over a kv group's query heads is taken in f32, in a
- * fixed order: no atomics).  q / k are the ROTATED projections, o the forward's output, dout its gradient.  workspace:
- * v3d_attention_backward_workspace_bytes(S, Hq) bytes.  Differentiates modeling_qwen2.py:248-482. */
+/* Attention backward as tiled kernels (the [S, S] matrices never reach HBM): v3d_attention_train is v3d_attention at head dim 128
+ * (outputs bit-identical) that also writes lse [B, Hq, Sq] f32, the row log-sum-exp in the kernel's scaled log2 units;
+ * v3d_attention_backward (Sq = Sk = S, heads 128 columns apart inside a token row, B sequences with element strides bs*; causal =
+ * the decoder, modeling_qwen2.py:248-482, non-causal = the SigLIP encoder with its 72-wide heads zero-padded to 128,
+ * siglip_encoder.py:197-250) recomputes the probabilities from q, k and lse and writes dq [S, Hq 128], dk, dv [S, Hkv 128] per sequence
+ * (the sum over a kv group's query heads is taken in f32, in a fixed order: no atomics).  q / k are what the forward multiplied (the
+ * ROTATED projections in the decoder), o the forward's output, dout its gradient.  workspace:
+ * v3d_attention_backward_workspace_bytes(B, S, Hq) bytes. */
 int v3d_attention_train(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int Sq, int Sk, int Hq,
                         int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bso, int hsq,
-                        int hsk, int hso, int q_pos0, float scale, void* stream);
-int64_t v3d_attention_backward_workspace_bytes(int S, int Hq);
+                        int hsk, int hso, int causal, int q_pos0, float scale, void* stream);
+int64_t v3d_attention_backward_workspace_bytes(int B, int S, int Hq);
 int v3d_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
-                           void* dk, void* dv, int dtype, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                           int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, void* workspace,
-                           int64_t workspace_bytes, void* stream);
-
+                           void* dk, void* dv, int dtype, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv,
+                           int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t bsq, int64_t bsk, int64_t bsv,
+                           int64_t bso, int64_t bsdo, int64_t bsdq, int64_t bsdk, int64_t bsdv, int causal, float scale,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 /* One AdamW update of a flat parameter tensor (torch.optim.AdamW's single-tensor form = the reference's HF Trainer optimizer; ZeRO
  * runs the same update on its f32 master partition): p32 / m / v [n] f32 in place, grad [n] in grad_dtype (f32 / f16 / bf16) times
  * grad_scale, p16 (may be null) the 16-bit copy the next forward reads.  step counts from 1 (bias correction). */
@@ -424,6 +426,13 @@ int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_
 int v3d_gelu(const void* z, int64_t ldz, void* out, int64_t ldo, int64_t rows, int cols, int tanh_form, int dtype, void* stream);
 int v3d_gelu_grad(const void* z, int64_t ldz, const void* dy, int64_t ldy, void* dz, int64_t ldo, int64_t rows, int cols, int tanh_form,
                   int dtype, void* stream);
+
+/* Backward of v3d_layernorm (nn.LayerNorm of the SigLIP encoder layers, siglip_encoder.py:272-274,292,300): with xh = (x - mean) rstd
+ * and g = dy * weight: dx = rstd (g - mean(g) - xh mean(g xh)) (+ add, the residual branch's gradient), dweight = sum_rows dy xh,
+ * dbias = sum_rows dy (f32, fixed order).  workspace: 2 * v3d_colsum_workspace_bytes(rows, cols) bytes.  cols <= 2048. */
+int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight, const void* dy, int64_t ldy, const void* add, int64_t lda, void* dx,
+                       int64_t ldd, float* workspace, void* dweight, void* dbias, int dw_dtype, int64_t rows, int cols, float eps,
+                       int dtype, void* stream);
 
 /* ------------------------------------------------------------------ host helpers -------- */
 

@@ -380,3 +380,68 @@ def test_inputs_embeds_backward_routes_rows(ops, train):
     assert torch.equal(dfeat, ref_feat) and torch.equal(dnl, ref_nl)           # (that kernel's own parity: tests/test_gpu_train_kernels.py)
     ref_E = torch.zeros(vocab, H).index_add_(0, ids.cpu(), dx[rows].float().cpu()).to(torch.bfloat16)
     assert torch.equal(dE.cpu(), ref_E)
+
+
+# ------------------------------------------------------------------------------ the SigLIP tower's layers
+
+
+@pytest.mark.parametrize("rows,cols,with_add", [(70, 1152, True), (1458, 1152, False), (33, 256, False)])
+def test_layernorm_grad_matches_autograd(ops, rows, cols, with_add):
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, cols, generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w = (1 + 0.2 * torch.randn(cols, generator=g)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(cols, generator=g)).to(torch.bfloat16)
+    dy = torch.randn(rows, cols, generator=g).to(torch.bfloat16)
+    add = torch.randn(rows, cols, generator=g).to(torch.bfloat16) if with_add else None
+    xr, wr, br = x.float().requires_grad_(), w.float().requires_grad_(), b.float().requires_grad_()
+    F.layer_norm(xr, (cols,), wr, br, 1e-6).backward(dy.float())          # nn.LayerNorm, siglip_encoder.py:272-274
+    dx, dw, db = ops.layernorm_grad(x.cuda(), w.cuda(), dy.cuda(), 1e-6, add=add.cuda() if with_add else None, dw_dtype=torch.float32)
+    _close(dx, xr.grad + (add.float() if with_add else 0), 6e-3, 1.5e-2, "dx")
+    _close(dw, wr.grad, 2e-3, 4e-3, "dweight")
+    _close(db, br.grad, 1e-4, 1e-4, "dbias")                                # plain f32 column sums of 16-bit values
+
+
+def _siglip_layer_ref(x, sd, frames, tokens, heads):
+    # SigLipEncoderLayer.forward, siglip_encoder.py:264-305, with SigLipAttention :197-250 and SigLipMLP :253-262
+    H = x.shape[1]
+    hd = H // heads
+    n1 = F.layer_norm(x, (H,), sd["ln1_w"], sd["ln1_b"], 1e-6)
+    q, k, v = (F.linear(n1, sd[n + "_w"], sd[n + "_b"]).view(frames, tokens, heads, hd).transpose(1, 2) for n in ("q", "k", "v"))
+    p = torch.softmax(q @ k.transpose(2, 3) * hd ** -0.5, -1)
+    o = (p @ v).transpose(1, 2).reshape(frames * tokens, H)
+    mid = x + F.linear(o, sd["o_w"], sd["o_b"])
+    n2 = F.layer_norm(mid, (H,), sd["ln2_w"], sd["ln2_b"], 1e-6)
+    return mid + F.linear(F.gelu(F.linear(n2, sd["fc1_w"], sd["fc1_b"]), approximate="tanh"), sd["fc2_w"], sd["fc2_b"])
+
+
+def test_siglip_layer_forward_and_backward_match_autograd(train):
+    """One SigLIP encoder layer at its true width (hidden 1152, 16 heads of 72, MLP 4304) on two frames of 729 patches: the training
+    layout pads the heads to 128 and the MLP to 4352; forward and every gradient (un-padded) against autograd in f32."""
+    frames, tokens, H, heads, inter = 2, 729, 1152, 16, 4304
+    g = torch.Generator().manual_seed(31)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
+    sd = {"ln1_w": (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16), "ln1_b": mk(H, s=0.1),
+          "ln2_w": (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16), "ln2_b": mk(H, s=0.1),
+          "q_w": mk(H, H, s=H ** -0.5), "q_b": mk(H, s=0.2), "k_w": mk(H, H, s=H ** -0.5), "k_b": mk(H, s=0.2),
+          "v_w": mk(H, H, s=H ** -0.5), "v_b": mk(H, s=0.2), "o_w": mk(H, H, s=H ** -0.5), "o_b": mk(H, s=0.2),
+          "fc1_w": mk(inter, H, s=H ** -0.5), "fc1_b": mk(inter, s=0.2), "fc2_w": mk(H, inter, s=inter ** -0.5), "fc2_b": mk(H, s=0.2)}
+    x, dout = mk(frames * tokens, H), mk(frames * tokens, H)
+    leaves = {k: v.float().requires_grad_() for k, v in sd.items()}
+    xr = x.float().requires_grad_()
+    ref = _siglip_layer_ref(xr, leaves, frames, tokens, heads)
+    ref.backward(dout.float())
+    p = train.siglip_pad_layer({k: v.cuda() for k, v in sd.items()})
+    out, saved = train.siglip_layer_forward(x.cuda(), p, frames)
+    _close(out, ref.detach(), 8e-3, 3e-2, "forward")
+    dx, grads = train.siglip_layer_backward(dout.cuda(), saved, p, frames)
+    _close(dx, xr.grad, 1.5e-2, 4e-2, "dx")
+    pad = grads["qkv"].view(3, heads, 128, H)[:, :, 72:]
+    assert not bool(pad.any()) and not bool(grads["o"].view(H, heads, 128)[:, :, 72:].any()) and not bool(grads["fc1"][inter:].any())   # the padding learns nothing
+    real = train.siglip_unpad_grads(grads)
+    for k in sd:
+        # the key bias has NO gradient (a constant added to every key shifts a query's scores alike: softmax does not see it): the
+        # reference's is f32 noise, the device's 16-bit noise - held to the scale of the query bias' gradient instead
+        if k == "k_b":
+            assert float(real[k].float().abs().max()) <= 0.04 * float(leaves["q_b"].grad.abs().max())
+            continue
+        _close(real[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)

@@ -1570,8 +1570,9 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
     }                                                                                                             \
     hipLaunchKernelGGL(k, grid, block, AT_LDS, st, p);                                                            \
   }
-  if (p.lse && !(D == 128 && causal)) { set_error("v3d_attention_train: causal attention with head dim 128 only"); return V3D_E_UNSUPPORTED; }
+  if (p.lse && D != 128) { set_error("v3d_attention_train: head dim 128 only (zero-pad narrower heads)"); return V3D_E_UNSUPPORTED; }
   if (D == 128 && causal && p.lse) V3D_ATTN(128, true, 8, true)
+  else if (D == 128 && p.lse) V3D_ATTN(128, false, 8, true)
   else if (D == 128 && causal) V3D_ATTN(128, true, 8, false)
   else if (D == 128) V3D_ATTN(128, false, 8, false)
   else if (D == 96 && causal) V3D_ATTN(96, true, 6, false)
@@ -1623,13 +1624,13 @@ extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* 
                          scale, stream, nullptr);
 }
 
-// The training forward: v3d_attention (causal, head dim 128) that also writes the row log-sum-exp the backward recomputes the
+// The training forward: v3d_attention (head dim 128) that also writes the row log-sum-exp the backward recomputes the
 // probabilities from (same kernel with one more store after the tile loop; outputs bit-identical to v3d_attention's).
 extern "C" int v3d_attention_train(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int B, int Sq, int Sk,
                                    int Hq, int Hkv, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk,
-                                   int64_t bso, int hsq, int hsk, int hso, int q_pos0, float scale, void* stream) {
+                                   int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0, float scale, void* stream) {
   V3D_REQUIRE(lse, "v3d_attention_train: null lse");
-  return attention_entry(q, k, v, o, dtype, B, Sq, Sk, Hq, Hkv, 128, 128, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, 1, q_pos0, scale,
+  return attention_entry(q, k, v, o, dtype, B, Sq, Sk, Hq, Hkv, 128, 128, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, causal, q_pos0, scale,
                          stream, lse);
 }
 

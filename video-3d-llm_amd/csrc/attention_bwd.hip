@@ -1,6 +1,6 @@
 // Backward of the causal GQA flash attention (training step, BASELINE configs[4]; reference: Qwen2Attention /
-// Qwen2FlashAttention2, llava/model/language_model/qwen2/modeling_qwen2.py:248-482, differentiated).  Head dim 128, one sequence,
-// Sq = Sk = S.  The S x S matrices never leave the chip: the probabilities are RECOMPUTED from q, k and the forward's row
+// Qwen2FlashAttention2, llava/model/language_model/qwen2/modeling_qwen2.py:248-482, differentiated).  Head dim 128 (narrower heads zero-padded), Sq = Sk = S,
+// causal (the decoder) or not (the SigLIP encoder, siglip_encoder.py:197-250), a batch of sequences.  The S x S matrices never leave the chip: the probabilities are RECOMPUTED from q, k and the forward's row
 // log-sum-exp (v3d_attention_train writes it), tile by tile, with the forward kernel's own primitives - 64-row LDS images staged by
 // LDS-DMA under one XOR swizzle, row fragments by ds_read_b128, transposed fragments by ds_read_b64_tr_b16, 32x32x16 MFMAs whose
 // accumulator registers are re-used as the next product's B operand (both operands in the same permuted k order).
@@ -49,7 +49,8 @@ struct BwdArgs {
   const float* lse; float* delta;            // [Hq, S]
   void* dq; float* dk_part; float* dv_part;  // dq [S, .] 16 bit; partials [Hq, S, 128] f32
   int64_t ldq, ldk, ldv, ldo, lddo, lddq;    // token strides (elements); heads are 128 apart
-  int S, Hq, group;
+  int64_t bsq, bsk, bsv, bso, bsdo, bsdq;    // batch strides (elements); lse / delta / the partials are [B, Hq, S(, 128)]
+  int S, Hq, group, B, causal;
   float scale, scale_log2;
 };
 
@@ -132,14 +133,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_delta_kernel(BwdArgs p) {
   const int lane = threadIdx.x & 63;
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= (int64_t)p.S * p.Hq) return;
-  const int t = (int)(item / p.Hq), head = (int)(item - (int64_t)t * p.Hq);
-  const uint32_t a = *reinterpret_cast<const uint32_t*>((const uint16_t*)p.o + (int64_t)t * p.ldo + head * 128 + 2 * lane);
-  const uint32_t b = *reinterpret_cast<const uint32_t*>((const uint16_t*)p.dout + (int64_t)t * p.lddo + head * 128 + 2 * lane);
+  if (item >= (int64_t)p.B * p.S * p.Hq) return;
+  const int head = (int)(item % p.Hq);
+  const int64_t bt = item / p.Hq;
+  const int t = (int)(bt % p.S), bi = (int)(bt / p.S);
+  const uint32_t a = *reinterpret_cast<const uint32_t*>((const uint16_t*)p.o + bi * p.bso + (int64_t)t * p.ldo + head * 128 + 2 * lane);
+  const uint32_t b = *reinterpret_cast<const uint32_t*>((const uint16_t*)p.dout + bi * p.bsdo + (int64_t)t * p.lddo + head * 128 + 2 * lane);
   float s = pair_lo<T>(a) * pair_lo<T>(b) + pair_hi<T>(a) * pair_hi<T>(b);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) p.delta[(int64_t)head * p.S + t] = s;
+  if (lane == 0) p.delta[((int64_t)bi * p.Hq + head) * p.S + t] = s;
 }
 
 template <typename T>
@@ -150,12 +153,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, h = lane >> 5;
   const int qt = (int)gridDim.y - 1 - (int)blockIdx.y;            // heaviest query tiles first
-  const int head = blockIdx.x, hk = head / p.group;
+  const int head = blockIdx.x, hk = head / p.group, bi = blockIdx.z;
   const int q0 = qt * 128;
-  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)head * 128;
-  const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * 128;
-  const uint16_t* V = (const uint16_t*)p.v + (int64_t)hk * 128;
-  const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)head * 128;
+  const uint16_t* Q = (const uint16_t*)p.q + bi * p.bsq + (int64_t)head * 128;
+  const uint16_t* K = (const uint16_t*)p.k + bi * p.bsk + (int64_t)hk * 128;
+  const uint16_t* V = (const uint16_t*)p.v + bi * p.bsv + (int64_t)hk * 128;
+  const uint16_t* DO = (const uint16_t*)p.dout + bi * p.bsdo + (int64_t)head * 128;
   const int qi = q0 + wave * 32 + ql;
   const int qi_ld = qi < p.S ? qi : p.S - 1;
   v4i qf[8], dof[8];
@@ -168,10 +171,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
     qf[ks] = pack8<T>(f);
     dof[ks] = *reinterpret_cast<const v4i*>(DO + (int64_t)qi_ld * p.lddo + ks * 16 + h * 8);
   }
-  const float L = p.lse[(int64_t)head * p.S + qi_ld], dl = p.delta[(int64_t)head * p.S + qi_ld];
+  const int64_t stat0 = ((int64_t)bi * p.Hq + head) * p.S;
+  const float L = p.lse[stat0 + qi_ld], dl = p.delta[stat0 + qi_ld];
   const int last_q = q0 + 127 < p.S ? q0 + 127 : p.S - 1;
-  const int n_tiles = last_q / 64 + 1;
-  const int n_wave = min((q0 + wave * 32 + 31) / 64 + 1, n_tiles);
+  const int n_tiles = p.causal ? last_q / 64 + 1 : (p.S + 63) / 64;
+  const int n_wave = p.causal ? min((q0 + wave * 32 + 31) / 64 + 1, n_tiles) : n_tiles;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   f32x16 acc[4];
 #pragma unroll
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) dp[kt] = M::run(fa[ks], dof[ks], dp[kt]);
       }
-      const int limit = (qi < p.S - 1 ? qi : p.S - 1) - t * 64 - 4 * h;       // visible iff tile-local key offset <= limit
+      const int limit = ((p.causal && qi < p.S - 1) ? qi : p.S - 1) - t * 64 - 4 * h;       // visible iff tile-local key offset <= limit
       v4i pf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
       *reinterpret_cast<uint2*>(so + ql * OROW + d * 2) = pk;
     }
   __syncthreads();
-  uint16_t* DQ = (uint16_t*)p.dq + (int64_t)head * 128;
+  uint16_t* DQ = (uint16_t*)p.dq + bi * p.bsdq + (int64_t)head * 128;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int idx = i * 64 + lane, row = idx >> 4, ch = idx & 15;
@@ -263,12 +267,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kl = lane & 31, h = lane >> 5;
-  const int head = blockIdx.x, hk = head / p.group;
+  const int head = blockIdx.x, hk = head / p.group, bi = blockIdx.z;
   const int k0 = (int)blockIdx.y * 128;
-  const uint16_t* Q = (const uint16_t*)p.q + (int64_t)head * 128;
-  const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * 128;
-  const uint16_t* V = (const uint16_t*)p.v + (int64_t)hk * 128;
-  const uint16_t* DO = (const uint16_t*)p.dout + (int64_t)head * 128;
+  const uint16_t* Q = (const uint16_t*)p.q + bi * p.bsq + (int64_t)head * 128;
+  const uint16_t* K = (const uint16_t*)p.k + bi * p.bsk + (int64_t)hk * 128;
+  const uint16_t* V = (const uint16_t*)p.v + bi * p.bsv + (int64_t)hk * 128;
+  const uint16_t* DO = (const uint16_t*)p.dout + bi * p.bsdo + (int64_t)head * 128;
+  const int64_t stat0 = ((int64_t)bi * p.Hq + head) * p.S;
   const int key = k0 + wave * 32 + kl;
   const int key_ld = key < p.S ? key : p.S - 1;
   v4i kf[8], vf[8];
@@ -286,11 +291,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
   const int n_qt = (p.S + 63) / 64;
   const int wave_first_key = k0 + wave * 32;
-  const int t0 = k0 / 64;
+  const int t0 = p.causal ? k0 / 64 : 0;
   auto stat_load = [&](int t) -> float {                            // threads 0..127: L or delta of one query of tile t
     const int qrow = t * 64 + (tid & 63);
     const float* src = tid < 64 ? p.lse : p.delta;
-    return (tid < 128 && qrow < p.S) ? src[(int64_t)head * p.S + qrow] : 0.f;
+    return (tid < 128 && qrow < p.S) ? src[stat0 + qrow] : 0.f;
   };
   {
     const float sv = stat_load(t0);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
       stage_image(DO, (unsigned)p.lddo * 2u, smem + (buf ^ 1) * BW_BUF + BW_TILE, (t + 1) * 64, p.S, wave, lane);
     }
     const unsigned lds_q = lds0 + buf * BW_BUF, lds_do = lds_q + BW_TILE;
-    if (t * 64 + 63 >= wave_first_key) {            // some query of the tile sees some key of this wave
+    if (!p.causal || t * 64 + 63 >= wave_first_key) {            // some query of the tile sees some key of this wave
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
           const int r = 8 * (i & 1) + j;
           const int row = (i >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;        // query within the tile
           const int qidx = t * 64 + row;
-          const bool vis = key <= qidx && qidx < p.S;
+          const bool vis = (!p.causal || key <= qidx) && qidx < p.S;
           const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(s[i >> 1][r], p.scale_log2, -Lr[4 * (i >> 1) + (r >> 2)][r & 3])) : 0.f;
           ep[j] = pr;
           es[j] = pr * (dp[i >> 1][r] - Dr[4 * (i >> 1) + (r >> 2)][r & 3]);
@@ -366,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     __syncthreads();
   }
   if (key < p.S) {
-    float* ok = p.dk_part + ((int64_t)head * p.S + key) * 128;
-    float* ov = p.dv_part + ((int64_t)head * p.S + key) * 128;
+    float* ok = p.dk_part + (stat0 + key) * 128;
+    float* ov = p.dv_part + (stat0 + key) * 128;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -379,24 +384,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   }
 }
 
-// dk[t][g, d] = T(sum over the query heads of kv group g, in order, of dk_part[head][t][d]); likewise dv
+// dk[b][t][g, d] = T(sum over the query heads of kv group g, in order, of dk_part[b][head][t][d]); likewise dv
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __restrict__ dk_part, const float* __restrict__ dv_part, T* __restrict__ dk,
-                                                              int64_t lddk, T* __restrict__ dv, int64_t lddv, int S, int Hkv, int group) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (t, g, d / 8)
-  const int64_t total = (int64_t)S * Hkv * 16;
+                                                              int64_t lddk, int64_t bsdk, T* __restrict__ dv, int64_t lddv, int64_t bsdv, int B, int S,
+                                                              int Hkv, int group) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // (b, t, g, d / 8)
+  const int64_t total = (int64_t)B * S * Hkv * 16;
   if (idx >= total) return;
   const int ch = (int)(idx & 15);
   const int g = (int)((idx >> 4) % Hkv);
-  const int t = (int)((idx >> 4) / Hkv);
+  const int64_t bt = (idx >> 4) / Hkv;
+  const int t = (int)(bt % S), bi = (int)(bt / S);
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < group; ++j) {
-    const int64_t off = ((int64_t)(g * group + j) * S + t) * 128 + ch * 8;
+    const int64_t off = ((((int64_t)bi * Hkv + g) * group + j) * S + t) * 128 + ch * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { a[i] += dk_part[off + i]; b[i] += dv_part[off + i]; }
   }
-  *reinterpret_cast<uint4*>(dk + (int64_t)t * lddk + g * 128 + ch * 8) = vec_pack<T>(a);
-  *reinterpret_cast<uint4*>(dv + (int64_t)t * lddv + g * 128 + ch * 8) = vec_pack<T>(b);
+  *reinterpret_cast<uint4*>(dk + bi * bsdk + (int64_t)t * lddk + g * 128 + ch * 8) = vec_pack<T>(a);
+  *reinterpret_cast<uint4*>(dv + bi * bsdv + (int64_t)t * lddv + g * 128 + ch * 8) = vec_pack<T>(b);
 }
 
 }  // namespace bwd
@@ -405,35 +412,39 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_kernel(const float* __res
 using namespace v3d;
 using namespace v3d::bwd;
 
-extern "C" int64_t v3d_attention_backward_workspace_bytes(int S, int Hq) {
-  if (S <= 0 || Hq <= 0) return 0;
-  return ((int64_t)Hq * S + 2 * (int64_t)Hq * S * 128) * (int64_t)sizeof(float);
+extern "C" int64_t v3d_attention_backward_workspace_bytes(int B, int S, int Hq) {
+  if (B <= 0 || S <= 0 || Hq <= 0) return 0;
+  return ((int64_t)B * Hq * S + 2 * (int64_t)B * Hq * S * 128) * (int64_t)sizeof(float);
 }
 
 extern "C" int v3d_attention_backward(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                                      void* dq, void* dk, void* dv, int dtype, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk,
-                                      int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
-                                      void* workspace, int64_t workspace_bytes, void* stream) {
+                                      void* dq, void* dk, void* dv, int dtype, int B, int S, int Hq, int Hkv, int64_t ldq, int64_t ldk,
+                                      int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t bsq,
+                                      int64_t bsk, int64_t bsv, int64_t bso, int64_t bsdo, int64_t bsdq, int64_t bsdk, int64_t bsdv,
+                                      int causal, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
   V3D_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && workspace, "v3d_attention_backward: null pointer");
   V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_attention_backward: dtype must be f16 or bf16");
-  V3D_REQUIRE(S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq <= 65535, "v3d_attention_backward: bad shape");
-  V3D_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0,
+  V3D_REQUIRE(B > 0 && B <= 65535 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "v3d_attention_backward: bad shape");
+  V3D_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0 &&
+                  bsq % 8 == 0 && bsk % 8 == 0 && bsv % 8 == 0 && bso % 8 == 0 && bsdo % 8 == 0 && bsdq % 8 == 0 && bsdk % 8 == 0 && bsdv % 8 == 0,
               "v3d_attention_backward: strides must be multiples of 8 elements");
   V3D_REQUIRE(ldq >= (int64_t)Hq * 128 && ldo >= (int64_t)Hq * 128 && lddo >= (int64_t)Hq * 128 && lddq >= (int64_t)Hq * 128 &&
                   ldk >= (int64_t)Hkv * 128 && ldv >= (int64_t)Hkv * 128 && lddk >= (int64_t)Hkv * 128 && lddv >= (int64_t)Hkv * 128,
               "v3d_attention_backward: heads are 128 columns apart inside a token row");
   V3D_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv) &&
                   aligned16(workspace), "v3d_attention_backward: pointers must be 16-byte aligned");
-  V3D_REQUIRE(workspace_bytes >= v3d_attention_backward_workspace_bytes(S, Hq), "v3d_attention_backward: workspace too small");
-  V3D_REQUIRE((int64_t)S * ldq < (1ll << 31) && (int64_t)S * ldk < (1ll << 31) && (int64_t)S * lddo < (1ll << 31), "v3d_attention_backward: row offsets must fit 32 bits");
+  V3D_REQUIRE(workspace_bytes >= v3d_attention_backward_workspace_bytes(B, S, Hq), "v3d_attention_backward: workspace too small");
+  V3D_REQUIRE((int64_t)S * ldq < (1ll << 31) && (int64_t)S * ldk < (1ll << 31) && (int64_t)S * ldv < (1ll << 31) && (int64_t)S * lddo < (1ll << 31),
+              "v3d_attention_backward: row offsets inside one sequence must fit 32 bits");
   BwdArgs p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.dout = dout; p.lse = lse;
   p.delta = (float*)workspace;
-  p.dk_part = p.delta + (int64_t)Hq * S;
-  p.dv_part = p.dk_part + (int64_t)Hq * S * 128;
+  p.dk_part = p.delta + (int64_t)B * Hq * S;
+  p.dv_part = p.dk_part + (int64_t)B * Hq * S * 128;
   p.dq = dq;
   p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq;
-  p.S = S; p.Hq = Hq; p.group = Hq / Hkv;
+  p.bsq = bsq; p.bsk = bsk; p.bsv = bsv; p.bso = bso; p.bsdo = bsdo; p.bsdq = bsdq;
+  p.S = S; p.Hq = Hq; p.group = Hq / Hkv; p.B = B; p.causal = causal ? 1 : 0;
   p.scale = scale; p.scale_log2 = scale * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
   const unsigned n128 = (unsigned)((S + 127) / 128);
@@ -446,11 +457,11 @@ extern "C" int v3d_attention_backward(const void* q, const void* k, const void* 
       if (e != hipSuccess) { set_error("v3d_attention_backward: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
       attr_done = true;                                                                                                          \
     }                                                                                                                            \
-    hipLaunchKernelGGL(attn_delta_kernel<TT>, dim3((unsigned)(((int64_t)S * Hq + 3) / 4)), dim3(256), 0, st, p);                  \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<TT>, dim3(Hq, n128), dim3(256), BW_LDS, st, p);                                         \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<TT>, dim3(Hq, n128), dim3(256), BW_LDS, st, p);                                        \
-    hipLaunchKernelGGL(attn_bwd_reduce_kernel<TT>, dim3((unsigned)(((int64_t)S * Hkv * 16 + 255) / 256)), dim3(256), 0, st,       \
-                       (const float*)p.dk_part, (const float*)p.dv_part, (TT*)dk, lddk, (TT*)dv, lddv, S, Hkv, p.group);          \
+    hipLaunchKernelGGL(attn_delta_kernel<TT>, dim3((unsigned)(((int64_t)B * S * Hq + 3) / 4)), dim3(256), 0, st, p);              \
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<TT>, dim3(Hq, n128, B), dim3(256), BW_LDS, st, p);                                      \
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<TT>, dim3(Hq, n128, B), dim3(256), BW_LDS, st, p);                                     \
+    hipLaunchKernelGGL(attn_bwd_reduce_kernel<TT>, dim3((unsigned)(((int64_t)B * S * Hkv * 16 + 255) / 256)), dim3(256), 0, st,   \
+                       (const float*)p.dk_part, (const float*)p.dv_part, (TT*)dk, lddk, bsdk, (TT*)dv, lddv, bsdv, B, S, Hkv, p.group); \
   }
   if (dtype == V3D_BF16) V3D_BWD(bf16_t) else V3D_BWD(f16_t)
 #undef V3D_BWD

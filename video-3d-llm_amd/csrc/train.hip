@@ -517,6 +517,98 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ z, int6
   }
 }
 
+
+// nn.LayerNorm of the SigLIP encoder layers (siglip_encoder.py:272-274): y = xh w + b, xh = (x - mean) rstd.  With g = dy w:
+// dx = rstd (g - mean(g) - xh mean(g xh)) [+ add],  dw = sum_rows dy xh,  db = sum_rows dy.   Same shape as rmsnorm_grad_kernel:
+// 32 rows per workgroup, their dw / db contributions leave as one partial row each (partial_b follows partial_w's n_part rows).
+constexpr int LN_MAXV = 4;       // cols <= 2048
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, const T* __restrict__ dy,
+                                                             int64_t ldy, const T* __restrict__ add, int64_t lda, T* __restrict__ dx, int64_t ldd,
+                                                             float* __restrict__ partial_w, float* __restrict__ partial_b, int64_t rows, int cols, float eps) {
+  extern __shared__ float red[];              // [2][4][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = cols / 8;
+  float dwp[LN_MAXV][8], dbp[LN_MAXV][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dwp[i][j] = 0.f; dbp[i][j] = 0.f; }
+  for (int round = 0; round < TG_RPB / 4; ++round) {
+    const int64_t row = (int64_t)blockIdx.x * TG_RPB + round * 4 + wave;
+    if (row >= rows) break;
+    uint4 xv[LN_MAXV], gv[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+        xv[i] = *reinterpret_cast<const uint4*>(x + row * ldx + k * 8);
+        gv[i] = *reinterpret_cast<const uint4*>(dy + row * ldy + k * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += vec_get<T>(xv[i], j);
+      }
+    }
+    const float mean = wave_sum_f(sum) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = vec_get<T>(xv[i], j) - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum_f(q) / (float)cols + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (vec_get<T>(xv[i], j) - mean) * rstd, d = vec_get<T>(gv[i], j), g = d * vec_get<T>(wv, j);
+          sg += g;
+          sgx = fmaf(g, xh, sgx);
+          dwp[i][j] = fmaf(d, xh, dwp[i][j]);
+          dbp[i][j] += d;
+        }
+      }
+    }
+    sg = wave_sum_f(sg) / (float)cols;
+    sgx = wave_sum_f(sgx) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
+        uint4 av = make_uint4(0, 0, 0, 0);
+        if (add) av = *reinterpret_cast<const uint4*>(add + row * lda + k * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (vec_get<T>(xv[i], j) - mean) * rstd, g = vec_get<T>(gv[i], j) * vec_get<T>(wv, j);
+          o[j] = rstd * (g - sg - xh * sgx);
+          if (add) o[j] = round_to<T>(o[j]) + vec_get<T>(av, j);
+        }
+        *reinterpret_cast<uint4*>(dx + row * ldd + k * 8) = vec_pack<T>(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int k = i * 64 + lane;
+    if (k < nv)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[wave * cols + k * 8 + j] = dwp[i][j]; red[(4 + wave) * cols + k * 8 + j] = dbp[i][j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    partial_w[(int64_t)blockIdx.x * cols + c] = ((red[c] + red[cols + c]) + red[2 * cols + c]) + red[3 * cols + c];
+    partial_b[(int64_t)blockIdx.x * cols + c] = ((red[4 * cols + c] + red[5 * cols + c]) + red[6 * cols + c]) + red[7 * cols + c];
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -735,4 +827,32 @@ extern "C" int v3d_gelu_grad(const void* z, int64_t ldz, const void* dy, int64_t
                              int dtype, void* stream) {
   V3D_REQUIRE(dy, "v3d_gelu_grad: null pointer");
   return gelu_launch(z, ldz, dy, ldy, dz, ldo, rows, cols, tanh_form, dtype, stream, "v3d_gelu_grad");
+}
+
+extern "C" int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight, const void* dy, int64_t ldy, const void* add, int64_t lda,
+                                  void* dx, int64_t ldd, float* workspace, void* dweight, void* dbias, int dw_dtype, int64_t rows, int cols,
+                                  float eps, int dtype, void* stream) {
+  V3D_REQUIRE(x && weight && dy && dx && workspace && dweight && dbias, "v3d_layernorm_grad: null pointer");
+  V3D_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAXV * 512, "v3d_layernorm_grad: cols=%d unsupported", cols);
+  V3D_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldd % 8 == 0 && (!add || lda % 8 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) &&
+              aligned16(weight) && aligned16(add), "v3d_layernorm_grad: alignment");
+  const int64_t n_part = (rows + TG_RPB - 1) / TG_RPB;
+  V3D_REQUIRE(n_part < (1ll << 31), "v3d_layernorm_grad: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  float* pw = workspace;
+  float* pb = workspace + n_part * cols;
+  const size_t lds = (size_t)8 * cols * sizeof(float);
+  V3D_DISPATCH_HALF(dtype, {
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)layernorm_grad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * LN_MAXV * 512 * 4);
+      if (e != hipSuccess) { set_error("v3d_layernorm_grad: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; }
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(layernorm_grad_kernel<T>, dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight, (const T*)dy, ldy,
+                       (const T*)add, lda, (T*)dx, ldd, pw, pb, rows, cols, eps);
+  });
+  if (int e = check_launch("v3d_layernorm_grad")) return e;
+  if (int e = colsum_final(pw, n_part, cols, dweight, dw_dtype, st, "v3d_layernorm_grad")) return e;
+  return colsum_final(pb, n_part, cols, dbias, dw_dtype, st, "v3d_layernorm_grad");
 }

@@ -92,14 +92,15 @@ SIGNATURES = {
     "v3d_causal_softmax_rows": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_f, c_i, c_p]),
     "v3d_softmax_grad_rows": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_f, c_i, c_p]),
     "v3d_attention_train": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_i, c_i, c_i,
-                                  c_i, c_f, c_p]),
-    "v3d_attention_backward_workspace_bytes": (c_l, [c_i, c_i]),
-    "v3d_attention_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
-                                     c_f, c_p, c_l, c_p]),
+                                  c_i, c_i, c_f, c_p]),
+    "v3d_attention_backward_workspace_bytes": (c_l, [c_i, c_i, c_i]),
+    "v3d_attention_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
+                                     c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_i, c_f, c_p, c_l, c_p]),
     "v3d_adamw_step": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
     "v3d_embed_grad": (c_i, [c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_i, c_p]),
     "v3d_gelu": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
     "v3d_gelu_grad": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
+    "v3d_layernorm_grad": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),
     "v3d_gemm_plan_host": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "v3d_voxel_keys_f32": (c_i, [c_p, c_l, c_f, c_p, c_p]),

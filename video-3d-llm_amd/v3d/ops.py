@@ -768,27 +768,28 @@ def softmax_grad_rows(p, dp, scale, out=None):
     return out
 
 
-def attention_train(qkv, out, S, n_q, n_kv, scale):
-    """Causal GQA attention (head dim 128) over one sequence whose rotated q | k | v sit side by side in qkv [>= S, (n_q + 2 n_kv) 128];
-    out [S, n_q 128].  Returns the row log-sum-exp [n_q, S] f32 (scaled log2 units) that attention_backward needs."""
+def attention_train(qkv, out, S, n_q, n_kv, scale, B=1, causal=True):
+    """Attention (head dim 128) over B sequences of S rows whose q | k | v sit side by side in qkv [>= B S, (n_q + 2 n_kv) 128] (sequence b =
+    rows [b S, (b + 1) S)); out [B S, n_q 128].  Returns the row log-sum-exp [B, n_q, S] f32 (scaled log2 units) for attention_backward."""
     qkv = _dev(qkv, "qkv")
     w = qkv.stride(0)
-    lse = torch.empty((n_q, S), dtype=torch.float32, device=qkv.device)
-    check(lib().v3d_attention_train(_p(qkv), _p(qkv[:, n_q * 128:]), _p(qkv[:, (n_q + n_kv) * 128:]), _p(out), _p(lse), _code(qkv), 1, S, S,
-                                    n_q, n_kv, w, w, w, out.stride(0), 0, 0, 0, 128, 128, 128, 0, float(scale), _stream()), "v3d_attention_train")
+    lse = torch.empty((B, n_q, S), dtype=torch.float32, device=qkv.device)
+    check(lib().v3d_attention_train(_p(qkv), _p(qkv[:, n_q * 128:]), _p(qkv[:, (n_q + n_kv) * 128:]), _p(out), _p(lse), _code(qkv), B, S, S,
+                                    n_q, n_kv, w, w, w, out.stride(0), S * w, S * w, S * out.stride(0), 128, 128, 128, 1 if causal else 0, 0,
+                                    float(scale), _stream()), "v3d_attention_train")
     return lse
 
 
-def attention_backward(qkv, out, dout, lse, dqkv, S, n_q, n_kv, scale):
-    """Gradients of attention_train with respect to the rotated q | k | v, written side by side into dqkv [S, (n_q + 2 n_kv) 128]."""
+def attention_backward(qkv, out, dout, lse, dqkv, S, n_q, n_kv, scale, B=1, causal=True):
+    """Gradients of attention_train with respect to q | k | v, written side by side into dqkv [B S, (n_q + 2 n_kv) 128]."""
     qkv, dout = _dev(qkv, "qkv"), _dev(dout, "dout")
-    w, dw = qkv.stride(0), dqkv.stride(0)
-    nbytes = lib().v3d_attention_backward_workspace_bytes(S, n_q)
+    w, dw, so, sd = qkv.stride(0), dqkv.stride(0), out.stride(0), dout.stride(0)
+    nbytes = lib().v3d_attention_backward_workspace_bytes(B, S, n_q)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device)
     check(lib().v3d_attention_backward(_p(qkv), _p(qkv[:, n_q * 128:]), _p(qkv[:, (n_q + n_kv) * 128:]), _p(out), _p(dout), _p(lse),
-                                       _p(dqkv), _p(dqkv[:, n_q * 128:]), _p(dqkv[:, (n_q + n_kv) * 128:]), _code(qkv), S, n_q, n_kv,
-                                       w, w, w, out.stride(0), dout.stride(0), dw, dw, dw, float(scale), _p(ws), nbytes, _stream()),
-          "v3d_attention_backward")
+                                       _p(dqkv), _p(dqkv[:, n_q * 128:]), _p(dqkv[:, (n_q + n_kv) * 128:]), _code(qkv), B, S, n_q, n_kv,
+                                       w, w, w, so, sd, dw, dw, dw, S * w, S * w, S * w, S * so, S * sd, S * dw, S * dw, S * dw,
+                                       1 if causal else 0, float(scale), _p(ws), nbytes, _stream()), "v3d_attention_backward")
     return dqkv
 
 
@@ -833,3 +834,19 @@ def gelu_grad(z, dy, tanh_form=False):
     check(lib().v3d_gelu_grad(_p(z), z.stride(0), _p(dy), dy.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], 1 if tanh_form else 0,
                               _code(z), _stream()), "v3d_gelu_grad")
     return out
+
+
+def layernorm_grad(x, weight, dy, eps=1e-6, add=None, dw_dtype=None):
+    """Backward of layernorm: returns (dx [rows, cols] (+ add), dweight [cols], dbias [cols])."""
+    x, dy = _dev(x, "x"), _dev(dy, "dy")
+    rows, cols = x.shape
+    if tuple(dy.shape) != (rows, cols) or (add is not None and tuple(add.shape) != (rows, cols)):
+        raise V3DError("layernorm_grad: dy / add must have x's shape")
+    dx = torch.empty((rows, cols), dtype=x.dtype, device=x.device)
+    dw = torch.empty(cols, dtype=dw_dtype or x.dtype, device=x.device)
+    db = torch.empty(cols, dtype=dw_dtype or x.dtype, device=x.device)
+    ws = torch.empty(max(1, 2 * lib().v3d_colsum_workspace_bytes(rows, cols) // 4), dtype=torch.float32, device=x.device)
+    check(lib().v3d_layernorm_grad(_p(x), x.stride(0), _p(weight), _p(dy), dy.stride(0), _p(add), add.stride(0) if add is not None else 0,
+                                   _p(dx), dx.stride(0), _p(ws), _p(dw), _p(db), _DT[dw.dtype], rows, cols, eps, _code(x), _stream()),
+          "v3d_layernorm_grad")
+    return dx, dw, db

@@ -250,3 +250,76 @@ def inputs_embeds_backward(dx, n_pre, frames, text_rows, text_ids, embed_grad_ou
     dfeat, dnl = ops.visual_tokens_grad(dx[n_pre:n_pre + n_vis], frames, side=side, n=n, newline=True)
     ops.embed_grad(dx, text_rows, text_ids, embed_grad_out)
     return dfeat, dnl
+
+
+# ------------------------------------------------------------------------------ the SigLIP tower (mm_vision_tower is tuned too, train_multi.sh:44)
+
+SIGLIP_HD, SIGLIP_PAD = 72, 128
+
+
+def siglip_pad_layer(sd, heads=16, inter_pad=4352):
+    """A SigLIP encoder layer's checkpoint tensors (siglip_encoder.py:197-305: q/k/v/out_proj, fc1/fc2, two LayerNorms) in the training
+    layout: heads zero-padded 72 -> 128 so that attention runs on the head-dim-128 kernels (padded q / k columns add 0 to the scores,
+    padded v columns produce zero output columns, and every padded weight row / column receives a zero gradient), fc1 / fc2 padded
+    4304 -> 4352 (a multiple of 128 for the GEMM; gelu(0) = 0)."""
+    H = sd["q_w"].shape[1]
+    dt, dev = sd["q_w"].dtype, sd["q_w"].device
+
+    def pad_rows(w, b):
+        wp = torch.zeros((heads * SIGLIP_PAD, H), dtype=dt, device=dev)
+        bp = torch.zeros(heads * SIGLIP_PAD, dtype=dt, device=dev)
+        wp.view(heads, SIGLIP_PAD, H)[:, :SIGLIP_HD] = w.view(heads, SIGLIP_HD, H)
+        bp.view(heads, SIGLIP_PAD)[:, :SIGLIP_HD] = b.view(heads, SIGLIP_HD)
+        return wp, bp
+
+    ws, bs = zip(*(pad_rows(sd[n + "_w"], sd[n + "_b"]) for n in ("q", "k", "v")))
+    wo = torch.zeros((H, heads * SIGLIP_PAD), dtype=dt, device=dev)
+    wo.view(H, heads, SIGLIP_PAD)[:, :, :SIGLIP_HD] = sd["o_w"].view(H, heads, SIGLIP_HD)
+    inter = sd["fc1_w"].shape[0]
+    fc1 = torch.zeros((inter_pad, H), dtype=dt, device=dev)
+    fc1[:inter] = sd["fc1_w"]
+    b1 = torch.zeros(inter_pad, dtype=dt, device=dev)
+    b1[:inter] = sd["fc1_b"]
+    fc2 = torch.zeros((H, inter_pad), dtype=dt, device=dev)
+    fc2[:, :inter] = sd["fc2_w"]
+    return {"ln1_w": sd["ln1_w"], "ln1_b": sd["ln1_b"], "qkv": torch.cat(ws).contiguous(), "qkv_b": torch.cat(bs).contiguous(), "o": wo, "o_b": sd["o_b"],
+            "ln2_w": sd["ln2_w"], "ln2_b": sd["ln2_b"], "fc1": fc1, "fc1_b": b1, "fc2": fc2, "fc2_b": sd["fc2_b"]}
+
+
+def siglip_unpad_grads(g, heads=16, inter=4304):
+    """Gradients of siglip_pad_layer's tensors back in the checkpoint's shapes (the padding's gradients are zero and dropped)."""
+    H = g["qkv"].shape[1]
+    q, k, v = (t.view(heads, SIGLIP_PAD, H)[:, :SIGLIP_HD].reshape(heads * SIGLIP_HD, H) for t in g["qkv"].view(3, heads * SIGLIP_PAD, H))
+    qb, kb, vb = (t.view(heads, SIGLIP_PAD)[:, :SIGLIP_HD].reshape(-1) for t in g["qkv_b"].view(3, heads * SIGLIP_PAD))
+    return {"q_w": q, "k_w": k, "v_w": v, "q_b": qb, "k_b": kb, "v_b": vb, "o_w": g["o"].view(H, heads, SIGLIP_PAD)[:, :, :SIGLIP_HD].reshape(H, -1),
+            "o_b": g["o_b"], "fc1_w": g["fc1"][:inter], "fc1_b": g["fc1_b"][:inter], "fc2_w": g["fc2"][:, :inter], "fc2_b": g["fc2_b"],
+            "ln1_w": g["ln1_w"], "ln1_b": g["ln1_b"], "ln2_w": g["ln2_w"], "ln2_b": g["ln2_b"]}
+
+
+def siglip_layer_forward(x, p, frames, tokens=729, heads=16, eps=1e-6):
+    """SigLipEncoderLayer.forward (siglip_encoder.py:264-305) on x [frames * tokens, 1152]; p from siglip_pad_layer."""
+    n1 = ops.layernorm(x, p["ln1_w"], p["ln1_b"], eps)
+    qkv = ops.gemm(n1, p["qkv"], bias=p["qkv_b"], epilogue=ops.EPI_BIAS)
+    o = torch.empty((x.shape[0], heads * SIGLIP_PAD), dtype=x.dtype, device=x.device)
+    lse = ops.attention_train(qkv, o, tokens, heads, heads, SIGLIP_HD ** -0.5, B=frames, causal=False)
+    mid = ops.gemm(o, p["o"], bias=p["o_b"], res=x, epilogue=ops.EPI_BIAS_RES)
+    n2 = ops.layernorm(mid, p["ln2_w"], p["ln2_b"], eps)
+    z = ops.gemm(n2, p["fc1"], bias=p["fc1_b"], epilogue=ops.EPI_BIAS)
+    a = ops.gelu(z, tanh_form=True)
+    out = ops.gemm(a, p["fc2"], bias=p["fc2_b"], res=mid, epilogue=ops.EPI_BIAS_RES)
+    return out, (x, n1, qkv, o, lse, mid, n2, z, a)
+
+
+def siglip_layer_backward(dout, saved, p, frames, tokens=729, heads=16, eps=1e-6):
+    x, n1, qkv, o, lse, mid, n2, z, a = saved
+    da, d_fc2, d_b2 = linear_backward(a, p["fc2"], dout, need_db=True)
+    dz = ops.gelu_grad(z, da, tanh_form=True)
+    dn2, d_fc1, d_b1 = linear_backward(n2, p["fc1"], dz, need_db=True)
+    dmid, d_ln2w, d_ln2b = ops.layernorm_grad(mid, p["ln2_w"], dn2, eps, add=dout)
+    do, d_o, d_ob = linear_backward(o, p["o"], dmid, need_db=True)
+    dqkv = torch.empty_like(qkv)
+    ops.attention_backward(qkv, o, do, lse, dqkv, tokens, heads, heads, SIGLIP_HD ** -0.5, B=frames, causal=False)
+    dn1, d_qkv, d_qkvb = linear_backward(n1, p["qkv"], dqkv, need_db=True)
+    dx, d_ln1w, d_ln1b = ops.layernorm_grad(x, p["ln1_w"], dn1, eps, add=dmid)
+    return dx, {"ln1_w": d_ln1w, "ln1_b": d_ln1b, "qkv": d_qkv, "qkv_b": d_qkvb, "o": d_o, "o_b": d_ob, "ln2_w": d_ln2w, "ln2_b": d_ln2b,
+                "fc1": d_fc1, "fc1_b": d_b1, "fc2": d_fc2, "fc2_b": d_b2}
