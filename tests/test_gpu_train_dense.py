@@ -445,3 +445,88 @@ def test_siglip_layer_forward_and_backward_match_autograd(train):
             assert float(real[k].float().abs().max()) <= 0.04 * float(leaves["q_b"].grad.abs().max())
             continue
         _close(real[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)
+
+
+def test_whole_sample_step_matches_autograd(ops, train):
+    """SigLIP tower (2 layers at true width, 2 frames) -> mm_projector -> pool + 3-D PE + newline, spliced between text rows -> a 2-layer
+    Qwen2 with labels: loss and the gradient of EVERY parameter group against autograd over the reference's composition in f32
+    (llava_qwen.py:121-205, llava_arch.py:191-210, 307-328, 506-517, 650-836)."""
+    frames, tokens, Hv, heads, inter, kpad = 2, 729, 1152, 16, 4304, 640
+    H, I, n_q, n_kv, hd, V, L = 768, 1024, 4, 2, 128, 1024, 2
+    g = torch.Generator().manual_seed(77)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
+    ln = lambda n_: (1 + 0.1 * torch.randn(n_, generator=g)).to(torch.bfloat16)
+
+    def vit_layer():
+        return {"ln1_w": ln(Hv), "ln1_b": mk(Hv, s=0.1), "ln2_w": ln(Hv), "ln2_b": mk(Hv, s=0.1),
+                "q_w": mk(Hv, Hv, s=Hv ** -0.5), "q_b": mk(Hv, s=0.2), "k_w": mk(Hv, Hv, s=Hv ** -0.5), "k_b": mk(Hv, s=0.2),
+                "v_w": mk(Hv, Hv, s=Hv ** -0.5), "v_b": mk(Hv, s=0.2), "o_w": mk(Hv, Hv, s=Hv ** -0.5), "o_b": mk(Hv, s=0.2),
+                "fc1_w": mk(inter, Hv, s=Hv ** -0.5), "fc1_b": mk(inter, s=0.2), "fc2_w": mk(Hv, inter, s=inter ** -0.5), "fc2_b": mk(Hv, s=0.2)}
+
+    vit = [vit_layer() for _ in range(2)]
+    patch_w, patch_b, pos = mk(Hv, kpad, s=588 ** -0.5), mk(Hv, s=0.1), mk(tokens, Hv, s=0.5)
+    patch_w[:, 588:] = 0                                                     # the k padding of the patch convolution's GEMM
+    proj = {"w1": mk(H, Hv, s=Hv ** -0.5), "b1": mk(H, s=0.1), "w2": mk(H, H, s=H ** -0.5), "b2": mk(H, s=0.1)}
+    newline, embed = mk(H, s=0.5), mk(V, H, s=0.5)
+    width = (n_q + 2 * n_kv) * hd
+    layers = [{"ln1": ln(H), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.3), "o": mk(H, n_q * hd, s=(n_q * hd) ** -0.5),
+               "ln2": ln(H), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    llm = {"layers": layers, "norm": ln(H), "lm_head": mk(V, H, s=H ** -0.5)}
+    patches = mk(frames * tokens, kpad)
+    patches[:, 588:] = 0
+    ids = torch.randint(0, 64, (frames, 14, 14, 3), generator=g, dtype=torch.int32)
+    pre_ids, post_ids = torch.randint(0, V, (9,), generator=g), torch.randint(0, V, (31,), generator=g)
+    post_ids[3] = pre_ids[2]                                                 # a token that occurs on both sides of <image>
+    n_vis = frames * 14 * 15
+    S = 9 + n_vis + 31
+    labels = torch.full((S,), -100, dtype=torch.int64)
+    labels[S - 20:] = torch.randint(0, V, (20,), generator=g)
+
+    # ---- device
+    table = ops.Sin3DTable(H, 64, torch.bfloat16, "cuda")
+    pe = ops.sin3d_pe(ids.view(frames, 196, 3).to(torch.bfloat16).cuda(), H).float().cpu()          # the PE rows as constants of the reference
+    rope = train.RopeTables(hd, 1024, 1e6, torch.bfloat16, "cuda")
+    cu = lambda t: train._tree_map(lambda a: a.cuda(), t)
+    params = {"vision": {"patch_w": patch_w.cuda(), "patch_b": patch_b.cuda(), "pos": pos.cuda(), "layers": [train.siglip_pad_layer(cu(l)) for l in vit]},
+              "projector": cu(proj), "newline": newline.cuda(), "embed": embed.cuda(), "llm": cu(llm)}
+    loss, grads = train.sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), labels.cuda(), rope,
+                                                frames, n_q, n_kv, hd)
+
+    # ---- reference (f32 autograd over the same 16-bit parameters)
+    f32 = lambda t: train._tree_map(lambda a: a.float().requires_grad_(), t)
+    r_vit, r_proj, r_llm = f32(vit), f32(proj), f32(llm)
+    r_pw, r_pb, r_pos, r_nl, r_emb = (t.float().requires_grad_() for t in (patch_w, patch_b, pos, newline, embed))
+    h = (patches.float() @ r_pw.t() + r_pb).view(frames, tokens, Hv) + r_pos
+    h = h.view(frames * tokens, Hv)
+    for sd in r_vit:
+        h = _siglip_layer_ref(h, sd, frames, tokens, heads)
+    y = F.gelu(h @ r_proj["w1"].t() + r_proj["b1"]) @ r_proj["w2"].t() + r_proj["b2"]
+    pooled = F.interpolate(y.view(frames, 27, 27, H).permute(0, 3, 1, 2), size=[14, 14], mode="bilinear").permute(0, 2, 3, 1)
+    tok = pooled + pe.view(frames, 14, 14, H)
+    vis = torch.cat([tok, r_nl[None, None, None, :].expand(frames, 14, 1, H)], 2).reshape(-1, H)
+    x = torch.cat([r_emb[pre_ids], vis, r_emb[post_ids]], 0)
+    for p in r_llm["layers"]:
+        x = _layer_ref(x, p, n_q, n_kv, hd, 1e-6)
+    logits = _rmsnorm_ref(x, r_llm["norm"], 1e-6) @ r_llm["lm_head"].t()
+    ref_loss = F.cross_entropy(logits[:-1], labels[1:], ignore_index=-100)
+    ref_loss.backward()
+
+    assert abs(float(loss) - float(ref_loss.detach())) < 3e-2 * float(ref_loss.detach())
+    tol = (4e-2, 1e-1)                                   # four normalised blocks deep in 16-bit storage
+    _close(grads["newline"], r_nl.grad, *tol, "d newline")
+    _close(grads["embed"], r_emb.grad, *tol, "d embed")
+    for k in proj:
+        _close(grads["projector"][k], r_proj[k].grad, *tol, "d projector " + k)
+    _close(grads["vision"]["pos"], r_pos.grad, *tol, "d position embedding")
+    _close(grads["vision"]["patch_w"][:, :588], r_pw.grad[:, :588], *tol, "d patch weight")
+    _close(grads["vision"]["patch_b"], r_pb.grad, *tol, "d patch bias")
+    for i in range(2):
+        real = train.siglip_unpad_grads(grads["vision"]["layers"][i])
+        for k in vit[i]:
+            if k == "k_b":
+                continue                                  # no gradient (see the layer test)
+            _close(real[k], r_vit[i][k].grad, *tol, f"vit layer {i} d {k}")
+    for i in range(L):
+        for k in layers[i]:
+            _close(grads["llm"]["layers"][i][k], r_llm["layers"][i][k].grad, *tol, f"llm layer {i} d {k}")
+    _close(grads["llm"]["lm_head"], r_llm["lm_head"].grad, *tol, "d lm_head")

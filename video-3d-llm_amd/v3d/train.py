@@ -323,3 +323,53 @@ def siglip_layer_backward(dout, saved, p, frames, tokens=729, heads=16, eps=1e-6
     dx, d_ln1w, d_ln1b = ops.layernorm_grad(x, p["ln1_w"], dn1, eps, add=dmid)
     return dx, {"ln1_w": d_ln1w, "ln1_b": d_ln1b, "qkv": d_qkv, "qkv_b": d_qkvb, "o": d_o, "o_b": d_ob, "ln2_w": d_ln2w, "ln2_b": d_ln2b,
                 "fc1": d_fc1, "fc1_b": d_b1, "fc2": d_fc2, "fc2_b": d_b2}
+
+
+def siglip_tower_forward(patches, vp, frames, tokens=729):
+    """SigLipVisionEmbeddings (the patch convolution as a GEMM over v3d_patchify's rows + the position embedding, siglip_encoder.py:148-190)
+    and the encoder layers the projector reads (hidden_states[-2]: all but the last layer, siglip_encoder.py:576-589).
+    vp: {"patch_w" [1152, kpad], "patch_b", "pos" [tokens, 1152], "layers": [siglip_pad_layer dicts]}."""
+    h = ops.gemm(patches, vp["patch_w"], bias=vp["patch_b"], res=vp["pos"], res_mod=tokens, epilogue=ops.EPI_BIAS_RES)
+    saved = []
+    for p in vp["layers"]:
+        h, s = siglip_layer_forward(h, p, frames, tokens)
+        saved.append(s)
+    return h, (patches, saved)
+
+
+def siglip_tower_backward(dh, saved, vp, frames, tokens=729):
+    patches, layer_saved = saved
+    grads = [None] * len(layer_saved)
+    for i in range(len(layer_saved) - 1, -1, -1):
+        dh, grads[i] = siglip_layer_backward(dh, layer_saved[i], vp["layers"][i], frames, tokens)
+        layer_saved[i] = None
+    d_pos = ops.colsum(dh.view(frames, -1)).view(tokens, -1)           # the position embedding is added to every frame
+    _, d_patch_w, d_patch_b = linear_backward(patches, vp["patch_w"], dh, need_dx=False, need_db=True)
+    return {"patch_w": d_patch_w, "patch_b": d_patch_b, "pos": d_pos, "layers": grads}
+
+
+def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_ids, labels, rope, frames, n_q, n_kv, hd, tokens=729, side=27, n=14):
+    """One training sample end to end on the device (llava_qwen.py:121-205 -> llava_arch.py:336-836 -> modeling_qwen2.py:1145-1217):
+    SigLIP tower -> mm_projector -> bilinear pool + 3-D PE + newline rows, spliced between the embedded text rows -> Qwen2 with labels;
+    then the backward of all of it.  params: {"vision", "projector": {w1, b1, w2, b2}, "newline" [H], "embed" [vocab, H], "llm"};
+    patches [frames * tokens, kpad] (v3d_patchify of the preprocessed frames), voxel_ids [frames, n, n, 3] int32 (the discretised patch
+    coordinates: no gradient, llava_arch.py:515), pre_ids / post_ids: the text token ids around <image> (device int64), labels [S].
+    Returns (loss, grads in params' structure; "embed" is a dense [vocab, H] gradient with the text rows' sums)."""
+    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens)
+    pj = params["projector"]
+    y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
+    H = y.shape[1]
+    n_pre, n_post, n_vis = pre_ids.numel(), post_ids.numel(), frames * n * (n + 1)
+    x = torch.empty((n_pre + n_vis + n_post, H), dtype=y.dtype, device=y.device)
+    if n_pre:
+        ops.embed_gather(params["embed"], pre_ids, out=x[:n_pre])
+    ops.visual_tokens(y.view(frames, tokens, H), voxel_ids, pe_table, params["newline"], side=side, n=n, pool=True, out=x[n_pre:n_pre + n_vis])
+    if n_post:
+        ops.embed_gather(params["embed"], post_ids, out=x[n_pre + n_vis:])
+    loss, dx, llm_grads = llm_forward_backward(params["llm"], x, labels, rope, n_q, n_kv, hd)
+    d_embed = torch.zeros_like(params["embed"])
+    text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
+    dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
+    dfeat_in, pgrads = projector_backward(dfeat.view(frames * tokens, H), psaved, pj["w1"], pj["w2"])
+    vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
+    return loss, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed, "llm": llm_grads}
