@@ -11,7 +11,7 @@ in HBM before the timed region).  Every scene runs the complete path; scenes are
 (--decode-group, default 16) that share each pass over the weights.
 The default N = 1 line also carries `roofline` (the dominant kernel: the Qwen2 gate/up GEMM, MFMA), `roofline_north_star` (3D-PE +
 fusion kernel, HBM), `roofline_attention`, `fp8_config3` (the same step with e4m3 LLM weights, BASELINE configs[3]),
-`train_config4` (the language model's training step on one GPU: forward with labels + backward + AdamW, v3d/train.py),
+`train_config4` (one training sample end to end on one GPU: tower + projector + Qwen2 with labels, backward, AdamW; v3d/train.py),
 `cached_questions` (scene-level reuse, SURVEY 8 f1: further questions about an already prefilled scene), `ground_config2`
 (the ScanRefer / Multi3DRefer grounding forward at 32 frames / 50 proposals, BASELINE configs[2], one GPU) and `cpu_baseline`.
 
@@ -247,31 +247,51 @@ def measure_grounding(eng, ops, scenes, dev, steps):
     return steps / (time.perf_counter() - t0)
 
 
-def measure_train_step(dev, steps=2, S=TEXT_PRE + FRAMES * 210 + TEXT_POST, answer_tokens=64):
-    """BASELINE configs[4], the language model's part on ONE GPU (no ZeRO exchange): Qwen2-7B forward with labels + backward + AdamW
-    (v3d/train.py) over one sequence of the path's length, random-init bf16 weights, f32 master weights and moments."""
-    from v3d import train
+def measure_train_step(dev, steps=2, answer_tokens=64):
+    """BASELINE configs[4] on ONE GPU (no ZeRO exchange): one training sample end to end - SigLIP-so400m (26 layers, 32 frames) ->
+    mlp2x_gelu -> pool + 3-D PE + newline rows spliced between the text rows -> Qwen2-7B with labels, backward of all of it, AdamW on every
+    parameter (v3d/train.py: sample_forward_backward, AdamW); random-init bf16 weights, f32 master weights and moments."""
+    from v3d import ops, train
     L, H, I, n_q, n_kv, hd, V = 28, 3584, 18944, 28, 4, 128, 152064
+    Lv, Hv, Iv, heads, tokens, kpad = 26, 1152, 4304, 16, 729, 640
     width = (n_q + 2 * n_kv) * hd
     dt = torch.bfloat16
 
     def mk(*shape, s=1.0):
         return torch.empty(*shape, device=dev, dtype=dt).normal_(0.0, s)
 
-    ones = lambda: torch.ones(H, device=dev, dtype=dt)
-    layers = [{"ln1": ones(), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.1), "o": mk(H, n_q * hd, s=H ** -0.5),
-               "ln2": ones(), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
-    params = {"layers": layers, "norm": ones(), "lm_head": mk(V, H, s=H ** -0.5)}
+    ones = lambda n_: torch.ones(n_, device=dev, dtype=dt)
+    layers = [{"ln1": ones(H), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.1), "o": mk(H, n_q * hd, s=H ** -0.5),
+               "ln2": ones(H), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    llm = {"layers": layers, "norm": ones(H), "lm_head": mk(V, H, s=H ** -0.5)}
+
+    def vit_layer():
+        sd = {"ln1_w": ones(Hv), "ln1_b": mk(Hv, s=0.02), "ln2_w": ones(Hv), "ln2_b": mk(Hv, s=0.02), "o_w": mk(Hv, Hv, s=Hv ** -0.5), "o_b": mk(Hv, s=0.02),
+              "fc1_w": mk(Iv, Hv, s=Hv ** -0.5), "fc1_b": mk(Iv, s=0.02), "fc2_w": mk(Hv, Iv, s=Iv ** -0.5), "fc2_b": mk(Hv, s=0.02)}
+        for n_ in ("q", "k", "v"):
+            sd[n_ + "_w"], sd[n_ + "_b"] = mk(Hv, Hv, s=Hv ** -0.5), mk(Hv, s=0.02)
+        return train.siglip_pad_layer(sd)
+
+    patch_w = mk(Hv, kpad, s=588 ** -0.5)
+    patch_w[:, 588:] = 0
+    vision = {"patch_w": patch_w, "patch_b": mk(Hv, s=0.02), "pos": mk(tokens, Hv, s=0.02), "layers": [vit_layer() for _ in range(Lv)]}
+    params = {"vision": vision, "projector": {"w1": mk(H, Hv, s=Hv ** -0.5), "b1": mk(H, s=0.02), "w2": mk(H, H, s=H ** -0.5), "b2": mk(H, s=0.02)},
+              "newline": mk(H, s=0.02), "embed": mk(V, H, s=0.02), "llm": llm}
     rope = train.RopeTables(hd, 8192, 1e6, dt, dev)
+    table = ops.Sin3DTable(H, 512, dt, dev)
     opt = train.AdamW(params, lr=1e-5)
-    x = torch.empty(S, H, device=dev, dtype=dt).normal_()
+    patches = mk(FRAMES * tokens, kpad)
+    patches[:, 588:] = 0
+    ids = torch.randint(0, 512, (FRAMES, 14, 14, 3), device=dev, dtype=torch.int32)
+    pre_ids, post_ids = torch.randint(0, V, (TEXT_PRE,), device=dev), torch.randint(0, V, (TEXT_POST,), device=dev)
+    S = TEXT_PRE + FRAMES * 210 + TEXT_POST
     labels = torch.full((S,), -100, dtype=torch.int64, device=dev)
     labels[S - answer_tokens:] = torch.randint(0, V, (answer_tokens,), device=dev)
     fb, ad, first_loss = [], [], None
     for i in range(steps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        loss, dx, grads = train.llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd)
+        loss, grads = train.sample_forward_backward(params, patches, ids, table, pre_ids, post_ids, labels, rope, FRAMES, n_q, n_kv, hd)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         opt.step(params, grads)
@@ -279,19 +299,23 @@ def measure_train_step(dev, steps=2, S=TEXT_PRE + FRAMES * 210 + TEXT_POST, answ
         t2 = time.perf_counter()
         if first_loss is None:
             first_loss = float(loss)
-        del grads, dx
+        del grads
         if i:
             fb.append(t1 - t0)
             ad.append(t2 - t1)
-    n_par = sum(p.numel() for l in layers for p in l.values()) + H + V * H
+    n_llm = sum(p.numel() for l in layers for p in l.values()) + H + V * H
+    n_vit = Lv * (4 * Hv * Hv + 2 * Hv * Iv) + Hv * 588
+    n_proj = Hv * H + H * H
     ms = (sum(fb) + sum(ad)) / len(fb) * 1e3
-    flops = 6.0 * S * n_par + 3.5 * 2.0 * S * S * hd * n_q * L      # 6 N S for the linears; attention: 2 forward + 5 backward products, causal half
-    return {"what": "BASELINE configs[4], language-model part on one GPU (not the headline; no ZeRO exchange, no vision tower): Qwen2-7B forward "
-                    "with labels + backward + AdamW over one sequence of S=%d (%d answer tokens carry labels), random-init bf16 weights, "
-                    "f32 master weights / moments, all activations kept (no re-computation)" % (S, answer_tokens),
-            "value": S / (ms * 1e-3), "unit": "tokens/s", "ms_per_step": ms, "ms_forward_backward": sum(fb) / len(fb) * 1e3,
-            "ms_adamw": sum(ad) / len(ad) * 1e3, "model_tflops": flops / (ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0,
-            "first_loss": first_loss, "params": n_par, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+    T = FRAMES * tokens
+    flops = (6.0 * S * n_llm + 3.5 * 2.0 * S * S * hd * n_q * L              # linears 6 N S; causal attention: 2 forward + 5 backward products, halved
+             + 6.0 * T * (n_vit + n_proj) + 3.5 * 4.0 * FRAMES * tokens * tokens * 72 * heads * Lv)
+    return {"what": "BASELINE configs[4] on one GPU (not the headline; no ZeRO exchange): one training sample end to end - SigLIP-so400m (26 layers, "
+                    "%d frames) -> mlp2x_gelu -> pool + 3-D PE + newline -> Qwen2-7B with labels over S=%d (%d answer tokens carry labels), backward of "
+                    "all of it, AdamW on every parameter; random-init bf16 weights, f32 master weights / moments, all activations kept" % (FRAMES, S, answer_tokens),
+            "value": 1e3 / ms, "unit": "samples/s", "ms_per_step": ms, "ms_forward_backward": sum(fb) / len(fb) * 1e3, "ms_adamw": sum(ad) / len(ad) * 1e3,
+            "llm_tokens_per_s": S / (ms * 1e-3), "model_tflops": flops / (ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0, "first_loss": first_loss,
+            "params": n_llm + n_vit + n_proj + V * H + H, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
 
 
 def main():
