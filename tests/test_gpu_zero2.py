@@ -1,0 +1,88 @@
+"""ZeRO-2 rehearsal on ONE GPU (BASELINE configs[4]; scripts/zero2.json:22-34): two ranks share the card, exchange through gloo (flat
+buffers staged through host memory) and run the language model's step + ZeroAdamW.  Held to: both ranks end with identical
+parameters, and those equal - bit for bit - a single process that averages the two ranks' gradients the way the exchange does and
+runs the plain AdamW.  (The "nccl" = RCCL path keeps everything in HBM and has not run on hardware: there is one GPU per box here.)"""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+H, I, N_Q, N_KV, HD, V, L, S = 512, 1024, 4, 2, 128, 1024, 2, 96
+
+
+def _model(device):
+    g = torch.Generator().manual_seed(1234)
+    width = (N_Q + 2 * N_KV) * HD
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).to(device)
+    ln = lambda: (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(device)
+    layers = [{"ln1": ln(), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.3), "o": mk(H, N_Q * HD, s=(N_Q * HD) ** -0.5),
+               "ln2": ln(), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    return {"layers": layers, "norm": ln(), "lm_head": mk(V, H, s=H ** -0.5)}
+
+
+def _sample(rank, device):
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(S, H, generator=g).to(torch.bfloat16).to(device)
+    labels = torch.full((S,), -100, dtype=torch.int64)
+    labels[S // 2:] = torch.randint(0, V, (S - S // 2,), generator=g)
+    return x, labels.to(device)
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from v3d import train
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    params = _model(dev)
+    rope = train.RopeTables(HD, 256, 1e6, torch.bfloat16, dev)
+    opt = train.ZeroAdamW(params, lr=1e-3, weight_decay=0.01, bucket_elems=300000)      # several buckets
+    params = opt.params
+    for step in range(2):
+        x, labels = _sample(rank + 2 * step, dev)
+        loss, dx, grads = train.llm_forward_backward(params, x, labels, rope, N_Q, N_KV, HD)
+        params = opt.step(grads)
+    torch.cuda.synchronize()
+    torch.save(opt.flat[:opt.numel].cpu(), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_step_world2_equals_single_process_adamw_on_averaged_gradients():
+    from v3d import train
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as out_dir:
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        got = [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=True) for r in range(2)]
+    assert torch.equal(got[0], got[1])                                   # every rank holds the same model after the gather
+    # single process: the two ranks' gradients summed and averaged in the exchange's arithmetic (16-bit sum, then / world), plain AdamW
+    dev = "cuda:0"
+    params = _model(dev)
+    rope = train.RopeTables(HD, 256, 1e6, torch.bfloat16, dev)
+    opt = train.AdamW(params, lr=1e-3, weight_decay=0.01)
+    for step in range(2):
+        gs = []
+        for rank in range(2):
+            x, labels = _sample(rank + 2 * step, dev)
+            _, _, g = train.llm_forward_backward(params, x, labels, rope, N_Q, N_KV, HD)
+            gs.append(g)
+        flat0, flat1 = train._leaves(gs[0]), train._leaves(gs[1])
+        it = iter([((a.cpu() + b.cpu()) / 2).to(dev) for a, b in zip(flat0, flat1)])
+        avg = train._tree_map(lambda _: next(it), gs[0])
+        opt.step(params, avg)
+    want = torch.cat([p.reshape(-1) for p in train._leaves(params)]).cpu()
+    assert torch.equal(got[0], want)

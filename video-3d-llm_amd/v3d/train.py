@@ -373,3 +373,78 @@ def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_
     dfeat_in, pgrads = projector_backward(dfeat.view(frames * tokens, H), psaved, pj["w1"], pj["w2"])
     vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
     return loss, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed, "llm": llm_grads}
+
+
+# ------------------------------------------------------------------------------ ZeRO-2 (scripts/zero2.json:22-34)
+
+
+def _leaves(tree, out=None):
+    out = [] if out is None else out
+    if isinstance(tree, dict):
+        for k in tree:
+            _leaves(tree[k], out)
+    elif isinstance(tree, list):
+        for v in tree:
+            _leaves(v, out)
+    else:
+        out.append(tree)
+    return out
+
+
+class ZeroAdamW:
+    """DeepSpeed ZeRO stage 2 as the reference configures it (scripts/zero2.json:22-34: reduce_scatter true, 2e8-element buckets): every
+    rank keeps the whole 16-bit model, the ranks' gradients are reduce-scattered (averaged), each rank owns 1 / world of the f32 master
+    weights and AdamW moments and updates it (v3d_adamw_step), the updated 16-bit partitions are all-gathered.  The parameters live in ONE
+    flat 16-bit buffer (`params` is returned re-bound to views of it), so the gather writes them in place.
+    Exchanges: v3d.distributed.reduce_scatter_grads / all_gather_params over the process group ("nccl" = RCCL keeps everything in HBM;
+    with "gloo" - the one-GPU rehearsal of tests/test_gpu_zero2.py - the flat buffers are staged through host memory).
+    Not yet run on more than one GPU."""
+
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_elems=None, algorithm="ring"):
+        import torch.distributed as dist
+        from . import distributed as D
+        self.D, self.dist = D, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.host_staged = dist.get_backend() == "gloo"
+        self.lr, self.betas, self.eps, self.weight_decay, self.t = lr, betas, eps, weight_decay, 0
+        self.bucket = bucket_elems or D.ZERO2_BUCKET_ELEMS
+        self.algorithm = algorithm
+        leaves = _leaves(params)
+        self.numel = sum(p.numel() for p in leaves)
+        self.bounds, self.per = D.partition_bounds(self.numel, self.world)
+        dt, dev = leaves[0].dtype, leaves[0].device
+        self.flat = torch.zeros(self.per * self.world, dtype=dt, device=dev)            # padded so that every partition has `per` elements
+        off = 0
+        self.views = []
+        for p in leaves:
+            v = self.flat[off:off + p.numel()].view(p.shape)
+            v.copy_(p)
+            self.views.append(v)
+            off += p.numel()
+        it = iter(self.views)
+        self.params = _tree_map(lambda _: next(it), params)                            # the same tree over views of the flat buffer
+        b = self.rank * self.per
+        self.mine = self.flat[b:b + self.per]
+        self.master = self.mine.float()
+        self.m = torch.zeros_like(self.master)
+        self.v = torch.zeros_like(self.master)
+
+    def step(self, grads):
+        self.t += 1
+        flat_g = torch.zeros(self.per * self.world, dtype=self.flat.dtype, device=self.flat.device)
+        off = 0
+        for g in _leaves(grads):
+            flat_g[off:off + g.numel()].copy_(g.reshape(-1))
+            off += g.numel()
+        if self.host_staged:
+            part = self.D.reduce_scatter_grads(flat_g.cpu(), self.bucket, average=True, algorithm=self.algorithm).to(self.flat.device)
+        else:
+            part = self.D.reduce_scatter_grads(flat_g, self.bucket, average=True, algorithm=self.algorithm)
+        ops.adamw_step(self.master, self.m, self.v, part.contiguous(), p16=self.mine, lr=self.lr, betas=self.betas, eps=self.eps,
+                       weight_decay=self.weight_decay, step=self.t)
+        if self.host_staged:
+            full = self.D.all_gather_params(self.mine.cpu(), self.per * self.world, self.bucket).to(self.flat.device)
+        else:
+            full = self.D.all_gather_params(self.mine, self.per * self.world, self.bucket)
+        self.flat.copy_(full)
+        return self.params
