@@ -155,3 +155,34 @@ def test_gemm_split_k_plans_are_well_formed():
             cuts = [2 * (c * gpt // split) for c in range(split + 1)]
             assert cuts[0] == 0 and cuts[-1] == nt and all(b - a >= 2 for a, b in zip(cuts, cuts[1:]))
     assert seen > 50
+
+
+def test_training_entry_points_reject_bad_arguments_before_any_launch():
+    """Argument checks of the training step's entry points run on the host, before a kernel is launched: no GPU needed."""
+    import ctypes
+    l = _native.lib()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p = (p + 15) & ~15
+    bf16 = 2
+    bad = [
+        l.v3d_transpose(None, 8, 8, 8, p, 8, 8, bf16, None),                                   # null source
+        l.v3d_transpose(p, 12, 8, 12, p, 8, 8, bf16, None),                                    # cols % 8
+        l.v3d_transpose(p, 8, 8, 8, p, 8, 8, 0, None),                                         # f32: 16-bit only
+        l.v3d_colsum(p, 8, 4, 8, bf16, None, p, 0, None),                                      # null workspace
+        l.v3d_rmsnorm_grad(p, 8, p, p, 8, None, 0, p, 8, ctypes.cast(p, ctypes.c_void_p), p, 0, 4, 4096, 1e-6, bf16, None),    # cols > 3584
+        l.v3d_layernorm_grad(p, 8, p, p, 8, None, 0, p, 8, ctypes.cast(p, ctypes.c_void_p), p, p, 0, 4, 4096, 1e-6, bf16, None),  # cols > 2048
+        l.v3d_swiglu(p, 8, p, 8, 4, 8, bf16, None),                                            # row stride < 2 * inter
+        l.v3d_gelu(p, 8, p, 8, 4, 12, 0, bf16, None),                                          # cols % 8
+        l.v3d_causal_softmax_rows(p, 8, p, 8, 4, 16, 8, 0, 1.0, bf16, None),                   # n_keys > cols
+        l.v3d_attention_backward(p, p, p, p, p, ctypes.cast(p, ctypes.c_void_p), p, p, p, bf16, 1, 64, 3, 2, 512, 512, 512, 512, 512, 512, 512, 512,
+                                 0, 0, 0, 0, 0, 0, 0, 0, 1, 1.0, p, 1 << 30, None),             # 3 query heads over 2 kv heads
+        l.v3d_attention_backward(p, p, p, p, p, ctypes.cast(p, ctypes.c_void_p), p, p, p, bf16, 1, 64, 4, 2, 512, 512, 512, 512, 512, 512, 512, 512,
+                                 0, 0, 0, 0, 0, 0, 0, 0, 1, 1.0, p, 16, None),                  # workspace too small
+        l.v3d_adamw_step(ctypes.cast(p, ctypes.c_void_p), ctypes.cast(p, ctypes.c_void_p), ctypes.cast(p, ctypes.c_void_p), p, bf16, None, 0, 8, 1e-3, 0.9, 0.999,
+                         1e-8, 0.0, 0, 1.0, None),                                             # step counts from 1
+        l.v3d_embed_grad(p, 8, None, None, 1, 8, p, 8, bf16, None),                            # null index arrays
+    ]
+    assert all(rc < 0 for rc in bad), bad
+    assert l.v3d_attention_backward_workspace_bytes(2, 100, 4) == (2 * 4 * 100 + 2 * 2 * 4 * 100 * 128) * 4
+    assert l.v3d_colsum_workspace_bytes(65, 16) == 3 * 16 * 4
