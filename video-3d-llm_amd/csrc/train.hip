@@ -218,18 +218,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   for (int j = 0; j < 8; ++j) o[j] = s[j];
 }
 
-// out[c] = sum of the partials: thread (c, g) of a 64-column workgroup sums the partials b = g, g + 4, ... in order, the four
-// group sums are added in order (a fixed tree: run-to-run identical)
+// out[c] = sum of the partials: thread (c, g) of a 64-column workgroup (16 groups) sums the partials b = g, g + 16, ... in order, the
+// sixteen group sums are added in order (a fixed tree: run-to-run identical)
 template <typename TO>
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_part, int cols, TO* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_part, int cols, TO* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
   if (c < cols)
-    for (int64_t b = g; b < n_part; b += 4) s += partial[b * cols + c];
-  red[g][threadIdx.x & 63] = s;
+    for (int64_t b = g; b < n_part; b += 16) s += partial[b * cols + c];
+  red[g][cl] = s;
   __syncthreads();
-  if (g == 0 && c < cols) out[c] = from_f32<TO>(((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
+  if (g == 0 && c < cols) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) t += red[i][cl];
+    out[c] = from_f32<TO>(t);
+  }
 }
 
 // y = w * T(x r), r = rsqrt(mean(x^2) + eps).  With n = x r and g = dy w:  dx = r (g - n mean(g n)) [+ add],  dw = sum_rows dy n.
@@ -689,9 +695,9 @@ extern "C" int64_t v3d_colsum_workspace_bytes(int64_t rows, int cols) {
 static int colsum_final(const float* partial, int64_t n_part, int cols, void* out, int out_dtype, hipStream_t st, const char* what) {
   const dim3 grid((cols + 63) / 64);
   switch (out_dtype) {
-    case V3D_F32: hipLaunchKernelGGL(colsum_final_kernel<float>, grid, dim3(256), 0, st, partial, n_part, cols, (float*)out); break;
-    case V3D_F16: hipLaunchKernelGGL(colsum_final_kernel<f16_t>, grid, dim3(256), 0, st, partial, n_part, cols, (f16_t*)out); break;
-    case V3D_BF16: hipLaunchKernelGGL(colsum_final_kernel<bf16_t>, grid, dim3(256), 0, st, partial, n_part, cols, (bf16_t*)out); break;
+    case V3D_F32: hipLaunchKernelGGL(colsum_final_kernel<float>, grid, dim3(1024), 0, st, partial, n_part, cols, (float*)out); break;
+    case V3D_F16: hipLaunchKernelGGL(colsum_final_kernel<f16_t>, grid, dim3(1024), 0, st, partial, n_part, cols, (f16_t*)out); break;
+    case V3D_BF16: hipLaunchKernelGGL(colsum_final_kernel<bf16_t>, grid, dim3(1024), 0, st, partial, n_part, cols, (bf16_t*)out); break;
     default: set_error("%s: unknown output dtype %d", what, out_dtype); return V3D_E_INVALID;
   }
   return check_launch(what);
