@@ -1,17 +1,25 @@
-"""Backward of the decoder's dense blocks for the training step (BASELINE configs[4]): nn.Linear, Qwen2RMSNorm and
-Qwen2MLP (llava/model/language_model/qwen2/modeling_qwen2.py:76-90, 177-189, 771-789).  Every product runs on v3d_gemm
-(out = A . W^T): with y = x . W^T,
+"""The training step (BASELINE configs[4]) as a host-side mirror of LlavaQwenForCausalLM.forward(labels=...) +
+loss.backward() + the optimizer for one sample (llava_qwen.py:121-205, train_multi.sh:35-90), every operation a C-ABI call:
+
+    sample_forward_backward   SigLIP tower -> mm_projector -> pool + 3-D PE + newline rows spliced between text rows -> Qwen2 with labels
+    llm_forward_backward      the language model alone (decoder layers, final norm, LM head, shifted cross-entropy)
+    decoder_layer_* / attn_block_* / mlp_block_*, siglip_layer_* / siglip_tower_*, projector_*, inputs_embeds_backward
+    AdamW, ZeroAdamW          torch.optim.AdamW's update on f32 master weights; ZeRO-2 partitions over a process group
+
+Every product runs on v3d_gemm (out = A . W^T): with y = x . W^T (nn.Linear),
 
     dx = dy . W    = gemm(dy,   W^T)        W^T [K, N] by v3d_transpose
     dW = dy^T . x  = gemm(dy^T, x^T)        dy^T [N, Mp], x^T [K, Mp]: the token rows become the k dimension, zero-padded to 64
 
 so the backward costs two more products of the forward's size and three transposes.  Weights are in the checkpoint's layout
-(gate_proj / up_proj stacked as planar [gate | up] rows), not the inference engine's tile-interleaved one: the training forward has
-to keep gate and up for the backward, so SwiGLU is a pass of its own here (v3d_swiglu) instead of the GEMM epilogue.
+(gate_proj / up_proj stacked as planar [gate | up] rows; the tower's 72-wide heads zero-padded to 128 by siglip_pad_layer), not the
+inference engine's tile-interleaved one: the training forward has to keep gate and up for the backward, so SwiGLU is a pass of its
+own here (v3d_swiglu) instead of the GEMM epilogue.
 Attention backward exists in two forms: tiled kernels that recompute the probabilities from the forward's row log-sum-exp and never
 write an [S, S] matrix (v3d_attention_backward, csrc/attention_bwd.hip - the default), and the first, MATERIALISED form below
 (one head's probability matrix in HBM with the rounding points of the reference's eager attention, modeling_qwen2.py:248-327, all five
-products on v3d_gemm), kept as an independent cross-check.  Not here yet: the SigLIP tower's backward, the optimizer."""
+products on v3d_gemm), kept as an independent cross-check.  Parity: tests/test_gpu_train_dense.py, tests/test_gpu_zero2.py (autograd in
+f32 over the reference's formulae).  Not here: gradient accumulation, the grounding loss (box_labels), LoRA, the HF Trainer surface."""
 import math
 
 import torch
