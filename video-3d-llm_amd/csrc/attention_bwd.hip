@@ -12,9 +12,9 @@
 //       S = Q K^T      P = exp2(c S - L)      dP = dO V^T      dS = P (dP - delta)      dV^T += dO^T P      dK^T += Q^T dS
 //       -> f32 partials per query head; attn_bwd_reduce_kernel sums the heads of a kv group in a fixed order (no atomics).
 // Seven products instead of the minimal five (S and dP are formed in both kernels): that buys a dQ without atomics and a
-// deterministic result.  The images are double-buffered (the next tile's LDS-DMA flies under the current tile's MFMAs) and every
-// fragment read is an asm statement with its own wait: hipcc puts a vmcnt(0) in front of LDS reads it can see, which would drain the
-// prefetch.  One workgroup per CU (the accumulators of both gradients live in AGPRs); no finer software pipeline yet.
+// deterministic result.  The images are double-buffered (the next tile's LDS-DMA flies under the current tile's MFMAs) and the
+// fragments are read through two register rings by asm statements with counted waits (hipcc puts a vmcnt(0) in front of LDS reads it
+// can see, which would drain the prefetch): eight reads fly under the eight MFMAs of the previous ring.  One workgroup per CU (the accumulators of both gradients live in AGPRs); no finer software pipeline yet.
 #include "v3d_common.h"
 
 namespace v3d {
@@ -76,17 +76,21 @@ __device__ __forceinline__ void stage_image(const uint16_t* src, unsigned ld_byt
 }
 
 // A-operand fragments f[ks] of image row (32 half + (lane & 31)), d = 16 ks + 8 (lane >> 5) .. + 8, ks = 0..7: the k-step toggles address
-// bits 5..7 (chunk (2 ks + h) ^ swz = 2 ks ^ (h ^ swz)).  One asm statement with its wait (see the header).
-__device__ __forceinline__ void row_frags(unsigned image_lds, int lane, int half, v4i (&f)[8]) {
+// bits 5..7 (chunk (2 ks + h) ^ swz = 2 ks ^ (h ^ swz)).  ISSUE only: the data is complete after frags_wait<N>(f) with N = the LDS
+// reads issued after these eight (LDS returns in order).  The reads are asm statements because hipcc puts a vmcnt(0) in front of LDS
+// reads it can see (which would drain the prefetch) and serialises read -> wait -> MFMA; the wait ties the eight registers ("+v") so
+// that nothing reads them before it (the pattern of attention.hip's K / V fragment rings).
+__device__ __forceinline__ void row_frags_issue(unsigned image_lds, int lane, int half, v4i (&f)[8]) {
   const int r = lane & 31, h = lane >> 5;
   const unsigned b = image_lds + (32 * half + r) * BW_ROW + ((h ^ swz(r)) << 4);
-  asm volatile(
-      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
-      "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
-      : "v"(b), "v"(b ^ 32u), "v"(b ^ 64u), "v"(b ^ 96u), "v"(b ^ 128u), "v"(b ^ 160u), "v"(b ^ 192u), "v"(b ^ 224u)
-      : "memory");
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("ds_read_b128 %0, %1" : "=v"(f[ks]) : "v"(b ^ ((unsigned)ks << 5)));
+}
+template <int N> __device__ __forceinline__ void frags_wait(v4i (&f)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void frags_wait(v2i (&f)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : "n"(N) : "memory");
 }
 
 // Row statistics of the accumulator registers' rows: x[4 qh + g][j] = stat[32 qh + 8 g + 4 h + j] (register r = 4 g + j of row block qh)
@@ -104,22 +108,21 @@ __device__ __forceinline__ void stat_frags(unsigned stat_lds, int lane, f32x4 (&
 
 // A-operand fragments of the image's TRANSPOSE for the 32 columns d = 32 dt ..: f[2 s4 + {0,1}] cover the 16 rows of block s4 in the
 // k order the accumulator registers have ((j & 3) + 8 (j >> 2) + 4 h), so that {f[2 s4], f[2 s4 + 1]} multiplies a B operand packed
-// straight from accumulator registers 8 (s4 & 1) .. + 8 of row block s4 >> 1.   (address form of attention.hip's V^T reads)
-__device__ __forceinline__ void tr_frags(unsigned image_lds, int lane, int dt, v2i (&f)[8]) {
+// straight from accumulator registers 8 (s4 & 1) .. + 8 of row block s4 >> 1.   (address form of attention.hip's V^T reads; ISSUE only)
+__device__ __forceinline__ void tr_frags_issue(unsigned image_lds, int lane, int dt, v2i (&f)[8]) {
   const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3, h = lane >> 5;
   const int chunk_lo = 2 * (g & 1) + (pp >> 1), byte = 8 * (pp & 1);
   const int row0 = 4 * h + qq;
   const unsigned a0 = (image_lds + row0 * BW_ROW + byte + ((chunk_lo ^ swz(row0)) << 4)) ^ (dt << 6);
   const unsigned a1 = (image_lds + (row0 + 8) * BW_ROW + byte + ((chunk_lo ^ swz(row0 + 8)) << 4)) ^ (dt << 6);
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
-      "ds_read_b64_tr_b16 %2, %8 offset:4096\n\tds_read_b64_tr_b16 %3, %9 offset:4096\n\t"
-      "ds_read_b64_tr_b16 %4, %8 offset:8192\n\tds_read_b64_tr_b16 %5, %9 offset:8192\n\t"
-      "ds_read_b64_tr_b16 %6, %8 offset:12288\n\tds_read_b64_tr_b16 %7, %9 offset:12288\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
-      : "v"(a0), "v"(a1)
-      : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[0]) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[1]) : "v"(a1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f[2]) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f[3]) : "v"(a1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[4]) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[5]) : "v"(a1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[6]) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[7]) : "v"(a1));
 }
 
 template <typename T> __device__ __forceinline__ v4i pack8(const float* e) {
@@ -197,17 +200,30 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
     if (t < n_wave) {
       f32x16 s[2], dp[2];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[kt][r] = -L; dp[kt][r] = 0.f; }
-        v4i fa[8];
-        row_frags(lds_k, lane, kt, fa);
+      // two fragment rings: the reads of the next eight fragments fly under the eight MFMAs of the current ones
+      v4i fa[8], fb[8];
+      row_frags_issue(lds_k, lane, 0, fa);
+      row_frags_issue(lds_v, lane, 0, fb);
+      frags_wait<8>(fa);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) s[kt] = M::run(fa[ks], qf[ks], s[kt]);
-        row_frags(lds_v, lane, kt, fa);
+      for (int ks = 0; ks < 8; ++ks) s[0] = M::run(fa[ks], qf[ks], s[0]);
+      row_frags_issue(lds_k, lane, 1, fa);
+      frags_wait<8>(fb);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) dp[kt] = M::run(fa[ks], dof[ks], dp[kt]);
-      }
+      for (int ks = 0; ks < 8; ++ks) dp[0] = M::run(fb[ks], dof[ks], dp[0]);
+      row_frags_issue(lds_v, lane, 1, fb);
+      frags_wait<8>(fa);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) s[1] = M::run(fa[ks], qf[ks], s[1]);
+      v2i f0[8], f1[8];
+      tr_frags_issue(lds_k, lane, 0, f0);                 // K^T fragments of the first two d tiles: in flight under dp and the softmax
+      frags_wait<8>(fb);                                  // (lgkmcnt counts to 15: never more than two rings in flight)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fb[ks], dof[ks], dp[1]);
+      tr_frags_issue(lds_k, lane, 1, f1);
       const int limit = ((p.causal && qi < p.S - 1) ? qi : p.S - 1) - t * 64 - 4 * h;       // visible iff tile-local key offset <= limit
       v4i pf[4];
 #pragma unroll
@@ -222,16 +238,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
         }
         pf[i] = pack8<T>(e);
       }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        v2i f[8];
-        tr_frags(lds_k, lane, dt, f);
+      auto mma4 = [&](const v2i (&f)[8], int dt) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
           acc[dt] = M::run(a, pf[s4], acc[dt]);
         }
-      }
+      };
+      frags_wait<8>(f0); mma4(f0, 0);
+      tr_frags_issue(lds_k, lane, 2, f0);
+      frags_wait<8>(f1); mma4(f1, 1);
+      tr_frags_issue(lds_k, lane, 3, f1);
+      frags_wait<8>(f0); mma4(f0, 2);
+      frags_wait<0>(f1); mma4(f1, 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                  // the next tile has landed and is visible; everyone is done with this one
@@ -318,20 +337,32 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     if (!p.causal || t * 64 + 63 >= wave_first_key) {            // some query of the tile sees some key of this wave
       f32x16 s[2], dp[2];
 #pragma unroll
-      for (int qh = 0; qh < 2; ++qh) {
+      for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[qh][r] = 0.f; dp[qh][r] = 0.f; }
-        v4i fa[8];
-        row_frags(lds_q, lane, qh, fa);
+      v4i fa[8], fb[8];
+      row_frags_issue(lds_q, lane, 0, fa);
+      row_frags_issue(lds_do, lane, 0, fb);
+      frags_wait<8>(fa);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) s[qh] = M::run(fa[ks], kf[ks], s[qh]);
-        row_frags(lds_do, lane, qh, fa);
+      for (int ks = 0; ks < 8; ++ks) s[0] = M::run(fa[ks], kf[ks], s[0]);
+      row_frags_issue(lds_q, lane, 1, fa);
+      frags_wait<8>(fb);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) dp[qh] = M::run(fa[ks], vf[ks], dp[qh]);
-      }
+      for (int ks = 0; ks < 8; ++ks) dp[0] = M::run(fb[ks], vf[ks], dp[0]);
+      row_frags_issue(lds_do, lane, 1, fb);
+      frags_wait<8>(fa);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) s[1] = M::run(fa[ks], kf[ks], s[1]);
+      frags_wait<0>(fb);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fb[ks], vf[ks], dp[1]);
       f32x4 Lr[8], Dr[8];
       stat_frags(lds0 + BW_STAT + buf * 512, lane, Lr);
       stat_frags(lds0 + BW_STAT + buf * 512 + 256, lane, Dr);
+      v2i f0[8], f1[8];
+      tr_frags_issue(lds_do, lane, 0, f0);               // dO^T and Q^T fragments of the first d tile: in flight under the softmax
+      tr_frags_issue(lds_q, lane, 0, f1);
       v4i pfp[4], pfs[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -349,21 +380,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
         pfp[i] = pack8<T>(ep);
         pfs[i] = pack8<T>(es);
       }
+      auto mma4 = [&](const v2i (&f)[8], const v4i (&b)[4], f32x16& acc) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
+          acc = M::run(a, b[s4], acc);
+        }
+      };
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        v2i f[8];
-        tr_frags(lds_do, lane, dt, f);                 // dO^T
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
-          dv[dt] = M::run(a, pfp[s4], dv[dt]);
-        }
-        tr_frags(lds_q, lane, dt, f);                  // Q^T
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
-          dk[dt] = M::run(a, pfs[s4], dk[dt]);
-        }
+        frags_wait<8>(f0); mma4(f0, pfp, dv[dt]);        // dV^T += dO^T P
+        if (dt < 3) tr_frags_issue(lds_do, lane, dt + 1, f0);
+        if (dt < 3) { frags_wait<8>(f1); } else { frags_wait<0>(f1); }
+        mma4(f1, pfs, dk[dt]);                           // dK^T += Q^T dS
+        if (dt < 3) tr_frags_issue(lds_q, lane, dt + 1, f1);
       }
     }
     if (more && tid < 128) stat[(buf ^ 1) * 128 + tid] = sv;
