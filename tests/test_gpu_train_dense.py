@@ -530,3 +530,22 @@ def test_whole_sample_step_matches_autograd(ops, train):
         for k in layers[i]:
             _close(grads["llm"]["layers"][i][k], r_llm["layers"][i][k].grad, *tol, f"llm layer {i} d {k}")
     _close(grads["llm"]["lm_head"], r_llm["lm_head"].grad, *tol, "d lm_head")
+
+
+def test_attention_train_non_causal_batch_equals_plain_attention(ops):
+    """v3d_attention_train on a batch of non-causal sequences (the SigLIP encoder's shape: 729 rows, heads padded to 128): the outputs are
+    the plain kernel's bit for bit, the log-sum-exp matches the f32 definition."""
+    B, S, heads, hd = 3, 729, 4, 128
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(B * S, 3 * heads * hd, generator=g).to(torch.bfloat16).cuda()
+    o = torch.empty(B * S, heads * hd, dtype=torch.bfloat16, device="cuda")
+    lse = ops.attention_train(qkv, o, S, heads, heads, 72 ** -0.5, B=B, causal=False)
+    w = qkv.stride(0)
+    plain = torch.empty_like(o)
+    ops.attention(qkv, qkv[:, heads * hd:], qkv[:, 2 * heads * hd:], plain, B, S, S, heads, heads, hd, hd, w, w, w, heads * hd, S * w, S * w, S * heads * hd,
+                  hd, hd, hd, False, 0, 72 ** -0.5)
+    assert torch.equal(o, plain)
+    q = qkv[:, :heads * hd].float().cpu().view(B, S, heads, hd).transpose(1, 2)
+    k = qkv[:, heads * hd:2 * heads * hd].float().cpu().view(B, S, heads, hd).transpose(1, 2)
+    ref = torch.logsumexp(q @ k.transpose(2, 3) * 72 ** -0.5, -1) * 1.4426950408889634          # [B, heads, S] in log2 units
+    assert float((lse.cpu() - ref).abs().max()) < 3e-2
