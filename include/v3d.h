@@ -434,6 +434,10 @@ int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight, const voi
                        int64_t ldd, float* workspace, void* dweight, void* dbias, int dw_dtype, int64_t rows, int cols, float eps,
                        int dtype, void* stream);
 
+/* y[i] = T(y[i] + alpha * x[i]) for flat 16-bit tensors: gradient accumulation over micro-batches (train_multi.sh:31-32, 60:
+ * gradient_accumulation_steps = 2), in the arithmetic torch uses when it adds a new gradient to .grad (f32 add, one rounding). */
+int v3d_axpy(void* y, const void* x, float alpha, int64_t n, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ host helpers -------- */
 
 /* The launch plan v3d_gemm takes for an M x N x K product on a chip with `slots` compute units (pure host code, no device needed;

@@ -549,3 +549,20 @@ def test_attention_train_non_causal_batch_equals_plain_attention(ops):
     k = qkv[:, heads * hd:2 * heads * hd].float().cpu().view(B, S, heads, hd).transpose(1, 2)
     ref = torch.logsumexp(q @ k.transpose(2, 3) * 72 ** -0.5, -1) * 1.4426950408889634          # [B, heads, S] in log2 units
     assert float((lse.cpu() - ref).abs().max()) < 3e-2
+
+
+def test_axpy_and_gradient_accumulation(ops, train):
+    g = torch.Generator().manual_seed(4)
+    for n in (8, 1000003, 77):
+        y = torch.randn(n, generator=g).to(torch.bfloat16)
+        x = torch.randn(n, generator=g).to(torch.bfloat16)
+        got = ops.axpy(y.clone().cuda(), x.cuda())
+        assert torch.equal(got.cpu(), y + x)                                   # torch's own 16-bit add: f32 sum, one rounding
+        got = ops.axpy(y.clone().cuda(), x.cuda(), alpha=0.5)
+        assert torch.equal(got.cpu(), (y.float() + 0.5 * x.float()).to(torch.bfloat16))
+    a = {"w": torch.randn(16, 24, generator=g).to(torch.bfloat16).cuda(), "l": [torch.randn(40, generator=g).cuda()]}
+    b = {"w": torch.randn(16, 24, generator=g).to(torch.bfloat16).cuda(), "l": [torch.randn(40, generator=g).cuda()]}
+    want_w, want_l = a["w"] + b["w"], a["l"][0] + b["l"][0]
+    total = train.accumulate_grads(None, a)
+    total = train.accumulate_grads(total, b)
+    assert torch.equal(total["w"], want_w) and torch.equal(total["l"][0], want_l)

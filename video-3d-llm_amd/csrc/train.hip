@@ -615,6 +615,24 @@ __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict
   }
 }
 
+
+// y = T(y + alpha x): gradient accumulation over micro-batches (torch adds a new gradient to .grad in the parameter's dtype)
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(T* __restrict__ y, const T* __restrict__ x, float alpha, int64_t n) {
+  const int64_t nv = n / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const uint4 a = reinterpret_cast<const uint4*>(y)[i], b = reinterpret_cast<const uint4*>(x)[i];
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = vec_get<T>(a, j) + alpha * vec_get<T>(b, j);
+    reinterpret_cast<uint4*>(y)[i] = vec_pack<T>(o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const int64_t i = nv * 8 + threadIdx.x;
+    y[i] = from_f32<T>(to_f32(y[i]) + alpha * to_f32(x[i]));
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -861,4 +879,13 @@ extern "C" int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight
   if (int e = check_launch("v3d_layernorm_grad")) return e;
   if (int e = colsum_final(pw, n_part, cols, dweight, dw_dtype, st, "v3d_layernorm_grad")) return e;
   return colsum_final(pb, n_part, cols, dbias, dw_dtype, st, "v3d_layernorm_grad");
+}
+
+extern "C" int v3d_axpy(void* y, const void* x, float alpha, int64_t n, int dtype, void* stream) {
+  V3D_REQUIRE(y && x && n > 0 && aligned16(y) && aligned16(x), "v3d_axpy: bad arguments (16-byte aligned, n > 0)");
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(axpy_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (T*)y, (const T*)x, alpha, n));
+  return check_launch("v3d_axpy");
 }

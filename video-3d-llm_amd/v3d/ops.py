@@ -850,3 +850,12 @@ def layernorm_grad(x, weight, dy, eps=1e-6, add=None, dw_dtype=None):
                                    _p(dx), dx.stride(0), _p(ws), _p(dw), _p(db), _DT[dw.dtype], rows, cols, eps, _code(x), _stream()),
           "v3d_layernorm_grad")
     return dx, dw, db
+
+
+def axpy(y, x, alpha=1.0):
+    """y += alpha * x in place (flat view of two contiguous 16-bit tensors of one shape)."""
+    y, x = _dev(y, "y"), _dev(x, "x")
+    if y.shape != x.shape or y.dtype != x.dtype or not y.is_contiguous() or not x.is_contiguous():
+        raise V3DError("axpy: y and x must be contiguous tensors of one shape and dtype")
+    check(lib().v3d_axpy(_p(y), _p(x), float(alpha), y.numel(), _code(y), _stream()), "v3d_axpy")
+    return y

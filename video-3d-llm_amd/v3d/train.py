@@ -19,7 +19,7 @@ Attention backward exists in two forms: tiled kernels that recompute the probabi
 write an [S, S] matrix (v3d_attention_backward, csrc/attention_bwd.hip - the default), and the first, MATERIALISED form below
 (one head's probability matrix in HBM with the rounding points of the reference's eager attention, modeling_qwen2.py:248-327, all five
 products on v3d_gemm), kept as an independent cross-check.  Parity: tests/test_gpu_train_dense.py, tests/test_gpu_zero2.py (autograd in
-f32 over the reference's formulae).  Not here: gradient accumulation, the grounding loss (box_labels), LoRA, the HF Trainer surface."""
+f32 over the reference's formulae).  Not here: the grounding loss (box_labels), LoRA, the HF Trainer surface."""
 import math
 
 import torch
@@ -196,6 +196,23 @@ def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6):
         dh, layer_grads[i] = decoder_layer_backward(dh, saved[i], params["layers"][i], rope, n_q, n_kv, hd, eps)
         saved[i] = None                                               # the layer's activations are no longer needed
     return loss, dh, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
+
+
+def accumulate_grads(total, grads):
+    """Gradient accumulation over micro-batches (train_multi.sh:31-32: two per optimizer step on 8 GPUs): total += grads, leaf by leaf, in
+    the gradients' own 16-bit dtype as torch accumulates .grad; the first micro-batch's tree is taken as it is.  The mean over the
+    micro-batches is the optimizer's grad_scale (1 / steps)."""
+    if total is None:
+        return grads
+
+    def add(t, g, _):
+        if t.dtype == torch.float32:
+            t.add_(g)                                   # image_newline's [H] f32 row sum (14 KB): left to torch
+        else:
+            ops.axpy(t, g)
+
+    _tree_zip(add, total, grads, total)
+    return total
 
 
 class AdamW:
@@ -437,7 +454,7 @@ class ZeroAdamW:
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
 
-    def step(self, grads):
+    def step(self, grads, grad_scale=1.0):
         self.t += 1
         flat_g = torch.zeros(self.per * self.world, dtype=self.flat.dtype, device=self.flat.device)
         off = 0
@@ -449,7 +466,7 @@ class ZeroAdamW:
         else:
             part = self.D.reduce_scatter_grads(flat_g, self.bucket, average=True, algorithm=self.algorithm)
         ops.adamw_step(self.master, self.m, self.v, part.contiguous(), p16=self.mine, lr=self.lr, betas=self.betas, eps=self.eps,
-                       weight_decay=self.weight_decay, step=self.t)
+                       weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale)
         if self.host_staged:
             full = self.D.all_gather_params(self.mine.cpu(), self.per * self.world, self.bucket).to(self.flat.device)
         else:
