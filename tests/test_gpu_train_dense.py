@@ -566,3 +566,28 @@ def test_axpy_and_gradient_accumulation(ops, train):
     total = train.accumulate_grads(None, a)
     total = train.accumulate_grads(total, b)
     assert torch.equal(total["w"], want_w) and torch.equal(total["l"][0], want_l)
+
+
+def test_a_few_optimizer_steps_fit_one_sample(train):
+    """Functional check of the whole loop: a 2-layer language model memorises one sample's 40 answer tokens in a few AdamW steps."""
+    H, I, n_q, n_kv, hd, V, S, L = 512, 1024, 4, 2, 128, 1024, 120, 2
+    g = torch.Generator().manual_seed(99)
+    width = (n_q + 2 * n_kv) * hd
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16).cuda()
+    ones = lambda: torch.ones(H, dtype=torch.bfloat16, device="cuda")
+    layers = [{"ln1": ones(), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.02), "o": mk(H, n_q * hd, s=(n_q * hd) ** -0.5),
+               "ln2": ones(), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    params = {"layers": layers, "norm": ones(), "lm_head": mk(V, H, s=H ** -0.5)}
+    x = mk(S, H)
+    labels = torch.full((S,), -100, dtype=torch.int64)
+    labels[80:] = torch.randint(0, V, (40,), generator=g)
+    labels = labels.cuda()
+    rope = train.RopeTables(hd, 256, 1e6, torch.bfloat16, "cuda")
+    opt = train.AdamW(params, lr=2e-3)
+    losses = []
+    for _ in range(12):
+        loss, _, grads = train.llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd)
+        losses.append(float(loss))
+        opt.step(params, grads)
+    assert losses[0] > 6.0 and losses[-1] < 0.5 * losses[0], losses        # ln(1024) = 6.9 at the start
+    assert all(torch.isfinite(p.float()).all() for l in layers for p in l.values())
