@@ -64,9 +64,15 @@ def test_zero2_step_world2_equals_single_process_adamw_on_averaged_gradients():
         procs = [ctx.Process(target=_worker, args=(r, 2, port, out_dir)) for r in range(2)]
         for p in procs:
             p.start()
-        for p in procs:
-            p.join(timeout=300)
-            assert p.exitcode == 0
+        try:
+            for p in procs:
+                p.join(timeout=300)
+            assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        finally:
+            for p in procs:                                  # never leave a rank behind on the card
+                if p.is_alive():
+                    p.terminate()
+                    p.join(timeout=30)
         got = [torch.load(os.path.join(out_dir, f"rank{r}.pt"), weights_only=True) for r in range(2)]
     assert torch.equal(got[0], got[1])                                   # every rank holds the same model after the gather
     # single process: the two ranks' gradients summed and averaged in the exchange's arithmetic (16-bit sum, then / world), plain AdamW
