@@ -422,14 +422,15 @@ int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_
 
 /* GELU as a pass of its own for the training forward (which keeps the pre-activation z) and its gradient dz = dy * gelu'(z):
  * tanh_form 0 = nn.GELU() of the mm_projector (multimodal_projector/builder.py:41-48), 1 = gelu_pytorch_tanh of the SigLIP MLP
- * (siglip_encoder.py:253-262).  f32 inside, one rounding. */
+ * (siglip_encoder.py:253-262), 2 = nn.ReLU() of the grounding heads (llava_qwen.py:99-110; z may be the ReLU's output).  f32 inside,
+ * one rounding. */
 int v3d_gelu(const void* z, int64_t ldz, void* out, int64_t ldo, int64_t rows, int cols, int tanh_form, int dtype, void* stream);
 int v3d_gelu_grad(const void* z, int64_t ldz, const void* dy, int64_t ldy, void* dz, int64_t ldo, int64_t rows, int cols, int tanh_form,
                   int dtype, void* stream);
 
 /* Backward of v3d_layernorm (nn.LayerNorm of the SigLIP encoder layers, siglip_encoder.py:272-274,292,300): with xh = (x - mean) rstd
  * and g = dy * weight: dx = rstd (g - mean(g) - xh mean(g xh)) (+ add, the residual branch's gradient), dweight = sum_rows dy xh,
- * dbias = sum_rows dy (f32, fixed order).  workspace: 2 * v3d_colsum_workspace_bytes(rows, cols) bytes.  cols <= 2048. */
+ * dbias = sum_rows dy (f32, fixed order).  workspace: 2 * v3d_colsum_workspace_bytes(rows, cols) bytes.  cols <= 3584. */
 int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight, const void* dy, int64_t ldy, const void* add, int64_t lda, void* dx,
                        int64_t ldd, float* workspace, void* dweight, void* dbias, int dw_dtype, int64_t rows, int cols, float eps,
                        int dtype, void* stream);
@@ -437,6 +438,17 @@ int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight, const voi
 /* y[i] = T(y[i] + alpha * x[i]) for flat 16-bit tensors: gradient accumulation over micro-batches (train_multi.sh:31-32, 60:
  * gradient_accumulation_steps = 2), in the arithmetic torch uses when it adds a new gradient to .grad (f32 add, one rounding). */
 int v3d_axpy(void* y, const void* x, float alpha, int64_t n, int dtype, void* stream);
+
+/* The grounding loss (ScanRefer / Multi3DRefer samples of the joint training), predict_box 'infonce', llava_qwen.py:296-310: with
+ * s_i = <normalize(obj[i]), normalize(query)> (v3d_ground_scores) over the n head outputs obj [n, C] (the zero-target row included),
+ * loss = -log(sum_{positive i} e^{s_i / temperature} / sum_i e^{s_i / temperature}); positive: device uint8 [n].  Writes loss (f32
+ * scalar), scores (f32 [n], may be null) and the gradients dobj [n, C], dquery [C].  n <= 1024. */
+int v3d_ground_infonce(const void* obj, int64_t ldo, int n, const void* query, int C, const uint8_t* positive, float temperature,
+                       float* loss, float* scores, void* dobj, int64_t ldd, void* dquery, int dtype, void* stream);
+/* Backward of v3d_masked_mean (llava_arch.py:482-501): dfeat[t, :] = (accumulate ? dfeat[t, :] : 0) + sum over the objects o with
+ * mask[o, t] != 0, in order, of dobj[o, :] / count[o]; dfeat [T, C] contiguous, inv_count: f32 [n_obj] scratch. */
+int v3d_masked_mean_grad(const uint8_t* mask, int n_obj, int T, int C, const void* dobj, void* dfeat, int accumulate, float* inv_count,
+                         int dtype, void* stream);
 
 /* ------------------------------------------------------------------ host helpers -------- */
 

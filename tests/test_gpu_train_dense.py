@@ -591,3 +591,88 @@ def test_a_few_optimizer_steps_fit_one_sample(train):
         opt.step(params, grads)
     assert losses[0] > 6.0 and losses[-1] < 0.5 * losses[0], losses        # ln(1024) = 6.9 at the start
     assert all(torch.isfinite(p.float()).all() for l in layers for p in l.values())
+
+
+def test_grounding_sample_step_matches_autograd(ops, train):
+    """A ScanRefer / Multi3DRefer training sample: tower -> projector -> splice -> decoder, then predict_box's infonce loss between the
+    <ground> row's hidden state and the object proposals (llava_qwen.py:239-310, llava_arch.py:479-501); loss, scores and the
+    gradients of the heads, the zero-target, the decoder, the projector and the tower against autograd in f32."""
+    frames, tokens, Hv, heads, inter, kpad = 2, 729, 1152, 16, 4304, 640
+    H, I, n_q, n_kv, hd, V, L, n_obj = 768, 1024, 4, 2, 128, 1024, 2, 6
+    g = torch.Generator().manual_seed(55)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
+    ln = lambda n_: (1 + 0.1 * torch.randn(n_, generator=g)).to(torch.bfloat16)
+    vit = {"ln1_w": ln(Hv), "ln1_b": mk(Hv, s=0.1), "ln2_w": ln(Hv), "ln2_b": mk(Hv, s=0.1),
+           "q_w": mk(Hv, Hv, s=Hv ** -0.5), "q_b": mk(Hv, s=0.2), "k_w": mk(Hv, Hv, s=Hv ** -0.5), "k_b": mk(Hv, s=0.2),
+           "v_w": mk(Hv, Hv, s=Hv ** -0.5), "v_b": mk(Hv, s=0.2), "o_w": mk(Hv, Hv, s=Hv ** -0.5), "o_b": mk(Hv, s=0.2),
+           "fc1_w": mk(inter, Hv, s=Hv ** -0.5), "fc1_b": mk(inter, s=0.2), "fc2_w": mk(Hv, inter, s=inter ** -0.5), "fc2_b": mk(Hv, s=0.2)}
+    patch_w, patch_b, pos = mk(Hv, kpad, s=588 ** -0.5), mk(Hv, s=0.1), mk(tokens, Hv, s=0.5)
+    patch_w[:, 588:] = 0
+    proj = {"w1": mk(H, Hv, s=Hv ** -0.5), "b1": mk(H, s=0.1), "w2": mk(H, H, s=H ** -0.5), "b2": mk(H, s=0.1)}
+    newline, embed = mk(H, s=0.5), mk(V, H, s=0.5)
+    width = (n_q + 2 * n_kv) * hd
+    layers = [{"ln1": ln(H), "qkv": mk(width, H, s=H ** -0.5), "qkv_bias": mk(width, s=0.3), "o": mk(H, n_q * hd, s=(n_q * hd) ** -0.5),
+               "ln2": ln(H), "gate_up": mk(2 * I, H, s=H ** -0.5), "down": mk(H, I, s=I ** -0.5)} for _ in range(L)]
+    llm = {"layers": layers, "norm": ln(H)}
+    head = lambda: {"w0": mk(H, H, s=H ** -0.5), "b0": mk(H, s=0.1), "ln_w": ln(H), "ln_b": mk(H, s=0.1), "w3": mk(H, H, s=H ** -0.5), "b3": mk(H, s=0.1)}
+    ground = {"obj": head(), "query": head(), "zero_target": mk(H)}
+    patches = mk(frames * tokens, kpad)
+    patches[:, 588:] = 0
+    ids = torch.randint(0, 64, (frames, 14, 14, 3), generator=g, dtype=torch.int32)
+    pre_ids, post_ids = torch.randint(0, V, (9,), generator=g), torch.randint(0, V, (21,), generator=g)
+    n_vis = frames * 14 * 15
+    ground_row = 9 + n_vis + 17                                              # the <ground> label token sits among the trailing text rows
+    mask = (torch.rand(n_obj, frames * tokens, generator=g) < 0.02).to(torch.uint8)
+    mask[4] = 0                                                               # a proposal that covers no patch: its feature is the PE alone
+    box_pe = mk(n_obj, H, s=0.5)
+    positive = torch.zeros(n_obj + 1, dtype=torch.uint8)
+    positive[[1, 3]] = 1
+
+    table = ops.Sin3DTable(H, 64, torch.bfloat16, "cuda")
+    pe = ops.sin3d_pe(ids.view(frames, 196, 3).to(torch.bfloat16).cuda(), H).float().cpu()
+    rope = train.RopeTables(hd, 1024, 1e6, torch.bfloat16, "cuda")
+    cu = lambda t: train._tree_map(lambda a: a.cuda(), t)
+    params = {"vision": {"patch_w": patch_w.cuda(), "patch_b": patch_b.cuda(), "pos": pos.cuda(), "layers": [train.siglip_pad_layer(cu(vit))]},
+              "projector": cu(proj), "newline": newline.cuda(), "embed": embed.cuda(), "llm": cu(llm), "ground": cu(ground)}
+    loss, scores, grads = train.ground_sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), ground_row,
+                                                               mask.cuda(), box_pe.cuda(), positive.cuda(), rope, frames, n_q, n_kv, hd)
+
+    f32 = lambda t: train._tree_map(lambda a: a.float().requires_grad_(), t)
+    r_vit, r_proj, r_llm, r_gr = f32(vit), f32(proj), f32(llm), f32(ground)
+    r_pw, r_nl, r_emb = (t.float().requires_grad_() for t in (patch_w, newline, embed))
+    h = ((patches.float() @ r_pw.t() + patch_b.float()).view(frames, tokens, Hv) + pos.float()).view(frames * tokens, Hv)
+    h = _siglip_layer_ref(h, r_vit, frames, tokens, heads)
+    y = F.gelu(h @ r_proj["w1"].t() + r_proj["b1"]) @ r_proj["w2"].t() + r_proj["b2"]
+    pooled = F.interpolate(y.view(frames, 27, 27, H).permute(0, 3, 1, 2), size=[14, 14], mode="bilinear").permute(0, 2, 3, 1)
+    vis = torch.cat([pooled + pe.view(frames, 14, 14, H), r_nl[None, None, None, :].expand(frames, 14, 1, H)], 2).reshape(-1, H)
+    x = torch.cat([r_emb[pre_ids], vis, r_emb[post_ids]], 0)
+    for p in r_llm["layers"]:
+        x = _layer_ref(x, p, n_q, n_kv, hd, 1e-6)
+    query = _rmsnorm_ref(x[ground_row:ground_row + 1], r_llm["norm"], 1e-6)
+    objs = []
+    for i in range(n_obj):                                                    # llava_arch.py:482-501
+        rows = mask[i].bool()
+        objs.append((y[rows].mean(0) if bool(rows.any()) else torch.zeros(H)) + box_pe[i].float())
+    of = torch.cat([torch.stack(objs), r_gr["zero_target"][None]], 0)         # llava_qwen.py:297
+    mlp = lambda t, hp: F.linear(F.layer_norm(F.relu(F.linear(t, hp["w0"], hp["b0"])), (H,), hp["ln_w"], hp["ln_b"], 1e-5), hp["w3"], hp["b3"])
+    sc = (F.normalize(mlp(of, r_gr["obj"])) * F.normalize(mlp(query, r_gr["query"]))).sum(-1)
+    lg = torch.exp(sc / 0.07)
+    ref_loss = -torch.log(lg[positive.bool()].sum() / lg.sum())                # :306-307
+    ref_loss.backward()
+
+    assert float((scores.cpu() - sc.detach()).abs().max()) < 2e-2
+    assert abs(float(loss) - float(ref_loss.detach())) < 0.05 * max(1.0, float(ref_loss.detach()))
+    tol = (5e-2, 1.2e-1)
+    for hname in ("obj", "query"):
+        for k in ground[hname]:
+            _close(grads["ground"][hname][k], r_gr[hname][k].grad, *tol, f"d {hname} head {k}")
+    _close(grads["ground"]["zero_target"], r_gr["zero_target"].grad, *tol, "d zero target")
+    _close(grads["llm"]["norm"], r_llm["norm"].grad, *tol, "d final norm")
+    for k in layers[0]:
+        _close(grads["llm"]["layers"][0][k], r_llm["layers"][0][k].grad, *tol, "llm layer 0 d " + k)
+    for k in proj:
+        _close(grads["projector"][k], r_proj[k].grad, *tol, "d projector " + k)
+    real = train.siglip_unpad_grads(grads["vision"]["layers"][0])
+    for k in ("q_w", "o_w", "fc1_w", "fc2_w", "ln1_w"):
+        _close(real[k], r_vit[k].grad, *tol, "vit d " + k)
+    _close(grads["embed"], r_emb.grad, *tol, "d embed")

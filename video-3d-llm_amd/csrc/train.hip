@@ -492,10 +492,12 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const T* __restrict__ d
 // nn.GELU() of the mm_projector (erf form, multimodal_projector/builder.py:41-48) and the SigLIP MLP's gelu_pytorch_tanh
 // (siglip_encoder.py:253-262) as passes of their own for the training forward (which keeps the pre-activation), and their gradients.
 template <int TANH> __device__ __forceinline__ float gelu_f(float x) {
+  if (TANH == 2) return fmaxf(x, 0.f);                  // kind 2: ReLU (the grounding heads, llava_qwen.py:99-110)
   if (TANH) { const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x); return 0.5f * x * (1.0f + tanhf(u)); }
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 template <int TANH> __device__ __forceinline__ float gelu_df(float x) {
+  if (TANH == 2) return x > 0.f ? 1.0f : 0.f;           // (also right on the ReLU's OUTPUT: h > 0 iff z > 0)
   if (TANH) {
     const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x), t = tanhf(u);
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ z, int6
 // nn.LayerNorm of the SigLIP encoder layers (siglip_encoder.py:272-274): y = xh w + b, xh = (x - mean) rstd.  With g = dy w:
 // dx = rstd (g - mean(g) - xh mean(g xh)) [+ add],  dw = sum_rows dy xh,  db = sum_rows dy.   Same shape as rmsnorm_grad_kernel:
 // 32 rows per workgroup, their dw / db contributions leave as one partial row each (partial_b follows partial_w's n_part rows).
-constexpr int LN_MAXV = 4;       // cols <= 2048
+constexpr int LN_MAXV = 7;       // cols <= 3584 (the grounding heads' LayerNorm is as wide as the LLM)
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, const T* __restrict__ dy,
                                                              int64_t ldy, const T* __restrict__ add, int64_t lda, T* __restrict__ dx, int64_t ldd,
@@ -630,6 +632,104 @@ __global__ __launch_bounds__(256) void axpy_kernel(T* __restrict__ y, const T* _
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     const int64_t i = nv * 8 + threadIdx.x;
     y[i] = from_f32<T>(to_f32(y[i]) + alpha * to_f32(x[i]));
+  }
+}
+
+
+// The grounding head's loss, predict_box 'infonce' (llava_qwen.py:296-310): s_i = <o_i / |o_i|, q / |q|>, logits e^{s_i / tau},
+// loss = -log(sum over the positives / sum over all rows), and its gradient with respect to the head outputs o [n, C] and q [C]:
+//   dloss / ds_i = (l_i / Z - [i positive] l_i / P) / tau,   do_i = ds_i (q^ - s_i o^_i) / |o_i|,   dq = sum_i ds_i (o^_i - s_i q^) / |q|.
+// One workgroup; n <= 1024 rows.
+template <typename T>
+__global__ __launch_bounds__(256) void ground_infonce_kernel(const T* __restrict__ obj, int64_t ldo, int n, const T* __restrict__ query, int C,
+                                                             const uint8_t* __restrict__ positive, float inv_tau, float* __restrict__ loss,
+                                                             float* __restrict__ scores, T* __restrict__ dobj, int64_t ldd, T* __restrict__ dquery) {
+  __shared__ float s_sc[1024], s_nrm[1024], s_ds[1024];
+  __shared__ float s_q;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) {
+    float qq = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = to_f32(query[c]); qq = fmaf(v, v, qq); }
+    qq = wave_sum_f(qq);
+    if (lane == 0) s_q = fmaxf(sqrtf(qq), 1e-12f);               // F.normalize's eps
+  }
+  __syncthreads();
+  const float qn = s_q;
+  for (int i = wave; i < n; i += 4) {
+    float oo = 0.f, oq = 0.f;
+    for (int c = lane; c < C; c += 64) { const float o = to_f32(obj[i * ldo + c]); oo = fmaf(o, o, oo); oq = fmaf(o, to_f32(query[c]), oq); }
+    oo = wave_sum_f(oo); oq = wave_sum_f(oq);
+    if (lane == 0) { const float on = fmaxf(sqrtf(oo), 1e-12f); s_nrm[i] = on; s_sc[i] = oq / (on * qn); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = -INFINITY;
+    for (int i = 0; i < n; ++i) m = fmaxf(m, s_sc[i] * inv_tau);
+    float Z = 0.f, P = 0.f;
+    for (int i = 0; i < n; ++i) { const float l = __expf(s_sc[i] * inv_tau - m); Z += l; if (positive[i]) P += l; }
+    *loss = -logf(P / Z);
+    for (int i = 0; i < n; ++i) {
+      const float l = __expf(s_sc[i] * inv_tau - m);
+      s_ds[i] = (l / Z - (positive[i] ? l / P : 0.f)) * inv_tau;
+      if (scores) scores[i] = s_sc[i];
+    }
+  }
+  __syncthreads();
+  for (int i = wave; i < n; i += 4) {
+    const float ds = s_ds[i], sc = s_sc[i], on = s_nrm[i];
+    for (int c = lane; c < C; c += 64) {
+      const float oh = to_f32(obj[i * ldo + c]) / on, qh = to_f32(query[c]) / qn;
+      dobj[i * ldd + c] = from_f32<T>(ds * (qh - sc * oh) / on);
+    }
+  }
+  for (int c = tid; c < C; c += 256) {
+    const float qh = to_f32(query[c]) / qn;
+    float a = 0.f;
+    for (int i = 0; i < n; ++i) a += s_ds[i] * (to_f32(obj[i * ldo + c]) / s_nrm[i] - s_sc[i] * qh);
+    dquery[c] = from_f32<T>(a / qn);
+  }
+}
+
+// inv_count[o] = 1 / #{t : mask[o, t] != 0} (0 if none): the mean's weights of v3d_masked_mean
+__global__ __launch_bounds__(256) void mask_count_kernel(const uint8_t* __restrict__ mask, int T_, float* __restrict__ inv_count) {
+  __shared__ int red[4];
+  int cnt = 0;
+  for (int t = threadIdx.x; t < T_; t += 256) cnt += mask[(int64_t)blockIdx.x * T_ + t] != 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { const int c = red[0] + red[1] + red[2] + red[3]; inv_count[blockIdx.x] = c > 0 ? 1.0f / (float)c : 0.f; }
+}
+
+// Backward of v3d_masked_mean: dfeat[t, :] (+)= sum over the objects o (in order) with mask[o, t] of dobj[o, :] / count[o]
+template <typename T>
+__global__ __launch_bounds__(256) void masked_mean_grad_kernel(const uint8_t* __restrict__ mask, const float* __restrict__ inv_count, const T* __restrict__ dobj,
+                                                               int n, int T_, int C, T* __restrict__ dfeat, int accumulate) {
+  const int nv = C / 8;
+  const int64_t total = (int64_t)T_ * nv;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t t = idx / nv;
+    const int k = (int)(idx - t * nv);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    for (int o = 0; o < n; ++o) {
+      if (mask[(int64_t)o * T_ + t]) {
+        any = true;
+        const uint4 d = *reinterpret_cast<const uint4*>(dobj + (int64_t)o * C + k * 8);
+        const float w = inv_count[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaf(vec_get<T>(d, j), w, a[j]);
+      }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(dfeat + t * C + k * 8);
+    if (accumulate) {
+      if (!any) continue;
+      const uint4 old = *dst;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = round_to<T>(a[j]) + vec_get<T>(old, j);
+    }
+    *dst = vec_pack<T>(a);
   }
 }
 
@@ -836,8 +936,8 @@ static int gelu_launch(const void* z, int64_t ldz, const void* dy, int64_t ldy, 
   hipStream_t st = (hipStream_t)stream;
 #define V3D_GELU(TH, GR) hipLaunchKernelGGL((gelu_kernel<T, TH, GR>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)z, ldz, (const T*)dy, ldy, (T*)out, ldo, rows, cols)
   V3D_DISPATCH_HALF(dtype, {
-    if (dy) { if (tanh_form) { V3D_GELU(1, true); } else { V3D_GELU(0, true); } }
-    else { if (tanh_form) { V3D_GELU(1, false); } else { V3D_GELU(0, false); } }
+    if (dy) { if (tanh_form == 2) { V3D_GELU(2, true); } else if (tanh_form) { V3D_GELU(1, true); } else { V3D_GELU(0, true); } }
+    else { if (tanh_form == 2) { V3D_GELU(2, false); } else if (tanh_form) { V3D_GELU(1, false); } else { V3D_GELU(0, false); } }
   });
 #undef V3D_GELU
   return check_launch(what);
@@ -888,4 +988,27 @@ extern "C" int v3d_axpy(void* y, const void* x, float alpha, int64_t n, int dtyp
   if (blocks > 256 * 16) blocks = 256 * 16;
   V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(axpy_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (T*)y, (const T*)x, alpha, n));
   return check_launch("v3d_axpy");
+}
+
+extern "C" int v3d_ground_infonce(const void* obj, int64_t ldo, int n, const void* query, int C, const uint8_t* positive, float temperature,
+                                  float* loss, float* scores, void* dobj, int64_t ldd, void* dquery, int dtype, void* stream) {
+  V3D_REQUIRE(obj && query && positive && loss && dobj && dquery, "v3d_ground_infonce: null pointer");
+  V3D_REQUIRE(n >= 1 && n <= 1024 && C > 0 && ldo >= C && ldd >= C && temperature > 0.f, "v3d_ground_infonce: 1 to 1024 rows, temperature > 0");
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(ground_infonce_kernel<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, (const T*)obj, ldo, n, (const T*)query, C,
+                                              positive, 1.0f / temperature, loss, scores, (T*)dobj, ldd, (T*)dquery));
+  return check_launch("v3d_ground_infonce");
+}
+
+extern "C" int v3d_masked_mean_grad(const uint8_t* mask, int n_obj, int T_, int C, const void* dobj, void* dfeat, int accumulate, float* inv_count,
+                                    int dtype, void* stream) {
+  V3D_REQUIRE(mask && dobj && dfeat && inv_count, "v3d_masked_mean_grad: null pointer");
+  V3D_REQUIRE(n_obj >= 1 && n_obj <= 65535 && T_ > 0 && C > 0 && C % 8 == 0 && aligned16(dobj) && aligned16(dfeat), "v3d_masked_mean_grad: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mask_count_kernel, dim3(n_obj), dim3(256), 0, st, mask, T_, inv_count);
+  if (int e = check_launch("v3d_masked_mean_grad")) return e;
+  int64_t blocks = ((int64_t)T_ * (C / 8) + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(masked_mean_grad_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, mask, (const float*)inv_count, (const T*)dobj,
+                                              n_obj, T_, C, (T*)dfeat, accumulate));
+  return check_launch("v3d_masked_mean_grad");
 }

@@ -102,6 +102,8 @@ SIGNATURES = {
     "v3d_gelu_grad": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
     "v3d_layernorm_grad": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_i, c_p]),
     "v3d_axpy": (c_i, [c_p, c_p, c_f, c_l, c_i, c_p]),
+    "v3d_ground_infonce": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_l, c_p, c_i, c_p]),
+    "v3d_masked_mean_grad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),
     "v3d_gemm_plan_host": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "v3d_voxel_keys_f32": (c_i, [c_p, c_l, c_f, c_p, c_p]),

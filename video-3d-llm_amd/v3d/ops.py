@@ -820,9 +820,10 @@ def embed_grad(dh, rows, ids, dE):
 
 
 def gelu(z, tanh_form=False):
+    """tanh_form: False = erf GELU, True = tanh GELU, 2 = ReLU."""
     z = _dev(z, "z")
     out = torch.empty_like(z)
-    check(lib().v3d_gelu(_p(z), z.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], 1 if tanh_form else 0, _code(z), _stream()), "v3d_gelu")
+    check(lib().v3d_gelu(_p(z), z.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], int(tanh_form), _code(z), _stream()), "v3d_gelu")
     return out
 
 
@@ -831,7 +832,7 @@ def gelu_grad(z, dy, tanh_form=False):
     if z.shape != dy.shape:
         raise V3DError("gelu_grad: dy must have z's shape")
     out = torch.empty_like(z)
-    check(lib().v3d_gelu_grad(_p(z), z.stride(0), _p(dy), dy.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], 1 if tanh_form else 0,
+    check(lib().v3d_gelu_grad(_p(z), z.stride(0), _p(dy), dy.stride(0), _p(out), out.stride(0), z.shape[0], z.shape[1], int(tanh_form),
                               _code(z), _stream()), "v3d_gelu_grad")
     return out
 
@@ -859,3 +860,31 @@ def axpy(y, x, alpha=1.0):
         raise V3DError("axpy: y and x must be contiguous tensors of one shape and dtype")
     check(lib().v3d_axpy(_p(y), _p(x), float(alpha), y.numel(), _code(y), _stream()), "v3d_axpy")
     return y
+
+
+def ground_infonce(obj, query, positive, temperature):
+    """The grounding loss and its gradients: obj [n, C] head outputs (zero-target row included), query [C], positive uint8 [n] on the device.
+    Returns (loss f32 scalar tensor, scores f32 [n], dobj [n, C], dquery [C])."""
+    obj, query = _dev(obj, "obj"), _dev(query, "query")
+    n, C = obj.shape
+    if positive.dtype != torch.uint8 or positive.numel() != n or not positive.is_cuda:
+        raise V3DError("ground_infonce: positive must be a device uint8 tensor with one entry per row")
+    loss = torch.empty(1, dtype=torch.float32, device=obj.device)
+    scores = torch.empty(n, dtype=torch.float32, device=obj.device)
+    dobj, dq = torch.empty_like(obj), torch.empty_like(query)
+    check(lib().v3d_ground_infonce(_p(obj), obj.stride(0), n, _p(query), C, _p(positive), float(temperature), _p(loss), _p(scores), _p(dobj),
+                                   dobj.stride(0), _p(dq), _code(obj), _stream()), "v3d_ground_infonce")
+    return loss[0], scores, dobj, dq
+
+
+def masked_mean_grad(mask, dobj, dfeat, accumulate=True):
+    """dfeat [T, C] (+)= the gradient of masked_mean(feat, mask) for dobj [n, C]; mask uint8 [n, T]."""
+    dobj = _dev(dobj, "dobj")
+    n, C = dobj.shape
+    T_ = dfeat.shape[0]
+    if mask.dtype != torch.uint8 or mask.numel() != n * T_ or not dfeat.is_contiguous() or not dobj.is_contiguous():
+        raise V3DError("masked_mean_grad: mask must be uint8 [n, T], dfeat [T, C] and dobj [n, C] contiguous")
+    inv = torch.empty(n, dtype=torch.float32, device=dobj.device)
+    check(lib().v3d_masked_mean_grad(_p(mask), n, T_, C, _p(dobj), _p(dfeat), 1 if accumulate else 0, _p(inv), _code(dobj), _stream()),
+          "v3d_masked_mean_grad")
+    return dfeat

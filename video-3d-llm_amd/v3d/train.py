@@ -19,7 +19,8 @@ Attention backward exists in two forms: tiled kernels that recompute the probabi
 write an [S, S] matrix (v3d_attention_backward, csrc/attention_bwd.hip - the default), and the first, MATERIALISED form below
 (one head's probability matrix in HBM with the rounding points of the reference's eager attention, modeling_qwen2.py:248-327, all five
 products on v3d_gemm), kept as an independent cross-check.  Parity: tests/test_gpu_train_dense.py, tests/test_gpu_zero2.py (autograd in
-f32 over the reference's formulae).  Not here: the grounding loss (box_labels), LoRA, the HF Trainer surface."""
+f32 over the reference's formulae).  ground_sample_forward_backward is the grounding samples' step (infonce loss over object proposals).
+Not here: the other grounding head types, LoRA, the HF Trainer surface."""
 import math
 
 import torch
@@ -181,21 +182,33 @@ def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6):
     int64 on the device (-100 = ignored).  Returns (loss (f32 scalar tensor), dx [S, H], grads in params' structure).  All layers'
     activations are kept (about 1 GB per 7B layer at S = 6.8 k: 28 GB of the 288), where the reference re-computes them under
     gradient checkpointing (train_multi.sh:72) - same numbers, less work."""
-    saved, h = [], x
-    for p in params["layers"]:
-        h, s = decoder_layer_forward(h, p, rope, n_q, n_kv, hd, eps)
-        saved.append(s)
+    h, saved = llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps)
     n = ops.rmsnorm(h, params["norm"], eps)
     logits = ops.gemm(n, params["lm_head"])
     loss, st = ops.cross_entropy(logits, labels)
     dlogits = ops.cross_entropy_grad(st)
     dn, dw_head, _ = linear_backward(n, params["lm_head"], dlogits)
     dh, dnorm = ops.rmsnorm_grad(h, params["norm"], dn, eps)
+    dx, layer_grads = llm_layers_backward(dh, saved, params, rope, n_q, n_kv, hd, eps)
+    return loss, dx, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
+
+
+def llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps=1e-6):
+    """Qwen2Model's decoder layers over inputs_embeds x (modeling_qwen2.py:952-1060): returns the residual stream before the final norm
+    and what the backward re-reads."""
+    saved, h = [], x
+    for p in params["layers"]:
+        h, s = decoder_layer_forward(h, p, rope, n_q, n_kv, hd, eps)
+        saved.append(s)
+    return h, saved
+
+
+def llm_layers_backward(dh, saved, params, rope, n_q, n_kv, hd, eps=1e-6):
     layer_grads = [None] * len(saved)
     for i in range(len(saved) - 1, -1, -1):
         dh, layer_grads[i] = decoder_layer_backward(dh, saved[i], params["layers"][i], rope, n_q, n_kv, hd, eps)
         saved[i] = None                                               # the layer's activations are no longer needed
-    return loss, dh, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
+    return dh, layer_grads
 
 
 def accumulate_grads(total, grads):
@@ -473,3 +486,71 @@ class ZeroAdamW:
             full = self.D.all_gather_params(self.mine, self.per * self.world, self.bucket)
         self.flat.copy_(full)
         return self.params
+
+
+# ------------------------------------------------------------------------------ grounding samples (ScanRefer / Multi3DRefer)
+
+
+def _ground_head_forward(x, hp):
+    """ground_head_obj / ground_head_query (llava_qwen.py:99-110): Linear, ReLU, LayerNorm (eps 1e-5), Linear."""
+    h1 = ops.gemm(x, hp["w0"], bias=hp["b0"], epilogue=ops.EPI_BIAS_RELU)
+    hn = ops.layernorm(h1, hp["ln_w"], hp["ln_b"], 1e-5)
+    return ops.gemm(hn, hp["w3"], bias=hp["b3"], epilogue=ops.EPI_BIAS), (x, h1, hn)
+
+
+def _ground_head_backward(dout, saved, hp):
+    x, h1, hn = saved
+    dhn, d_w3, d_b3 = linear_backward(hn, hp["w3"], dout, need_db=True)
+    dh1, d_lnw, d_lnb = ops.layernorm_grad(h1, hp["ln_w"], dhn, 1e-5)
+    dz = ops.gelu_grad(h1, dh1, tanh_form=2)                                     # ReLU: h1 > 0 iff its pre-activation was
+    dx, d_w0, d_b0 = linear_backward(x, hp["w0"], dz, need_db=True)
+    return dx, {"w0": d_w0, "b0": d_b0, "ln_w": d_lnw, "ln_b": d_lnb, "w3": d_w3, "b3": d_b3}
+
+
+def ground_sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_ids, ground_row, obj_mask, box_pe, positive, rope, frames,
+                                   n_q, n_kv, hd, temperature=0.07, tokens=729, side=27, n=14, eps=1e-6):
+    """A grounding sample of the joint training (llava_qwen.py:121-160 -> predict_box :239-310, object features llava_arch.py:351-376,
+    479-501): the same tower -> projector -> splice -> decoder as sample_forward_backward, but the loss is the infonce loss between the
+    <ground> token's final hidden state and the object proposals' features (masked means of the projector's patch rows + the box-centre
+    PE, and the learnt zero-target row), each through its head.  ground_row: the <ground> label token's row in inputs_embeds; obj_mask
+    uint8 [n_obj, frames * tokens] (v3d_object_patch_mask); box_pe [n_obj, H] (sin3d PE of the discretised box centres: no gradient);
+    positive uint8 [n_obj + 1] (the last entry = the zero-target, set when the sample has no target box).
+    params additionally holds "ground": {"obj": head, "query": head, "zero_target" [H]} (head = {w0, b0, ln_w, ln_b, w3, b3}).
+    Returns (loss, scores f32 [n_obj + 1], grads) - grads["llm"] has no "lm_head" entry (the LM head takes no part)."""
+    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens)
+    pj, gp = params["projector"], params["ground"]
+    y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
+    H = y.shape[1]
+    n_pre, n_post, n_vis = pre_ids.numel(), post_ids.numel(), frames * n * (n + 1)
+    x = torch.empty((n_pre + n_vis + n_post, H), dtype=y.dtype, device=y.device)
+    if n_pre:
+        ops.embed_gather(params["embed"], pre_ids, out=x[:n_pre])
+    ops.visual_tokens(y.view(frames, tokens, H), voxel_ids, pe_table, params["newline"], side=side, n=n, pool=True, out=x[n_pre:n_pre + n_vis])
+    if n_post:
+        ops.embed_gather(params["embed"], post_ids, out=x[n_pre + n_vis:])
+    h, lsaved = llm_layers_forward(params["llm"], x, rope, n_q, n_kv, hd, eps)
+    # predict_box: the query is the final-norm hidden state of the <ground> row; the objects are masked means of the projector rows
+    hq = h[ground_row:ground_row + 1]
+    query_in = ops.rmsnorm(hq, params["llm"]["norm"], eps)
+    obj_feat = ops.masked_mean(y, obj_mask, add=box_pe)
+    of = torch.cat([obj_feat, gp["zero_target"][None].to(obj_feat.dtype)], 0).contiguous()
+    obj_out, osaved = _ground_head_forward(of, gp["obj"])
+    q_out, qsaved = _ground_head_forward(query_in, gp["query"])
+    loss, scores, d_obj_out, d_q_out = ops.ground_infonce(obj_out, q_out[0], positive, temperature)
+    # backward
+    d_of, g_obj = _ground_head_backward(d_obj_out, osaved, gp["obj"])
+    d_qin, g_query = _ground_head_backward(d_q_out[None].contiguous(), qsaved, gp["query"])
+    d_hq, d_norm = ops.rmsnorm_grad(hq, params["llm"]["norm"], d_qin, eps)
+    dh = torch.zeros_like(h)
+    ops.copy_rows(d_hq, dh[ground_row:ground_row + 1])
+    dx, layer_grads = llm_layers_backward(dh, lsaved, params["llm"], rope, n_q, n_kv, hd, eps)
+    d_embed = torch.zeros_like(params["embed"])
+    text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
+    dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
+    dy = dfeat.view(frames * tokens, H)
+    ops.masked_mean_grad(obj_mask, d_of[:-1].contiguous(), dy, accumulate=True)       # the object features' share of the projector rows' gradient
+    dfeat_in, pgrads = projector_backward(dy, psaved, pj["w1"], pj["w2"])
+    vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
+    return loss, scores, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed,
+                          "llm": {"layers": layer_grads, "norm": d_norm},
+                          "ground": {"obj": g_obj, "query": g_query, "zero_target": d_of[-1].contiguous()}}
