@@ -489,8 +489,10 @@ def test_whole_sample_step_matches_autograd(ops, train):
     cu = lambda t: train._tree_map(lambda a: a.cuda(), t)
     params = {"vision": {"patch_w": patch_w.cuda(), "patch_b": patch_b.cuda(), "pos": pos.cuda(), "layers": [train.siglip_pad_layer(cu(l)) for l in vit]},
               "projector": cu(proj), "newline": newline.cuda(), "embed": embed.cuda(), "llm": cu(llm)}
+    coord_rows = torch.tensor([9 + frames * 14 * 15 + 4, 9 + frames * 14 * 15 + 11])   # two <coord> tokens of a Scan2Cap prompt (llava_arch.py:697-700)
+    coord_pe = mk(H, s=0.5)
     loss, grads = train.sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), labels.cuda(), rope,
-                                                frames, n_q, n_kv, hd)
+                                                frames, n_q, n_kv, hd, coord_rows=coord_rows.cuda(), coord_pe=coord_pe.cuda())
 
     # ---- reference (f32 autograd over the same 16-bit parameters)
     f32 = lambda t: train._tree_map(lambda a: a.float().requires_grad_(), t)
@@ -505,6 +507,7 @@ def test_whole_sample_step_matches_autograd(ops, train):
     tok = pooled + pe.view(frames, 14, 14, H)
     vis = torch.cat([tok, r_nl[None, None, None, :].expand(frames, 14, 1, H)], 2).reshape(-1, H)
     x = torch.cat([r_emb[pre_ids], vis, r_emb[post_ids]], 0)
+    x = x.index_add(0, coord_rows, coord_pe.float()[None].expand(2, H))
     for p in r_llm["layers"]:
         x = _layer_ref(x, p, n_q, n_kv, hd, 1e-6)
     logits = _rmsnorm_ref(x, r_llm["norm"], 1e-6) @ r_llm["lm_head"].t()

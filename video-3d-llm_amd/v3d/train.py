@@ -386,16 +386,10 @@ def siglip_tower_backward(dh, saved, vp, frames, tokens=729):
     return {"patch_w": d_patch_w, "patch_b": d_patch_b, "pos": d_pos, "layers": grads}
 
 
-def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_ids, labels, rope, frames, n_q, n_kv, hd, tokens=729, side=27, n=14):
-    """One training sample end to end on the device (llava_qwen.py:121-205 -> llava_arch.py:336-836 -> modeling_qwen2.py:1145-1217):
-    SigLIP tower -> mm_projector -> bilinear pool + 3-D PE + newline rows, spliced between the embedded text rows -> Qwen2 with labels;
-    then the backward of all of it.  params: {"vision", "projector": {w1, b1, w2, b2}, "newline" [H], "embed" [vocab, H], "llm"};
-    patches [frames * tokens, kpad] (v3d_patchify of the preprocessed frames), voxel_ids [frames, n, n, 3] int32 (the discretised patch
-    coordinates: no gradient, llava_arch.py:515), pre_ids / post_ids: the text token ids around <image> (device int64), labels [S].
-    Returns (loss, grads in params' structure; "embed" is a dense [vocab, H] gradient with the text rows' sums)."""
-    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens)
-    pj = params["projector"]
-    y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
+def _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n, coord_rows=None, coord_pe=None):
+    """prepare_inputs_labels_for_multimodal for one sample with one <image> (llava_arch.py:650-836): text rows | visual rows | text rows;
+    coord_rows / coord_pe: the PE of the discretised box centre added to the rows of the <coord> text tokens (Scan2Cap prompts,
+    llava_arch.py:416-417, 697-700) - no parameters, so the backward passes those rows' gradient through to the embedding."""
     H = y.shape[1]
     n_pre, n_post, n_vis = pre_ids.numel(), post_ids.numel(), frames * n * (n + 1)
     x = torch.empty((n_pre + n_vis + n_post, H), dtype=y.dtype, device=y.device)
@@ -404,6 +398,25 @@ def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_
     ops.visual_tokens(y.view(frames, tokens, H), voxel_ids, pe_table, params["newline"], side=side, n=n, pool=True, out=x[n_pre:n_pre + n_vis])
     if n_post:
         ops.embed_gather(params["embed"], post_ids, out=x[n_pre + n_vis:])
+    if coord_rows is not None and coord_rows.numel():
+        ops.add_row(x, coord_rows, coord_pe)
+    return x, n_pre, n_vis
+
+
+def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_ids, labels, rope, frames, n_q, n_kv, hd, tokens=729, side=27, n=14,
+                            coord_rows=None, coord_pe=None):
+    """One training sample end to end on the device (llava_qwen.py:121-205 -> llava_arch.py:336-836 -> modeling_qwen2.py:1145-1217):
+    SigLIP tower -> mm_projector -> bilinear pool + 3-D PE + newline rows, spliced between the embedded text rows -> Qwen2 with labels;
+    then the backward of all of it.  params: {"vision", "projector": {w1, b1, w2, b2}, "newline" [H], "embed" [vocab, H], "llm"};
+    patches [frames * tokens, kpad] (v3d_patchify of the preprocessed frames), voxel_ids [frames, n, n, 3] int32 (the discretised patch
+    coordinates: no gradient, llava_arch.py:515), pre_ids / post_ids: the text token ids around <image> (device int64), labels [S];
+    coord_rows (device int64) / coord_pe [H]: Scan2Cap's <coord> rows and the box-centre PE added to them.
+    Returns (loss, grads in params' structure; "embed" is a dense [vocab, H] gradient with the text rows' sums)."""
+    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens)
+    pj = params["projector"]
+    y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
+    H = y.shape[1]
+    x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n, coord_rows, coord_pe)
     loss, dx, llm_grads = llm_forward_backward(params["llm"], x, labels, rope, n_q, n_kv, hd)
     d_embed = torch.zeros_like(params["embed"])
     text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
@@ -521,13 +534,7 @@ def ground_sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids
     pj, gp = params["projector"], params["ground"]
     y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
     H = y.shape[1]
-    n_pre, n_post, n_vis = pre_ids.numel(), post_ids.numel(), frames * n * (n + 1)
-    x = torch.empty((n_pre + n_vis + n_post, H), dtype=y.dtype, device=y.device)
-    if n_pre:
-        ops.embed_gather(params["embed"], pre_ids, out=x[:n_pre])
-    ops.visual_tokens(y.view(frames, tokens, H), voxel_ids, pe_table, params["newline"], side=side, n=n, pool=True, out=x[n_pre:n_pre + n_vis])
-    if n_post:
-        ops.embed_gather(params["embed"], post_ids, out=x[n_pre + n_vis:])
+    x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n)
     h, lsaved = llm_layers_forward(params["llm"], x, rope, n_q, n_kv, hd, eps)
     # predict_box: the query is the final-norm hidden state of the <ground> row; the objects are masked means of the projector rows
     hq = h[ground_row:ground_row + 1]
