@@ -14,7 +14,10 @@
 // Seven products instead of the minimal five (S and dP are formed in both kernels): that buys a dQ without atomics and a
 // deterministic result.  The images are double-buffered (the next tile's LDS-DMA flies under the current tile's MFMAs) and the
 // fragments are read through two register rings by asm statements with counted waits (hipcc puts a vmcnt(0) in front of LDS reads it
-// can see, which would drain the prefetch): eight reads fly under the eight MFMAs of the previous ring.  One workgroup per CU (the accumulators of both gradients live in AGPRs); no finer software pipeline yet.
+// can see, which would drain the prefetch): eight reads fly under the eight MFMAs of the previous ring.  One workgroup per CU (the accumulators of both gradients live in AGPRs); no finer software pipeline yet.  The softmax is taken a quarter
+// (16 rows of the tile) at a time, each quarter's MFMAs issued before the next quarter's exponentials (measured: no faster than all
+// four quarters first - with one wave per SIMD the kernel is bound by exposed LDS / issue latency, 5.5-6 k cycles per tile against
+// 2 k of MFMA; two waves per SIMD need the accumulators of one gradient only, i.e. a third recomputation of S).
 #include "v3d_common.h"
 
 namespace v3d {
@@ -53,6 +56,8 @@ struct BwdArgs {
   int S, Hq, group, B, causal;
   float scale, scale_log2;
 };
+
+template <int N> struct IntC { static constexpr int value = N; };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -123,6 +128,21 @@ __device__ __forceinline__ void tr_frags_issue(unsigned image_lds, int lane, int
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8192" : "=v"(f[5]) : "v"(a1));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[6]) : "v"(a0));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:12288" : "=v"(f[7]) : "v"(a1));
+}
+
+// The same fragments by ROW BLOCK: f[2 dt + {0,1}] = the 16 rows of block S4 for the four d tiles dt - what the four products of one
+// softmax quarter need (the quarter's MFMAs then run while the next quarter's exponentials are computed).
+template <int S4> __device__ __forceinline__ void tr_block_issue(unsigned image_lds, int lane, v2i (&f)[8]) {
+  const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3, h = lane >> 5;
+  const int chunk_lo = 2 * (g & 1) + (pp >> 1), byte = 8 * (pp & 1);
+  const int row0 = 4 * h + qq;
+  const unsigned a0 = image_lds + row0 * BW_ROW + byte + ((chunk_lo ^ swz(row0)) << 4);
+  const unsigned a1 = image_lds + (row0 + 8) * BW_ROW + byte + ((chunk_lo ^ swz(row0 + 8)) << 4);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[2 * dt]) : "v"(a0 ^ ((unsigned)dt << 6)), "n"(S4 * 4096));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[2 * dt + 1]) : "v"(a1 ^ ((unsigned)dt << 6)), "n"(S4 * 4096));
+  }
 }
 
 template <typename T> __device__ __forceinline__ v4i pack8(const float* e) {
@@ -219,15 +239,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s[1] = M::run(fa[ks], qf[ks], s[1]);
       v2i f0[8], f1[8];
-      tr_frags_issue(lds_k, lane, 0, f0);                 // K^T fragments of the first two d tiles: in flight under dp and the softmax
+      tr_block_issue<0>(lds_k, lane, f0);                 // K^T fragments of the first 16 keys, all four d tiles: in flight under dp
       frags_wait<8>(fb);                                  // (lgkmcnt counts to 15: never more than two rings in flight)
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fb[ks], dof[ks], dp[1]);
-      tr_frags_issue(lds_k, lane, 1, f1);
       const int limit = ((p.causal && qi < p.S - 1) ? qi : p.S - 1) - t * 64 - 4 * h;       // visible iff tile-local key offset <= limit
-      v4i pf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      // a quarter (16 keys) at a time: its exponentials, then its four MFMAs - which run while the next quarter's exponentials are computed
+      auto quarter = [&](auto i_c, const v2i (&f)[8]) {
+        constexpr int i = decltype(i_c)::value;
         float e[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -236,21 +255,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
           const float pr = vis ? __builtin_amdgcn_exp2f(s[i >> 1][r]) : 0.f;
           e[j] = pr * (dp[i >> 1][r] - dl);
         }
-        pf[i] = pack8<T>(e);
-      }
-      auto mma4 = [&](const v2i (&f)[8], int dt) {
+        return pack8<T>(e);
+      };
+      auto mma_block = [&](const v2i (&f)[8], const v4i& b) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
-          acc[dt] = M::run(a, pf[s4], acc[dt]);
+        for (int dt = 0; dt < 4; ++dt) {
+          const v4i a = {f[2 * dt][0], f[2 * dt][1], f[2 * dt + 1][0], f[2 * dt + 1][1]};
+          acc[dt] = M::run(a, b, acc[dt]);
         }
       };
-      frags_wait<8>(f0); mma4(f0, 0);
-      tr_frags_issue(lds_k, lane, 2, f0);
-      frags_wait<8>(f1); mma4(f1, 1);
-      tr_frags_issue(lds_k, lane, 3, f1);
-      frags_wait<8>(f0); mma4(f0, 2);
-      frags_wait<0>(f1); mma4(f1, 3);
+      v4i pf = quarter(IntC<0>{}, f0);
+      tr_block_issue<1>(lds_k, lane, f1);
+      frags_wait<8>(f0); mma_block(f0, pf);
+      pf = quarter(IntC<1>{}, f1);
+      tr_block_issue<2>(lds_k, lane, f0);
+      frags_wait<8>(f1); mma_block(f1, pf);
+      pf = quarter(IntC<2>{}, f0);
+      tr_block_issue<3>(lds_k, lane, f1);
+      frags_wait<8>(f0); mma_block(f0, pf);
+      pf = quarter(IntC<3>{}, f1);
+      frags_wait<0>(f1); mma_block(f1, pf);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                  // the next tile has landed and is visible; everyone is done with this one
@@ -361,11 +385,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
       stat_frags(lds0 + BW_STAT + buf * 512, lane, Lr);
       stat_frags(lds0 + BW_STAT + buf * 512 + 256, lane, Dr);
       v2i f0[8], f1[8];
-      tr_frags_issue(lds_do, lane, 0, f0);               // dO^T and Q^T fragments of the first d tile: in flight under the softmax
-      tr_frags_issue(lds_q, lane, 0, f1);
-      v4i pfp[4], pfs[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      tr_block_issue<0>(lds_do, lane, f0);               // dO^T and Q^T fragments of the first 16 queries, all four d tiles
+      tr_block_issue<0>(lds_q, lane, f1);
+      // a quarter (16 queries) at a time: its probabilities, then its eight MFMAs - which run while the next quarter is computed
+      auto quarter = [&](auto i_c, v4i& bp, v4i& bs) {
+        constexpr int i = decltype(i_c)::value;
         float ep[8], es[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -377,24 +401,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
           ep[j] = pr;
           es[j] = pr * (dp[i >> 1][r] - Dr[4 * (i >> 1) + (r >> 2)][r & 3]);
         }
-        pfp[i] = pack8<T>(ep);
-        pfs[i] = pack8<T>(es);
-      }
-      auto mma4 = [&](const v2i (&f)[8], const v4i (&b)[4], f32x16& acc) {
+        bp = pack8<T>(ep);
+        bs = pack8<T>(es);
+      };
+      auto mma_block = [&](const v2i (&f)[8], const v4i& b, f32x16 (&acc)[4]) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const v4i a = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
-          acc = M::run(a, b[s4], acc);
+        for (int dt = 0; dt < 4; ++dt) {
+          const v4i a = {f[2 * dt][0], f[2 * dt][1], f[2 * dt + 1][0], f[2 * dt + 1][1]};
+          acc[dt] = M::run(a, b, acc[dt]);
         }
       };
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        frags_wait<8>(f0); mma4(f0, pfp, dv[dt]);        // dV^T += dO^T P
-        if (dt < 3) tr_frags_issue(lds_do, lane, dt + 1, f0);
-        if (dt < 3) { frags_wait<8>(f1); } else { frags_wait<0>(f1); }
-        mma4(f1, pfs, dk[dt]);                           // dK^T += Q^T dS
-        if (dt < 3) tr_frags_issue(lds_q, lane, dt + 1, f1);
-      }
+      v4i bp, bs;
+      quarter(IntC<0>{}, bp, bs);
+      frags_wait<8>(f0); mma_block(f0, bp, dv);           // dV^T += dO^T P
+      tr_block_issue<1>(lds_do, lane, f0);
+      frags_wait<8>(f1); mma_block(f1, bs, dk);           // dK^T += Q^T dS
+      tr_block_issue<1>(lds_q, lane, f1);
+      quarter(IntC<1>{}, bp, bs);
+      frags_wait<8>(f0); mma_block(f0, bp, dv);
+      tr_block_issue<2>(lds_do, lane, f0);
+      frags_wait<8>(f1); mma_block(f1, bs, dk);
+      tr_block_issue<2>(lds_q, lane, f1);
+      quarter(IntC<2>{}, bp, bs);
+      frags_wait<8>(f0); mma_block(f0, bp, dv);
+      tr_block_issue<3>(lds_do, lane, f0);
+      frags_wait<8>(f1); mma_block(f1, bs, dk);
+      tr_block_issue<3>(lds_q, lane, f1);
+      quarter(IntC<3>{}, bp, bs);
+      frags_wait<8>(f0); mma_block(f0, bp, dv);
+      frags_wait<0>(f1); mma_block(f1, bs, dk);
     }
     if (more && tid < 128) stat[(buf ^ 1) * 128 + tid] = sv;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
