@@ -57,6 +57,19 @@ struct BwdArgs {
   float scale, scale_log2;
 };
 
+using f32x4_ = __attribute__((ext_vector_type(4))) float;
+// Row statistics of one softmax quarter (accumulator registers 8 (I & 1) .. + 8 of row block I >> 1): x[g][j] = stat[32 (I >> 1) + 16 (I & 1) +
+// 8 g + 4 h + j], for the L and the delta array (256 bytes apart), one asm statement with its wait.
+template <int I> __device__ __forceinline__ void stat_quarter(unsigned stat_lds, int lane, f32x4_ (&L)[2], f32x4_ (&D)[2]) {
+  const unsigned b = stat_lds + 16u * (unsigned)(lane >> 5);
+  constexpr int o = (32 * (I >> 1) + 16 * (I & 1)) * 4;
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(L[0]), "=&v"(L[1]), "=&v"(D[0]), "=&v"(D[1])
+               : "v"(b), "n"(o), "n"(o + 32), "n"(o + 256), "n"(o + 256 + 32)
+               : "memory");
+}
+
 template <int N> struct IntC { static constexpr int value = N; };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -217,32 +230,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
       stage_image(V, (unsigned)p.ldv * 2u, smem + (buf ^ 1) * BW_BUF + BW_TILE, (t + 1) * 64, p.S, wave, lane);
     }
     const unsigned lds_k = lds0 + buf * BW_BUF, lds_v = lds_k + BW_TILE;
-    if (t < n_wave) {
+    {   // (no branch on t < n_wave: tiles past a wave's diagonal are masked to zeros; see the dK/dV kernel)
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[kt][r] = -L; dp[kt][r] = 0.f; }
-      // two fragment rings: the reads of the next eight fragments fly under the eight MFMAs of the current ones
-      v4i fa[8], fb[8];
+      v4i fa[8];                                          // one fragment ring (see the dK/dV kernel)
       row_frags_issue(lds_k, lane, 0, fa);
-      row_frags_issue(lds_v, lane, 0, fb);
-      frags_wait<8>(fa);
+      frags_wait<0>(fa);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s[0] = M::run(fa[ks], qf[ks], s[0]);
-      row_frags_issue(lds_k, lane, 1, fa);
-      frags_wait<8>(fb);
+      row_frags_issue(lds_v, lane, 0, fa);
+      frags_wait<0>(fa);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) dp[0] = M::run(fb[ks], dof[ks], dp[0]);
-      row_frags_issue(lds_v, lane, 1, fb);
-      frags_wait<8>(fa);
+      for (int ks = 0; ks < 8; ++ks) dp[0] = M::run(fa[ks], dof[ks], dp[0]);
+      row_frags_issue(lds_k, lane, 1, fa);
+      frags_wait<0>(fa);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s[1] = M::run(fa[ks], qf[ks], s[1]);
+      row_frags_issue(lds_v, lane, 1, fa);
       v2i f0[8], f1[8];
       tr_block_issue<0>(lds_k, lane, f0);                 // K^T fragments of the first 16 keys, all four d tiles: in flight under dp
-      frags_wait<8>(fb);                                  // (lgkmcnt counts to 15: never more than two rings in flight)
+      frags_wait<8>(fa);                                  // (lgkmcnt counts to 15: never more than two rings in flight)
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fb[ks], dof[ks], dp[1]);
+      for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fa[ks], dof[ks], dp[1]);
       const int limit = ((p.causal && qi < p.S - 1) ? qi : p.S - 1) - t * 64 - 4 * h;       // visible iff tile-local key offset <= limit
       // a quarter (16 keys) at a time: its exponentials, then its four MFMAs - which run while the next quarter's exponentials are computed
       auto quarter = [&](auto i_c, const v2i (&f)[8]) {
@@ -358,38 +370,39 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
       stage_image(DO, (unsigned)p.lddo * 2u, smem + (buf ^ 1) * BW_BUF + BW_TILE, (t + 1) * 64, p.S, wave, lane);
     }
     const unsigned lds_q = lds0 + buf * BW_BUF, lds_do = lds_q + BW_TILE;
-    if (!p.causal || t * 64 + 63 >= wave_first_key) {            // some query of the tile sees some key of this wave
+    {   // every wave computes every tile: a tile none of whose queries sees this wave's keys (the first one, for the upper half of the
+        // workgroup) is masked to zeros - a branch around the MFMAs makes hipcc copy all 128 accumulator registers AGPR <-> VGPR per tile
       f32x16 s[2], dp[2];
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[qh][r] = 0.f; dp[qh][r] = 0.f; }
-      v4i fa[8], fb[8];
-      row_frags_issue(lds_q, lane, 0, fa);
-      row_frags_issue(lds_do, lane, 0, fb);
-      frags_wait<8>(fa);
+      v4i fa[8];                                          // ONE fragment ring: the next eight reads are issued right behind the eight MFMAs
+      row_frags_issue(lds_q, lane, 0, fa);               // that consume the ring (they return while the matrix pipe is still busy)
+      frags_wait<0>(fa);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s[0] = M::run(fa[ks], kf[ks], s[0]);
-      row_frags_issue(lds_q, lane, 1, fa);
-      frags_wait<8>(fb);
+      row_frags_issue(lds_do, lane, 0, fa);
+      frags_wait<0>(fa);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) dp[0] = M::run(fb[ks], vf[ks], dp[0]);
-      row_frags_issue(lds_do, lane, 1, fb);
-      frags_wait<8>(fa);
+      for (int ks = 0; ks < 8; ++ks) dp[0] = M::run(fa[ks], vf[ks], dp[0]);
+      row_frags_issue(lds_q, lane, 1, fa);
+      frags_wait<0>(fa);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) s[1] = M::run(fa[ks], kf[ks], s[1]);
-      frags_wait<0>(fb);
+      row_frags_issue(lds_do, lane, 1, fa);
+      frags_wait<0>(fa);
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fb[ks], vf[ks], dp[1]);
-      f32x4 Lr[8], Dr[8];
-      stat_frags(lds0 + BW_STAT + buf * 512, lane, Lr);
-      stat_frags(lds0 + BW_STAT + buf * 512 + 256, lane, Dr);
+      for (int ks = 0; ks < 8; ++ks) dp[1] = M::run(fa[ks], vf[ks], dp[1]);
+      const unsigned stat_lds = lds0 + BW_STAT + buf * 512;
       v2i f0[8], f1[8];
       tr_block_issue<0>(lds_do, lane, f0);               // dO^T and Q^T fragments of the first 16 queries, all four d tiles
       tr_block_issue<0>(lds_q, lane, f1);
       // a quarter (16 queries) at a time: its probabilities, then its eight MFMAs - which run while the next quarter is computed
       auto quarter = [&](auto i_c, v4i& bp, v4i& bs) {
         constexpr int i = decltype(i_c)::value;
+        f32x4_ Lq[2], Dq[2];
+        stat_quarter<i>(stat_lds, lane, Lq, Dq);
         float ep[8], es[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -397,9 +410,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
           const int row = (i >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;        // query within the tile
           const int qidx = t * 64 + row;
           const bool vis = (!p.causal || key <= qidx) && qidx < p.S;
-          const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(s[i >> 1][r], p.scale_log2, -Lr[4 * (i >> 1) + (r >> 2)][r & 3])) : 0.f;
+          const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(s[i >> 1][r], p.scale_log2, -Lq[j >> 2][j & 3])) : 0.f;
           ep[j] = pr;
-          es[j] = pr * (dp[i >> 1][r] - Dr[4 * (i >> 1) + (r >> 2)][r & 3]);
+          es[j] = pr * (dp[i >> 1][r] - Dq[j >> 2][j & 3]);
         }
         bp = pack8<T>(ep);
         bs = pack8<T>(es);
