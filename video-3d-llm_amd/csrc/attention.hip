@@ -78,6 +78,8 @@ struct AttnArgs {
   int q_pos0;                        // causal: query i sits at key position q_pos0 + i
   float scale_log2;                  // softmax scale * log2(e)
   float* lse;                        // training only (v3d_attention_train): [B, Hq, Sq] row log-sum-exp in scaled log2 units, or null
+  int xcd_p;                         // > 0: 1-D grid, XCD-aware (head, query tile) mapping with xcd_p XCDs per kv head (see attn_prefill_kernel)
+  int n_qt;                          // query tiles per head (the mapped form needs it; the 3-D grid reads gridDim.y)
 };
 
 #ifdef V3D_ATTN_PROF   // tools/probes/attn_prof.hip only: per-wave cycle split of the tile loop (never in the product build)
@@ -106,6 +108,13 @@ template <int N> struct IntC { static constexpr int value = N; };
 // AT_RAISE (p <= 2^AT_RAISE stays far inside f32 / 16-bit range) - after the first tiles that is rare, so the common
 // tile costs one max3 chain, 32 v_exp, 32 adds and 16 packs per lane and no cross-lane traffic at all.
 constexpr float AT_RAISE = 8.0f;
+// r03: the raise is DETECTED from the tile's row-sum share instead of a max3 chain over the scores: every p is positive, so a lane
+// whose 32 probabilities sum to <= AT_LS_LIMIT holds no p > AT_LS_LIMIT, i.e. no score above log2(AT_LS_LIMIT) < AT_RAISE (255
+// rather than 256 leaves v_exp_f32's last-place error on the safe side).  Only when some lane's share exceeds the limit does the
+// wave compute the maxima and take the decision exactly as before (per lane: raise iff the query's maximum > AT_RAISE) - so the
+// outputs are bit-identical to the max-first form, the common tile loses 18 dependent VALU operations and, above all, the
+// exponentials no longer wait for the end of the score MFMA chain plus a reduction.
+constexpr float AT_LS_LIMIT = 255.0f;
 
 // KSV: k-steps of QK^T that can be non-zero (head dims >= d_out are zeroed in Q): SigLIP's 72-wide heads on the 96-wide tile
 // need 5 of the 6 (the sixth multiplies zeros)
@@ -124,8 +133,24 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   // Grid = (head, query tile, batch): workgroups are dispatched x-fastest, so ALL heads' heaviest (last, causal)
   // query tiles start first and the lightest ones fill the tail (longest-processing-time order; with the query
   // tile fastest the last heads' 107-tile workgroups started late and left 40 % of the launch half empty).
-  const int qt = (int)gridDim.y - 1 - (int)blockIdx.y;
-  const int head = blockIdx.x, b = blockIdx.z;
+  // r03, xcd_p > 0 (causal GQA prefill with 8 % Hkv == 0): 1-D grid.  Workgroups go to the XCDs round-robin by their linear id, and
+  // each XCD has its own L2, so id -> (head, query tile) is chosen such that an XCD only ever works on ONE kv head (xcd_p XCDs
+  // per kv head): the 7 query heads x all query tiles that share a K/V stream (3.5 MB at S = 6.8k) meet in one 4 MB L2 instead of
+  // all four kv heads' K/V passing through every L2.  Within an XCD the heaviest query tiles still come first.
+  int qt, head, b;
+  if (p.xcd_p > 0) {
+    const int n_kv = p.Hq / p.group, per_b = ((p.Hq * p.n_qt + 7) >> 3) << 3;
+    b = (int)blockIdx.x / per_b;
+    const int l = (int)blockIdx.x - b * per_b;
+    const int xcd = l & 7, kvh = xcd % n_kv, slot = xcd / n_kv;
+    const int jj = (l >> 3) * p.xcd_p + slot;
+    if (jj >= p.group * p.n_qt) return;          // padding of the grid to a multiple of 8 (whole workgroup)
+    head = kvh * p.group + jj % p.group;
+    qt = p.n_qt - 1 - jj / p.group;
+  } else {
+    qt = (int)gridDim.y - 1 - (int)blockIdx.y;
+    head = blockIdx.x; b = blockIdx.z;
+  }
   const int hk = head / p.group;
   const int q0 = qt * AT_BQ;
 
@@ -184,6 +209,29 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   };
   auto stage_k = [&](int buf, int t) { stage(K, ldk_b, smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW, t); };
   auto stage_v = [&](int buf, int t) { stage(V, ldv_b, smem + buf * 2 * AT_TILE + AT_TILE + (wave * 16) * AT_ROW, t); };
+  // r03, steady state (every row of the tile exists): the per-lane part of the four piece addresses is constant, the tile's base
+  // is wave-uniform and advances on the scalar unit - no v_mad_u64 / v_min per piece in the vector issue stream (8 pieces per
+  // step cost 8 x (add, min, 64-bit mad) = ~190 issue cycles of a step's ~1000).
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int chunk = st_chunk0 ^ i;
+    if (CH < 16) chunk = chunk < CH ? chunk : CH - 1;
+    koff[i] = (unsigned)(st_row0 + 4 * i) * ldk_b + (unsigned)chunk * 16u;
+    voff[i] = (unsigned)(st_row0 + 4 * i) * ldv_b + (unsigned)chunk * 16u;
+  }
+  // (inline asm: with the builtin, hipcc hoists the zero-extension of the loop-invariant offsets out of the loop, then no longer
+  //  matches the scalar-base + 32-bit-offset form and spends a 64-bit vector add and a register pair per piece)
+  const unsigned lds_wave0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(wave * 16) * AT_ROW;
+  auto stage_fast = [&](const uint16_t* src, unsigned ld_b, const unsigned (&off)[4], unsigned lds_dst, int t) {
+    const char* base = (const char*)src + (size_t)t * (size_t)(AT_BKV * ld_b);      // wave-uniform: scalar registers
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   : : "v"(off[i]), "s"(base), "s"(lds_dst + (unsigned)(i * 4 * AT_ROW)) : "memory", "m0");
+  };
+  auto stage_k_fast = [&](int buf, int t) { stage_fast(K, ldk_b, koff, lds_wave0 + buf * 2 * AT_TILE, t); };
+  auto stage_v_fast = [&](int buf, int t) { stage_fast(V, ldv_b, voff, lds_wave0 + buf * 2 * AT_TILE + AT_TILE, t); };
 
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   // ---- per-lane LDS read addresses (buffer 0; buffer 1 and the key sub-blocks are immediate offsets) ----
@@ -261,12 +309,12 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     }
   };
 
-  // Softmax part 1 for tile t (lane = one query; keys of register r: (r&3) + 8(r>>2) + 4h + 32kt): mask, max,
-  // and the (rare) raise of the running maximum.  Returns the factor O and l must be multiplied by (1 = untouched).
-  auto softmax_prep = [&](f32x16 (&s)[2], int t) -> float {
+  // Softmax part 1 for tile t (lane = one query; keys of register r: (r&3) + 8(r>>2) + 4h + 32kt): the mask (diagonal / tail
+  // tiles only, wave-uniform) ...
+  auto mask_scores = [&](f32x16 (&s)[2], int t) {
     const int kv0 = t * AT_BKV;
     const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > wave_first_pos) || (kv0 + AT_BKV > p.Sk);
-    if (need_mask) {   // wave-uniform; only diagonal / tail tiles pay for it (compare + select per score)
+    if (need_mask) {   // only diagonal / tail tiles pay for it (compare + select per score)
       int last = p.Sk - 1;
       if (CAUSAL) last = q_pos < last ? q_pos : last;
       const int limit = last - kv0 - 4 * h;            // visible iff tile-local key offset <= limit
@@ -276,26 +324,27 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r)
           s[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : s[kt][r];
     }
+  };
+  // ... and the raise of the running maximum: called for tile 0 (which FIXES the maximum) and for the rare tile whose row-sum
+  // share crossed AT_LS_LIMIT.  Subtracts the raise from the scores and returns the factor O and l must be multiplied by
+  // (1 = this lane's reference stays).
+  auto raise_max = [&](f32x16 (&s)[2], int t) -> float {
     float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-    float alpha = 1.0f;
-    if (t == 0 || __any(mx > AT_RAISE)) {              // wave-uniform
-      const float mp = fmaxf(mx, __shfl_xor(mx, 32));    // both key halves of the query
-      // the first tile FIXES the maximum, later ones only raise it - and only for the queries that crossed the threshold
-      // themselves: the branch is wave-uniform, the decision per lane, so a query's rounding history depends on its own
-      // scores alone and its output bits do not change with the rows that happen to share its wave (batch composition,
-      // position of the row inside the query tile: tests/test_gpu_scene_reuse.py)
-      float d = t == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);
-      d = mp == -INFINITY ? 0.f : d;
+    const float mp = fmaxf(mx, __shfl_xor(mx, 32));    // both key halves of the query
+    // the first tile FIXES the maximum, later ones only raise it - and only for the queries that crossed the threshold
+    // themselves: the decision is per lane, so a query's rounding history depends on its own scores alone and its output
+    // bits do not change with the rows that happen to share its wave (batch composition, position of the row inside the
+    // query tile: tests/test_gpu_scene_reuse.py)
+    float d = t == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);
+    d = mp == -INFINITY ? 0.f : d;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] -= d;
-      m_run += d;
-      alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);     // nothing accumulated yet at t = 0
-    }
-    return alpha;
+      for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+    m_run += d;
+    return t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);       // nothing accumulated yet at t = 0
   };
   // Softmax part 2, one quarter: 8 scores -> exp2 -> one P^T fragment (k order of the V^T fragments) + row-sum share.
   auto softmax_quarter = [&](const f32x16 (&s)[2], int i, Frag16& pf, float& ls0, float& ls1) {
@@ -333,14 +382,19 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     f32x16 s[2];
     V3D_STAMP(ts0);
     if (do_qk) qk_fill(IntC<1 - PAR>{});
-    if (FULL || t + 2 < n_tiles) stage_k(PAR, t + 2);          // K[PAR] (tile t) was consumed one step ago
-    if (FULL || t + 1 < n_tiles) stage_v(1 - PAR, t + 1);      // V[1-PAR] (tile t-1) was consumed one step ago
+    if constexpr (FULL) {
+      stage_k_fast(PAR, t + 2);                                // K[PAR] (tile t) was consumed one step ago
+      stage_v_fast(1 - PAR, t + 1);                            // V[1-PAR] (tile t-1) was consumed one step ago
+    } else {
+      if (t + 2 < n_tiles) stage_k(PAR, t + 2);
+      if (t + 1 < n_tiles) stage_v(1 - PAR, t + 1);
+    }
     if (do_qk) qk_run(IntC<1 - PAR>{}, s);
     V3D_STAMP(ts1);
     v2i va[8], vc[8];          // V^T fragments [2*s4 + half], ring of two d-tiles
     if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
-    float alpha = 1.0f, ls0 = 0.f, ls1 = 0.f;
-    if (do_qk) alpha = softmax_prep(s, t + 1);
+    float ls0 = 0.f, ls1 = 0.f;
+    if (do_qk) mask_scores(s, t + 1);
     V3D_STAMP(ts2);
     auto mmav = [&](const v2i* f, int dt, int quarter) {
 #pragma unroll
@@ -368,12 +422,24 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       }
     }
     if (do_qk) {
-      if (__any(alpha != 1.0f)) {     // wave-uniform, rare: the maximum moved, bring O and l to the new reference
+      if (__any(ls0 + ls1 > AT_LS_LIMIT)) {     // wave-uniform, rare: some probability of tile t+1 may exceed 2^AT_RAISE
+        // the scores were consumed in place by the exponentials: form them again (K of tile t+1 stays in its ring buffer until
+        // the next step; same MFMA chain from the same -m, so the same bits), then decide per lane as the max-first form did
+        f32x16 s2[2];
+        qk_fill(IntC<1 - PAR>{});
+        qk_run(IntC<1 - PAR>{}, s2);
+        mask_scores(s2, t + 1);
+        const float alpha = raise_max(s2, t + 1);
+        if (__any(alpha != 1.0f)) {   // the maximum moved: P of tile t+1 again at the new reference, O and l brought to it
+          ls0 = 0.f; ls1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+          for (int i = 0; i < 4; ++i) softmax_quarter(s2, i, pn[i], ls0, ls1);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        l_run *= alpha;
+          for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+          l_run *= alpha;
+        }
       }
       l_run += ls0 + ls1;
     }
@@ -400,13 +466,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     float ls0 = 0.f, ls1 = 0.f;
     qk_fill(IntC<0>{});
     qk_run(IntC<0>{}, s);
-    softmax_prep(s, 0);
+    mask_scores(s, 0);
+    raise_max(s, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) softmax_quarter(s, i, pa[i], ls0, ls1);
     l_run = ls0 + ls1;
   }
   {
-    const int n_full = (n_tiles - 2 < n_wave - 1 ? n_tiles - 2 : n_wave - 1) & ~1;     // steady-state steps, in pairs
+    // steady-state steps, in pairs: tiles t+1 and t+2 exist, this wave computes both, and every row of tile t+2 exists (the
+    // steady state stages with unclamped addresses)
+    int n_full = n_tiles - 2 < n_wave - 1 ? n_tiles - 2 : n_wave - 1;
+    n_full = (n_full < p.Sk / AT_BKV - 2 ? n_full : p.Sk / AT_BKV - 2) & ~1;
+    n_full = __builtin_amdgcn_readfirstlane(n_full);
     int t = 0;
     for (; t < n_full; t += 2) {
       step(IntC<0>{}, IntC<1>{}, t, pa, pb);
@@ -1558,7 +1629,18 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
 #undef V3D_ATTN64
     return check_launch("v3d_attention (64 queries per wave)");
   }
-  const dim3 grid(p.Hq, (p.Sq + AT_BQ - 1) / AT_BQ, B), block(256);
+  dim3 grid(p.Hq, (p.Sq + AT_BQ - 1) / AT_BQ, B), block(256);
+  AttnArgs pm = p;
+  pm.n_qt = (p.Sq + AT_BQ - 1) / AT_BQ;
+  pm.xcd_p = 0;
+  {   // XCD-aware mapping (attn_prefill_kernel): causal prefill at head dim 128 with the kv heads dividing the 8 XCDs
+    const int n_kv = p.Hq / p.group;
+    static const int xcd_env = getenv("V3D_ATTN_XCD") ? atoi(getenv("V3D_ATTN_XCD")) : 1;
+    if (xcd_env && D == 128 && causal && n_kv <= 8 && 8 % n_kv == 0 && pm.n_qt > 1) {
+      pm.xcd_p = 8 / n_kv;
+      grid = dim3((unsigned)(((p.Hq * pm.n_qt + 7) / 8 * 8) * B), 1, 1);
+    }
+  }
 #define V3D_ATTN(DD, CC, KK, LL)                                                                                    \
   {                                                                                                               \
     auto k = attn_prefill_kernel<T, DD, CC, KK, LL>;                                                              \
@@ -1568,7 +1650,7 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
       if (e != hipSuccess) { set_error("v3d_attention: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
       done = true;                                                                                                \
     }                                                                                                             \
-    hipLaunchKernelGGL(k, grid, block, AT_LDS, st, p);                                                            \
+    hipLaunchKernelGGL(k, grid, block, AT_LDS, st, pm);                                                           \
   }
   if (p.lse && D != 128) { set_error("v3d_attention_train: head dim 128 only (zero-pad narrower heads)"); return V3D_E_UNSUPPORTED; }
   if (D == 128 && causal && p.lse) V3D_ATTN(128, true, 8, true)
@@ -1607,6 +1689,7 @@ static int attention_entry(const void* q, const void* k, const void* v, void* o,
   p.d_out = d_out; p.q_pos0 = causal ? q_pos0 : 0;
   p.scale_log2 = scale * 1.44269504088896340736f;
   p.lse = lse;
+  p.xcd_p = 0; p.n_qt = 0;
   hipStream_t st = (hipStream_t)stream;
   if (Sq <= 8 && B == 1 && D == 128 && causal && !p.lse) {   // decode: stream the cache
     if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_kernel<bf16_t, 128>), dim3(Sq, Hq), dim3(256), 0, st, p);
