@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 3   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ... */
+#define V3D_ABI_VERSION 4   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds */
 
 enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
+enum { V3D_U8_HWC = 16 };   /* v3d_resize_bicubic_u8 only: 8-bit interleaved output, no normalisation */
 
 enum {
   V3D_OK = 0,
@@ -330,6 +331,21 @@ int v3d_copy_rows_bcast(const void* in, int64_t ldi, void* out, int64_t ldo, int
  * frames [F,H,W,3] u8 (device) -> out [F,3,H,W];  v = f32(f64(u8) * rescale);  out = T((v - mean[c]) / std[c]) in f32. */
 int v3d_preprocess_rgb_u8(const uint8_t* frames, int F, int H, int W, const float* mean_host, const float* std_host,
                           double rescale, void* out, int dtype, void* stream);
+
+/* a6 / a7, RGB half: `frame.resize((new_w, crop))` + centre crop of VideoProcessor.preprocess (video_utils.py:285-306), i.e.
+ * Pillow's Image.resize for 8-bit RGB with its default BICUBIC filter, reproduced bit for bit (libImaging Resample.c: horizontal
+ * pass, 8-bit intermediate, vertical pass; 22-bit fixed-point coefficients; clip8), optionally fused with v3d_preprocess_rgb_u8
+ * (SigLipImageProcessor.preprocess, siglip_encoder.py:47-67).
+ * frames [F,H,W,3] u8 (device).  The resized image would be OH x OW; only the window (crop_top, crop_left, crop_h, crop_w) of it is
+ * computed.  bounds_* [n][2] int32 = (first source index, tap count) and coeffs_* [n][ksize_*] int32 per output column (h, n = OW)
+ * / row (v, n = OH): DEVICE arrays holding what Pillow's precompute_coeffs + normalize_coeffs_8bpc produce for (W -> OW) and
+ * (H -> OH) (v3d.ops.pil_resample_tables; the double arithmetic stays on the caller's side like dim_t / inv_freq do).
+ * out_dtype V3D_U8_HWC: out [F,crop_h,crop_w,3] u8 (mean / std may be null);  V3D_F32 / F16 / BF16: out [F,3,crop_h,crop_w] =
+ * T((f32(f64(u8) * rescale) - mean[c]) / std[c]).  At most 32 taps per pass (reductions up to ~7x). */
+int v3d_resize_bicubic_u8(const uint8_t* frames, int F, int H, int W, int OH, int OW, const int32_t* bounds_h,
+                          const int32_t* coeffs_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeffs_v, int ksize_v,
+                          int crop_top, int crop_left, int crop_h, int crop_w, const float* mean_host, const float* std_host,
+                          double rescale, void* out, int out_dtype, void* stream);
 
 /* K10 input: SigLipVisionEmbeddings' Conv2d(kernel = stride = patch), siglip_encoder.py:156-172, as a
  * GEMM: gathers images [B,3,S,S] into rows [B*(S/patch)^2, kpad], columns (c, ky, kx) zero padded. */

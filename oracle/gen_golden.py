@@ -14,6 +14,7 @@ Usage:  python oracle/gen_golden.py [--only NAME ...]
 import sys
 sys.dont_write_bytecode = True  # never write into the reference tree
 import argparse
+import io
 import json
 import os
 import random
@@ -488,6 +489,58 @@ def g_imgproc():
     assert pv.dtype == torch.float32 and tuple(pv.shape) == (2, 3, 384, 384)
     save("imgproc", frames=frames[:, :96, :96].copy(), pixel_values=pv[:, :, :96, :96].numpy().copy(),
          full_sum=np.array(pv.double().sum().item()), small=small, small_pixel_values=pv_small[0, :, ::16, ::16].numpy().copy())
+
+
+def g_rgb_resize():
+    """a6 / a7, RGB half: the frame loop of VideoProcessor.preprocess, strategy "center_crop" (video_utils.py:285-306) - executed from
+    the reference's own source text (lines read at run time, nothing stored) on PIL images: PIL `frame.resize((new_w, crop))` with
+    the default filter + `frame.crop(...)`.  Frames: noise and smooth content, 640 x 480 (the ScanNet size) -> 512 x 384 -> 384 x 384,
+    plus a small 50 x 70 frame -> crop 24 (another ratio, clamped taps at every border).  Stored: inputs as PNG-free raw uint8,
+    outputs as uint8 (the 640 x 480 outputs as a strided sample + an exact checksum to stay small)."""
+    import inspect
+    import textwrap
+    from PIL import Image
+    from llava import video_utils as vu
+    src = inspect.getsource(vu.VideoProcessor.preprocess).split("\n")
+    a = next(i for i, l in enumerate(src) if l.strip() == "images = []")
+    b = next(i for i, l in enumerate(src) if "images = [frame.crop(" in l and i > a)
+    body = textwrap.dedent("\n".join(src[a: b + 1]))
+    assert "images = [frame.resize((new_width, new_height)) for frame in images]" in body and 'strategy == "center_crop"' in body, body
+
+    class _Proc:
+        def __init__(self, crop):
+            self.crop_size = {"height": crop, "width": crop}
+
+    cv2stub = type("cv2stub", (), {"INTER_NEAREST": 0, "resize": staticmethod(
+        lambda x, dsize, interpolation=None: np.zeros((dsize[1], dsize[0], 3), np.float32))})     # (the coordinate half: a6, elsewhere)
+
+    def run(frames, crop):
+        files = []
+        for fr in frames:
+            buf = io.BytesIO()
+            Image.fromarray(fr).save(buf, format="PNG")          # lossless: the loop's Image.open sees exactly `fr`
+            files.append(io.BytesIO(buf.getvalue()))
+        H, W = frames.shape[1:3]
+        env = {"Image": Image, "frame_files": files, "strategy": "center_crop", "image_processor": _Proc(crop), "cv2": cv2stub,
+               "world_coords": [torch.zeros(H, W, 3) for _ in frames], "H": H, "W": W}
+        exec(body, env)
+        return np.stack([np.asarray(im) for im in env["images"]])
+
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, size=(1, 480, 640, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    smooth = np.stack([(127 + 120 * np.sin(xx / 37.0 + c) * np.cos(yy / 23.0 - c)).astype(np.uint8) for c in range(3)], -1)[None]
+    edges = np.zeros((1, 480, 640, 3), np.uint8)
+    edges[0, ::7] = 255
+    edges[0, :, ::5, 1] = 255
+    big = np.concatenate([noise, smooth, edges])
+    big_out = run(big, 384)
+    assert big_out.shape == (3, 384, 384, 3) and big_out.dtype == np.uint8
+    small = rng.integers(0, 256, size=(2, 50, 70, 3), dtype=np.uint8)
+    small_out = run(small, 24)
+    save("rgb_resize", noise_seed=np.array(77), smooth=smooth[:, ::8, ::8].copy(), big_out_sample=big_out[:, ::4, ::4].copy(),
+         big_out_sum=np.array([int(big_out[i].astype(np.int64).sum()) for i in range(3)]),
+         big_out_rowsum=big_out.astype(np.int64).sum((2, 3)), small=small, small_out=small_out)
 
 
 def _bits(t):

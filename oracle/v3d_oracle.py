@@ -185,6 +185,78 @@ def image_preprocess(frames_u8, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), resca
     return np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32)
 
 
+def _pil_bicubic_filter(x):
+    """Pillow libImaging/Resample.c bicubic_filter (a = -0.5), support 2.0."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_coeffs(in_size, out_size, support=2.0):
+    """Pillow 12.2.0 libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc for box (0, in_size): per output index the
+    first source index, the tap count and the 22-bit fixed-point taps.  (Third-party arithmetic behind the reference's
+    `frame.resize(...)`, video_utils.py:303; Pillow is not under /root/reference - it is importable here and on the GPU box, so this
+    restatement is pinned against PIL itself: tests/test_oracle_golden.py::test_pil_resize_*.)"""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    sup = support * filterscale
+    ksize = int(math.ceil(sup)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - sup + 0.5), 0)
+        xmax = min(int(center + sup + 0.5), in_size) - xmin
+        w = [_pil_bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        bounds[xx] = (xmin, xmax)
+        for x, v in enumerate(w):
+            kk[xx, x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+    return bounds, kk
+
+
+def pil_resize_bicubic(frames_u8, out_hw):
+    """`Image.resize((OW, OH))` of 8-bit RGB frames with Pillow's default filter (BICUBIC), as VideoProcessor.preprocess calls it
+    (video_utils.py:303): ImagingResampleHorizontal_8bpc, then ImagingResampleVertical_8bpc on the 8-bit intermediate;
+    accumulators start at 1 << 21, clip8 = clamp(ss >> 22, 0, 255).  frames_u8 [F,H,W,3] -> [F,OH,OW,3] uint8."""
+    F_, H, W, _ = frames_u8.shape
+    OH, OW = out_hw
+    bh, kh = pil_resample_coeffs(W, OW)
+    bv, kv = pil_resample_coeffs(H, OH)
+    src = frames_u8.astype(np.int64)
+    tmp = np.zeros((F_, H, OW, 3), np.int64)
+    for xx in range(OW):
+        x0, n = bh[xx]
+        acc = (src[:, :, x0:x0 + n, :] * kh[xx, :n].astype(np.int64)[None, None, :, None]).sum(2) + (1 << 21)
+        tmp[:, :, xx] = np.clip(acc >> 22, 0, 255)
+    out = np.zeros((F_, OH, OW, 3), np.int64)
+    for yy in range(OH):
+        y0, n = bv[yy]
+        acc = (tmp[:, y0:y0 + n] * kv[yy, :n].astype(np.int64)[None, :, None, None]).sum(1) + (1 << 21)
+        out[:, yy] = np.clip(acc >> 22, 0, 255)
+    return out.astype(np.uint8)
+
+
+def resize_crop_rgb(frames_u8, crop=384):
+    """The RGB half of VideoProcessor.preprocess, strategy "center_crop" (video_utils.py:297-306): new_height = crop,
+    new_width = int(W * (crop / H)), PIL bicubic resize, centre crop of the columns."""
+    H, W = frames_u8.shape[1:3]
+    new_w = int(W * (crop / H))
+    left = (new_w - crop) // 2
+    return pil_resize_bicubic(frames_u8, (crop, new_w))[:, :, left:left + crop]
+
+
 def bilinear_taps(n_in=27, n_out=14):
     """Source taps of F.interpolate(mode='bilinear', align_corners=False) (ATen
     area_pixel_compute_source_index): src = scale*(o+0.5)-0.5 clamped at 0, scale = n_in/n_out in f32.

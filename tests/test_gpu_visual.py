@@ -328,3 +328,58 @@ def test_preprocess_rgb_bit_exact(golden):
     for dt in (torch.bfloat16, torch.float16):            # 16-bit output = one rounding of the f32 value
         got16 = ops.preprocess_rgb(torch.from_numpy(frames[:2]).cuda(), dtype=dt)
         assert torch.equal(got16.cpu(), torch.from_numpy(want[:2]).to(dt))
+
+
+# ---- a6 / a7 RGB half on the device (r03): Pillow's bicubic resize + centre crop, bit for bit
+
+
+def test_resize_crop_rgb_equals_reference_loop_golden_and_live_pil(ops, golden):
+    """v3d_resize_bicubic_u8 against (1) the fixture produced by the reference's own frame loop (video_utils.py:285-306) and (2) PIL
+    itself run here on the same bytes, at the ScanNet frame size 640 x 480 -> 512 x 384 -> crop 384: every byte equal."""
+    from PIL import Image
+    from test_oracle_golden import _rgb_resize_inputs
+    g = golden("rgb_resize")
+    big = _rgb_resize_inputs(g)
+    got = ops.resize_crop_rgb(torch.from_numpy(big).cuda(), (384, 512), crop=(0, 64, 384, 384)).cpu().numpy()
+    assert np.array_equal(got[:, ::4, ::4], g["big_out_sample"])
+    assert np.array_equal(got.astype(np.int64).sum((2, 3)), g["big_out_rowsum"])
+    for i in range(big.shape[0]):
+        want = np.asarray(Image.fromarray(big[i]).resize((512, 384)).crop((64, 0, 448, 384)))
+        assert np.array_equal(got[i], want)
+    small = g["small"]
+    new_w = int(70 * (24 / 50))
+    left = (new_w - 24) // 2
+    got_s = ops.resize_crop_rgb(torch.from_numpy(small).cuda(), (24, new_w), crop=(0, left, 24, 24)).cpu().numpy()
+    assert np.array_equal(got_s, g["small_out"])
+
+
+@pytest.mark.parametrize("shape", [(48, 64, 38, 51), (30, 40, 45, 60), (97, 33, 20, 31), (16, 16, 16, 24), (480, 640, 384, 384), (968, 1296, 384, 514)])
+def test_resize_rgb_other_sizes_equal_live_pil(ops, shape):
+    """up- and down-scaling, odd sizes, the ScanNet colour-stream size (1296 x 968): whole resized image vs PIL."""
+    from PIL import Image
+    H, W, OH, OW = shape
+    rng = np.random.default_rng(H * 7 + OW)
+    fr = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    got = ops.resize_crop_rgb(torch.from_numpy(fr).cuda(), (OH, OW)).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], np.asarray(Image.fromarray(fr[i]).resize((OW, OH)))), shape
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_resize_crop_fused_with_image_processor_equals_the_two_steps(ops, dtype):
+    """fused output (resize + crop + SigLipImageProcessor's rescale / normalise / CHW) == preprocess_rgb of the 8-bit crops, bit for bit,
+    at the eval shape (32 frames of 640 x 480)."""
+    g = torch.Generator().manual_seed(3)
+    fr = torch.randint(0, 256, (32, 480, 640, 3), generator=g, dtype=torch.uint8).cuda()
+    crops = ops.resize_crop_rgb(fr, (384, 512), crop=(0, 64, 384, 384))
+    want = ops.preprocess_rgb(crops, dtype)
+    got = ops.resize_crop_rgb(fr, (384, 512), crop=(0, 64, 384, 384), dtype=dtype)
+    assert got.shape == (32, 3, 384, 384) and torch.equal(got, want)
+
+
+def test_resize_rejects_bad_windows(ops):
+    fr = torch.zeros((1, 48, 64, 3), dtype=torch.uint8).cuda()
+    with pytest.raises(ops.V3DError):
+        ops.resize_crop_rgb(fr, (38, 51), crop=(0, 40, 38, 24))          # window leaves the resized image
+    with pytest.raises(ops.V3DError):
+        ops.resize_crop_rgb(torch.zeros((1, 4800, 64, 3), dtype=torch.uint8).cuda(), (38, 51))      # 126x vertical reduction: more than 32 taps

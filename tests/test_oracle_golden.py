@@ -172,3 +172,46 @@ def test_convert_pc_to_box(golden):
     g = golden("convert_pc_to_box")
     c, s = O.convert_pc_to_box(g["pc"])
     assert np.array_equal(np.array(c), g["center"]) and np.array_equal(np.array(s), g["size"])
+
+
+# ---- a6 / a7 RGB half: Pillow's bicubic resize (the arithmetic behind video_utils.py:303), restated in oracle/v3d_oracle.py
+
+
+def _rgb_resize_inputs(g):
+    rng = np.random.default_rng(int(g["noise_seed"]))
+    noise = rng.integers(0, 256, size=(1, 480, 640, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    smooth = np.stack([(127 + 120 * np.sin(xx / 37.0 + c) * np.cos(yy / 23.0 - c)).astype(np.uint8) for c in range(3)], -1)[None]
+    assert np.array_equal(smooth[:, ::8, ::8], g["smooth"])          # the regenerated input is the generator's
+    edges = np.zeros((1, 480, 640, 3), np.uint8)
+    edges[0, ::7] = 255
+    edges[0, :, ::5, 1] = 255
+    rng.integers(0, 256, size=(2, 50, 70, 3), dtype=np.uint8)         # (the generator drew `small` next; it is stored explicitly)
+    return np.concatenate([noise, smooth, edges])
+
+
+def test_pil_resize_oracle_matches_reference_loop_golden(golden):
+    g = golden("rgb_resize")
+    big = _rgb_resize_inputs(g)
+    out = O.resize_crop_rgb(big, 384)
+    assert out.shape == (3, 384, 384, 3)
+    assert np.array_equal(out[:, ::4, ::4], g["big_out_sample"])
+    assert np.array_equal(out.astype(np.int64).sum((2, 3)), g["big_out_rowsum"])
+    assert np.array_equal(O.resize_crop_rgb(g["small"], 24), g["small_out"])
+
+
+def test_pil_resize_oracle_matches_live_pil_on_other_sizes():
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    for (H, W, OH, OW) in ((48, 64, 38, 51), (30, 40, 45, 60), (97, 33, 20, 31), (16, 16, 16, 24)):
+        fr = rng.integers(0, 256, size=(1, H, W, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(fr[0]).resize((OW, OH)))
+        assert np.array_equal(O.pil_resize_bicubic(fr, (OH, OW))[0], want), (H, W, OH, OW)
+
+
+def test_product_resample_tables_equal_the_oracles():
+    from v3d import ops
+    for (n_in, n_out) in ((640, 512), (480, 384), (70, 33), (50, 24), (33, 70), (16, 16)):
+        b, k, ks = ops.pil_resample_tables(n_in, n_out)
+        ob, ok = O.pil_resample_coeffs(n_in, n_out)
+        assert ks == ok.shape[1] and np.array_equal(b.numpy(), ob) and np.array_equal(k.numpy(), ok)

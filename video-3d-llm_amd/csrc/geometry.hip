@@ -464,3 +464,130 @@ extern "C" int v3d_preprocess_rgb_u8(const uint8_t* frames, int F, int H, int W,
                                                std_host[1], std_host[2], rescale));
   return check_launch("v3d_preprocess_rgb_u8");
 }
+
+// ------------------------------------------------------------------------------------------
+// a6 / a7, RGB half (r03): VideoProcessor.preprocess's `frame.resize((new_w, crop))` + centre crop (video_utils.py:285-306) on the
+// device, bit for bit what Pillow's Image.resize does for 8-bit RGB with its default filter (BICUBIC): two passes, horizontal then
+// vertical, over 22-bit fixed-point coefficients, the intermediate image rounded to 8 bits (libImaging Resample.c:
+// ImagingResampleHorizontal_8bpc / Vertical_8bpc, clip8 = (ss >> 22) clamped to [0, 255], accumulators start at 1 << 21).  The
+// coefficient tables are the caller's (v3d.ops.pil_resample_tables evaluates precompute_coeffs / normalize_coeffs_8bpc in
+// double, as Pillow does) - integer arithmetic from there on, so there is nothing to round differently.  Optionally fused with
+// SigLipImageProcessor's rescale / normalise / HWC -> CHW (v3d_preprocess_rgb_u8's arithmetic) so that the 8-bit crops never
+// reach HBM.  One workgroup = a tile of RS_TW x th output pixels: the input rows x columns the tile's taps touch are staged in
+// LDS with coalesced byte loads, pass 1 writes the 8-bit intermediate to LDS, pass 2 reads it back.
+constexpr int RS_TW = 64, RS_RMAX = 64, RS_INB = 512, RS_KMAX = 32;
+
+struct ResizeArgs {
+  const uint8_t* src; void* out;
+  const int32_t *bh, *kh, *bv, *kv;        // device tables: bounds [n][2] = (first tap, tap count), coefficients [n][ksize]
+  int F, H, W, OH, OW, ksh, ksv;           // source size, resized size, table row lengths
+  int top, left, ch_h, cw;                 // crop window inside the resized image
+  int th;                                  // tile height
+  float m0, m1, m2, s0, s1, s2;
+  double rescale;
+};
+
+template <typename T, bool NORM>
+__global__ __launch_bounds__(256) void resize_bicubic_kernel(ResizeArgs a) {
+  __shared__ uint8_t s_in[RS_RMAX * RS_INB];
+  __shared__ uint8_t s_tmp[RS_RMAX * RS_TW * 3];
+  __shared__ int32_t s_kh[RS_TW * RS_KMAX], s_kv[RS_RMAX * RS_KMAX];
+  __shared__ int32_t s_bh[RS_TW * 2], s_bv[RS_RMAX * 2];
+  const int tid = threadIdx.x, f = blockIdx.z;
+  const int x0 = a.left + blockIdx.x * RS_TW, y0 = a.top + blockIdx.y * a.th;
+  const int tw = min(RS_TW, a.left + a.cw - x0), th = min(a.th, a.top + a.ch_h - y0);
+  // tables of the tile
+  for (int i = tid; i < tw * 2; i += 256) s_bh[i] = a.bh[x0 * 2 + i];
+  for (int i = tid; i < th * 2; i += 256) s_bv[i] = a.bv[y0 * 2 + i];
+  for (int i = tid; i < tw * a.ksh; i += 256) s_kh[i] = a.kh[x0 * a.ksh + i];
+  for (int i = tid; i < th * a.ksv; i += 256) s_kv[i] = a.kv[y0 * a.ksv + i];
+  __syncthreads();
+  const int r_lo = s_bv[0], r_hi = s_bv[2 * (th - 1)] + s_bv[2 * (th - 1) + 1];
+  const int c_lo = s_bh[0], c_hi = s_bh[2 * (tw - 1)] + s_bh[2 * (tw - 1) + 1];
+  const int R = r_hi - r_lo, nb = (c_hi - c_lo) * 3;
+  if (R > RS_RMAX || nb > RS_INB || R <= 0 || nb <= 0) return;      // (the launcher sized the tile so that this cannot happen)
+  // stage the input window: wave w takes rows w, w + 4, ...; lanes walk the row's bytes
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int r = wave; r < R; r += 4) {
+      const uint8_t* srow = a.src + (((int64_t)f * a.H + r_lo + r) * a.W + c_lo) * 3;
+      for (int bb = lane; bb < nb; bb += 64) s_in[r * RS_INB + bb] = srow[bb];
+    }
+  }
+  __syncthreads();
+  // pass 1 (horizontal): one (row, output column) per thread and turn
+  for (int idx = tid; idx < R * RS_TW; idx += 256) {
+    const int r = idx >> 6, x = idx & (RS_TW - 1);
+    if (x >= tw) continue;
+    const int xmin = s_bh[2 * x] - c_lo, n = s_bh[2 * x + 1];
+    const int32_t* k = s_kh + x * a.ksh;
+    const uint8_t* px = s_in + r * RS_INB + xmin * 3;
+    int ss0 = 1 << 21, ss1 = 1 << 21, ss2 = 1 << 21;
+    for (int t = 0; t < n; ++t) {
+      const int c = k[t];
+      ss0 += (int)px[3 * t] * c; ss1 += (int)px[3 * t + 1] * c; ss2 += (int)px[3 * t + 2] * c;
+    }
+    uint8_t* d = s_tmp + (r * RS_TW + x) * 3;
+    d[0] = (uint8_t)min(255, max(0, ss0 >> 22)); d[1] = (uint8_t)min(255, max(0, ss1 >> 22)); d[2] = (uint8_t)min(255, max(0, ss2 >> 22));
+  }
+  __syncthreads();
+  // pass 2 (vertical) + crop (+ rescale / normalise / CHW)
+  const float mean[3] = {a.m0, a.m1, a.m2}, sd[3] = {a.s0, a.s1, a.s2};
+  for (int idx = tid; idx < th * RS_TW; idx += 256) {
+    const int y = idx >> 6, x = idx & (RS_TW - 1);
+    if (x >= tw) continue;
+    const int ymin = s_bv[2 * y] - r_lo, n = s_bv[2 * y + 1];
+    const int32_t* k = s_kv + y * a.ksv;
+    int ss[3] = {1 << 21, 1 << 21, 1 << 21};
+    for (int t = 0; t < n; ++t) {
+      const uint8_t* px = s_tmp + ((ymin + t) * RS_TW + x) * 3;
+      const int c = k[t];
+      ss[0] += (int)px[0] * c; ss[1] += (int)px[1] * c; ss[2] += (int)px[2] * c;
+    }
+    const int oy = y0 + y - a.top, ox = x0 + x - a.left;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int u = min(255, max(0, ss[c] >> 22));
+      if constexpr (NORM) {
+        const float v = (float)((double)u * a.rescale);
+        ((T*)a.out)[(((int64_t)f * 3 + c) * a.ch_h + oy) * a.cw + ox] = from_f32<T>((v - mean[c]) / sd[c]);
+      } else {
+        ((uint8_t*)a.out)[(((int64_t)f * a.ch_h + oy) * a.cw + ox) * 3 + c] = (uint8_t)u;
+      }
+    }
+  }
+}
+
+extern "C" int v3d_resize_bicubic_u8(const uint8_t* frames, int F, int H, int W, int OH, int OW, const int32_t* bounds_h,
+                                     const int32_t* coeffs_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeffs_v, int ksize_v,
+                                     int crop_top, int crop_left, int crop_h, int crop_w, const float* mean_host, const float* std_host,
+                                     double rescale, void* out, int out_dtype, void* stream) {
+  V3D_REQUIRE(frames && bounds_h && coeffs_h && bounds_v && coeffs_v && out, "v3d_resize_bicubic_u8: null pointer");
+  V3D_REQUIRE(F > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "v3d_resize_bicubic_u8: bad shape");
+  V3D_REQUIRE(crop_top >= 0 && crop_left >= 0 && crop_h > 0 && crop_w > 0 && crop_top + crop_h <= OH && crop_left + crop_w <= OW,
+              "v3d_resize_bicubic_u8: crop window (%d, %d, %d, %d) outside the %d x %d resized image", crop_top, crop_left, crop_h, crop_w, OH, OW);
+  V3D_REQUIRE(ksize_h > 0 && ksize_h <= RS_KMAX && ksize_v > 0 && ksize_v <= RS_KMAX, "v3d_resize_bicubic_u8: at most %d taps per pass", RS_KMAX);
+  V3D_REQUIRE(out_dtype == V3D_U8_HWC || mean_host && std_host, "v3d_resize_bicubic_u8: mean / std needed for a normalised output");
+  // input window of a tile: (tile extent) x scale + taps; the tile shrinks until the window fits the LDS staging
+  auto span = [](int n_out, int in, int out, int ks) { return (int)(((int64_t)n_out * in + out - 1) / out) + ks + 2; };
+  V3D_REQUIRE(span(RS_TW, W, OW, ksize_h) * 3 <= RS_INB, "v3d_resize_bicubic_u8: horizontal reduction %d -> %d too strong for this kernel", W, OW);
+  int th = 16;
+  while (th > 1 && span(th, H, OH, ksize_v) > RS_RMAX) th >>= 1;
+  V3D_REQUIRE(span(th, H, OH, ksize_v) <= RS_RMAX, "v3d_resize_bicubic_u8: vertical reduction %d -> %d too strong for this kernel", H, OH);
+  ResizeArgs a;
+  a.src = frames; a.out = out; a.bh = bounds_h; a.kh = coeffs_h; a.bv = bounds_v; a.kv = coeffs_v;
+  a.F = F; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.ksh = ksize_h; a.ksv = ksize_v;
+  a.top = crop_top; a.left = crop_left; a.ch_h = crop_h; a.cw = crop_w; a.th = th;
+  a.m0 = a.m1 = a.m2 = 0.f; a.s0 = a.s1 = a.s2 = 1.f; a.rescale = rescale;
+  if (mean_host && std_host) { a.m0 = mean_host[0]; a.m1 = mean_host[1]; a.m2 = mean_host[2]; a.s0 = std_host[0]; a.s1 = std_host[1]; a.s2 = std_host[2]; }
+  const dim3 grid((crop_w + RS_TW - 1) / RS_TW, (crop_h + th - 1) / th, F);
+  hipStream_t st = (hipStream_t)stream;
+  switch (out_dtype) {
+    case V3D_U8_HWC: hipLaunchKernelGGL((resize_bicubic_kernel<float, false>), grid, dim3(256), 0, st, a); break;
+    case V3D_F32: hipLaunchKernelGGL((resize_bicubic_kernel<float, true>), grid, dim3(256), 0, st, a); break;
+    case V3D_F16: hipLaunchKernelGGL((resize_bicubic_kernel<f16_t, true>), grid, dim3(256), 0, st, a); break;
+    case V3D_BF16: hipLaunchKernelGGL((resize_bicubic_kernel<bf16_t, true>), grid, dim3(256), 0, st, a); break;
+    default: set_error("v3d_resize_bicubic_u8: out_dtype %d", out_dtype); return V3D_E_INVALID;
+  }
+  return check_launch("v3d_resize_bicubic_u8");
+}

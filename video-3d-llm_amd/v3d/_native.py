@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libv3d_hip.so")
 
 _lib = None
-ABI_VERSION = 3      # include/v3d.h V3D_ABI_VERSION
+ABI_VERSION = 4      # include/v3d.h V3D_ABI_VERSION
 
 
 class V3DError(RuntimeError):
@@ -65,6 +65,8 @@ SIGNATURES = {
     "v3d_linear_decode_rows": (c_i, [c_p, c_l, c_i, c_p, c_f, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
     "v3d_rope_kv_append": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     "v3d_preprocess_rgb_u8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, ctypes.c_double, c_p, c_i, c_p]),
+    "v3d_resize_bicubic_u8": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p,
+                                    ctypes.c_double, c_p, c_i, c_p]),
     "v3d_argmax": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "v3d_argmax_rows": (c_i, [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p]),
     "v3d_rope_kv_append_rows": (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p]),

@@ -626,6 +626,97 @@ def preprocess_rgb(frames, dtype=torch.float32, mean=(0.5, 0.5, 0.5), std=(0.5, 
     return out
 
 
+# ---- Pillow's resampling tables (libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc), evaluated in double exactly as
+#      Pillow does: python floats ARE C doubles and every statement below is one of Resample.c's, in its order.  The integer
+#      tables are all the device kernel needs (v3d_resize_bicubic_u8).
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic(x):
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_tables(in_size, out_size, support=2.0, filt=_pil_bicubic):
+    """(bounds int32 [out,2], coeffs int32 [out,ksize], ksize) of one resize pass in_size -> out_size over the whole axis
+    (box = (0, in_size)), BICUBIC by default (Image.resize's default filter for RGB)."""
+    in0, in1 = 0.0, float(in_size)
+    scale = filterscale = (in1 - in0) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    sup = support * filterscale
+    ksize = int(math.ceil(sup)) * 2 + 1
+    bounds = torch.zeros((out_size, 2), dtype=torch.int32)
+    kk = torch.zeros((out_size, ksize), dtype=torch.int32)
+    one = float(1 << _PIL_PRECISION_BITS)
+    for xx in range(out_size):
+        center = in0 + (xx + 0.5) * scale
+        ww = 0.0
+        ss = 1.0 / filterscale
+        xmin = int(center - sup + 0.5)            # (int) truncates toward zero, as the C cast does; the value is >= -sup + 0.5
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + sup + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = []
+        for x in range(xmax):
+            w = filt((x + xmin - center + 0.5) * ss)
+            k.append(w)
+            ww += w
+        for x in range(xmax):
+            if ww != 0.0:
+                k[x] /= ww
+        bounds[xx, 0], bounds[xx, 1] = xmin, xmax
+        for x in range(xmax):
+            kk[xx, x] = int(-0.5 + k[x] * one) if k[x] < 0 else int(0.5 + k[x] * one)
+    return bounds, kk, ksize
+
+
+_RESIZE_TABLES = {}
+
+
+def _resize_tables(in_size, out_size, device):
+    key = (in_size, out_size, str(device))
+    t = _RESIZE_TABLES.get(key)
+    if t is None:
+        b, k, ks = pil_resample_tables(in_size, out_size)
+        t = _RESIZE_TABLES[key] = (b.to(device).contiguous(), k.to(device).contiguous(), ks)
+    return t
+
+
+def resize_crop_rgb(frames, out_hw, crop=None, dtype=torch.uint8, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), rescale=1 / 255):
+    """PIL `Image.resize((OW, OH))` (default BICUBIC) + `.crop((left, top, left + cw, top + ch))` of RGB uint8 frames [F,H,W,3] on
+    the device, bit for bit (video_utils.py:285-306).  crop = (top, left, ch, cw) inside the resized image (default: all of it).
+    dtype uint8 -> [F,ch,cw,3] uint8; a float dtype -> SigLipImageProcessor's pixel_values [F,3,ch,cw] (rescale, normalise, CHW
+    fused: v3d_preprocess_rgb_u8's arithmetic on the resized bytes)."""
+    fr = _dev(frames, "frames")
+    if fr.dtype != torch.uint8 or fr.dim() != 4 or fr.shape[-1] != 3:
+        raise V3DError("resize_crop_rgb wants [F,H,W,3] uint8 frames")
+    fr = fr.contiguous()
+    F_, H, W, _ = fr.shape
+    OH, OW = int(out_hw[0]), int(out_hw[1])
+    top, left, ch, cw = crop if crop is not None else (0, 0, OH, OW)
+    bh, kh, ksh = _resize_tables(W, OW, fr.device)
+    bv, kv, ksv = _resize_tables(H, OH, fr.device)
+    if dtype == torch.uint8:
+        out = torch.empty((F_, ch, cw, 3), dtype=torch.uint8, device=fr.device)
+        code, m, sd = 16, None, None
+    else:
+        out = torch.empty((F_, 3, ch, cw), dtype=dtype, device=fr.device)
+        code, m, sd = _DT[dtype], (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(lib().v3d_resize_bicubic_u8(_p(fr), F_, H, W, OH, OW, _p(bh), _p(kh), ksh, _p(bv), _p(kv), ksv, top, left, ch, cw, m, sd,
+                                      float(rescale), _p(out), code, _stream()), "v3d_resize_bicubic_u8")
+    return out
+
+
 def patchify(images, patch=14, kpad=640):
     B, C, S, _ = images.shape
     g = S // patch
