@@ -55,7 +55,7 @@ def synth_inputs(dev, dtype, seed):
     frames = torch.randint(0, 256, (F_, 384, 384, 3), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)   # RGB crops
     text = torch.randint(0, 151000, (TEXT_PRE + TEXT_POST,), generator=g, device=dev)
     input_ids = torch.cat([text[:TEXT_PRE], torch.tensor([IMAGE_TOKEN_INDEX], device=dev), text[TEXT_PRE:]]).cpu()
-    return dict(depth=depth, K=K, P=P, frames=frames, input_ids=input_ids)
+    return dict(depth=depth, K=K, pose=P, P=P, frames=frames, input_ids=input_ids)
 
 
 class Stamp:
@@ -76,65 +76,12 @@ class Stamp:
         return sum(a.elapsed_time(b) for a, b in self.pairs) * 1e3 / max(1, len(self.pairs))
 
 
-def ids_on_device(inp, dev):
-    ids = inp["input_ids"]
-    inp["ids_pre"], inp["ids_post"] = ids[:TEXT_PRE].to(dev), ids[TEXT_PRE + 1:].to(dev)
-    return inp
-
-
-def prefill_phase(eng, ops, inp, stamps):
-    """geometry -> ViT -> projector -> fusion -> Qwen2 prefill; returns the last-row logits (MFMA-bound part)."""
-    dt = eng.dtype
-    coords = ops.unproject_sampled(inp["depth"], inp["K"], inp["P"], 384, dt)           # K1+K2
-    ids = eng.voxel_ids(coords)                                                         # K3+K4
-    images = ops.preprocess_rgb(inp["frames"], dt)                                      # a7: rescale + normalise + CHW
-    feats = eng.encode_images(images)                                                   # K10-K12
-    n_vis = FRAMES * 14 * 15
-    S = TEXT_PRE + n_vis + TEXT_POST
-    x = eng.l_x[:S]
-    ops.embed_gather(eng.embed, inp["ids_pre"], out=x[:TEXT_PRE])
-    stamps["pe"](lambda: ops.visual_tokens(feats, ids, eng.pe_table, eng.newline, out=x[TEXT_PRE:TEXT_PRE + n_vis]))  # K5-K8
-    ops.embed_gather(eng.embed, inp["ids_post"], out=x[TEXT_PRE + n_vis:])
-    return eng.llm_forward(x, 0, stamps=stamps), S                                      # K13-K18 prefill
-
-
-def scene_step(eng, ops, inp, stamps):
-    logits, S = prefill_phase(eng, ops, inp, stamps)
-    return eng.decode_loop(logits, S, DECODE_STEPS)                                     # 16 greedy tokens, no EOS stop
-
-
-def run_grouped(eng, ops, scenes, stamps, null, steps, sets, groups, streams, group_size):
-    """Scenes are prefilled one by one (MFMA-bound, stream A) and decoded in groups of up to `group_size` (stream B):
-    the 16 decode steps of a group stream the 15 GB of weights once per step for ALL its scenes (M-row linears),
-    instead of once per scene.  Two context sets alternate, so the prefills of group g+1 run while group g decodes.
-    Every scene still runs the complete path, and a scene's tokens do not depend on its group (tests/test_gpu_engine.py)."""
-    sA, sB = streams
-    toks, dec_done = [], []
-    n_groups = (steps + group_size - 1) // group_size
-    first = True
-    for gi in range(n_groups):
-        n = min(group_size, steps - gi * group_size)
-        ctxs = sets[gi % 2][:n]
-        with torch.cuda.stream(sA):
-            if gi >= 2:
-                sA.wait_event(dec_done[gi - 2])          # this context set's previous group has finished decoding
-            lens = []
-            for c in ctxs:
-                eng.use(c)
-                # kernel stamps on the first timed scene only: its prefill runs with nothing else on the chip, so the
-                # HIP-event durations are the kernels' own (later scenes share HBM with the previous group's decode)
-                _, S = prefill_phase(eng, ops, scenes[(gi * group_size + len(lens)) % len(scenes)], stamps if first else null)
-                first = False
-                lens.append(S)
-            pre_done = sA.record_event()
-        with torch.cuda.stream(sB):
-            sB.wait_event(pre_done)
-            toks.append(eng.decode_group(groups[gi % 2], ctxs, lens, DECODE_STEPS))
-            dec_done.append(sB.record_event())
-    cur = torch.cuda.current_stream()
-    for e in dec_done[-2:]:
-        cur.wait_event(e)
-    return torch.cat(toks, 0)
+def samples_of(scenes, n, SceneSample):
+    """n (scene, question) samples cycling over the resident synthetic scenes; no scene key: every step uploads nothing (inputs are
+    resident) but runs the complete device path, geometry and image preprocessing included."""
+    for i in range(n):
+        sc = scenes[i % len(scenes)]
+        yield SceneSample(input_ids=sc["input_ids"], raw=sc, key=None)
 
 
 def cpu_baseline(threads):
@@ -247,6 +194,115 @@ def measure_grounding(eng, ops, scenes, dev, steps):
     return steps / (time.perf_counter() - t0)
 
 
+def write_eval_dataset(root, n_scenes, frames=FRAMES):
+    """A synthetic scene set in the dataset's own on-disk form (what scripts/3d/preprocessing/generate_image_scannet.py exports and
+    llava/video_utils.py:90-105, 196-238, 285-290 read): per frame a 1296 x 968 colour JPEG, a 640 x 480 16-bit depth PNG and a 4 x 4 pose
+    text file; EmbodiedScan-style scene index pickles; box JSONs.  Smooth content with texture (camera-like compressibility), not noise."""
+    import pickle
+    import numpy as np
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:968, 0:1296].astype(np.float32)
+    dy, dx = np.mgrid[0:480, 0:640].astype(np.float32)
+    data_list = []
+    for s_ in range(n_scenes):
+        sid, folder = f"scannet/scene{s_:04d}_00", os.path.join(root, "posed_images", f"scene{s_:04d}_00")
+        os.makedirs(folder, exist_ok=True)
+        files = []
+        for v in range(frames):
+            ph = 0.37 * v + s_
+            base = os.path.join(folder, f"{v * 10:05d}")
+            rgb = np.stack([127 + 90 * np.sin(xx / (41 + 7 * c) + ph) * np.cos(yy / (29 + 5 * c) - ph) for c in range(3)], -1)
+            rgb = np.clip(rgb + rng.normal(0, 6, rgb.shape).astype(np.float32), 0, 255).astype(np.uint8)
+            Image.fromarray(rgb).save(base + ".jpg", quality=90)
+            depth = 2200 + 1500 * np.sin(dx / 97 + ph) * np.cos(dy / 71) + rng.normal(0, 3, dx.shape)
+            depth[(dx + dy + 13 * v) % 97 < 3] = 0                                   # holes, as sensor depth has
+            Image.fromarray(np.clip(depth, 0, 65535).astype(np.uint16)).save(base + ".png", compress_level=1)
+            pose = np.eye(4)
+            pose[:3, :3] = [[np.cos(ph), -np.sin(ph), 0], [np.sin(ph), np.cos(ph), 0], [0, 0, 1]]
+            pose[:3, 3] = rng.normal(0, 1.5, 3)
+            np.savetxt(base + ".txt", pose)
+            files.append(os.path.relpath(base + ".jpg", root))
+        data_list.append({"sample_idx": sid, "axis_align_matrix": np.eye(4).tolist(),
+                          "depth_cam2img": [[577.87, 0, 319.5, 0], [0, 577.87, 239.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                          "images": [{"img_path": f} for f in files]})
+    os.makedirs(os.path.join(root, "embodiedscan"), exist_ok=True)
+    os.makedirs(os.path.join(root, "metadata"), exist_ok=True)
+    for split in ("train", "val", "test"):
+        with open(os.path.join(root, "embodiedscan", f"embodiedscan_infos_{split}.pkl"), "wb") as f:
+            pickle.dump({"data_list": data_list if split == "val" else []}, f)
+    for name in ("scannet_train_gt_box.json", "scannet_val_pred_box.json"):
+        with open(os.path.join(root, "metadata", name), "w") as f:
+            json.dump({d["sample_idx"]: [[0, 0, 0, 1, 1, 1]] for d in data_list}, f)
+    return [d["sample_idx"] for d in data_list]
+
+
+def bench_tokenizer():
+    """A word-level stand-in tokenizer with the ChatML specials (no Qwen2 tokenizer ships here; the ids only have to be valid)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    names = {300: "system", 301: "user", 302: "assistant", 303: "\n", 304: "You", 305: "are", 306: "a", 307: "helpful",
+             308: "assistant.", 309: "<|im_start|>", 310: "<|im_end|>"}
+    vocab = {names.get(i, f"t{i}"): i for i in range(2048)}
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="t0"))
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split("\n", "isolated"), pre_tokenizers.Split(" ", "removed")])
+    return PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|im_end|>", pad_token="t0", unk_token="t0",
+                                   additional_special_tokens=["<|im_start|>", "<|im_end|>"])
+
+
+def measure_eval_runner(eng, dev, n_questions, n_scenes=8):
+    """The PRODUCT's eval loop end to end on files: v3d.eval_scanqa.model_answer_fn (pipelined: asynchronous loader -> upload -> device
+    geometry / Pillow-exact resize -> ViT -> ... -> grouped decode with the device-side stop test) over a synthetic on-disk scene set at the
+    dataset's true sizes.  Every question asks about ANOTHER scene than the previous eight (no scene reuse: the loader's worst case)."""
+    import contextlib
+    import shutil
+    import tempfile
+    import types
+    from llava.model.multimodal_encoder.siglip_encoder import SigLipImageProcessor
+    from llava.video_utils import VideoProcessor
+    from v3d import eval_scanqa as E
+    root = tempfile.mkdtemp(prefix="v3d_bench_scenes_")
+    try:
+        t0 = time.perf_counter()
+        sids = write_eval_dataset(root, n_scenes)
+        t_write = time.perf_counter() - t0
+        tok = bench_tokenizer()
+        with contextlib.redirect_stdout(sys.stderr):
+            vp = VideoProcessor(video_folder=root, annotation_dir=os.path.join(root, "embodiedscan"), metadata_dir=os.path.join(root, "metadata"))
+        words = " ".join(f"t{(7 * k) % 290 + 1}" for k in range(64))
+        def question(i, n_words):
+            return {"id": f"q{i}", "video": sids[i % n_scenes],
+                    "conversations": [{"from": "human", "value": "<image>\n" + " ".join(words.split()[:n_words])}, {"from": "gpt", "value": "t42"}],
+                    "metadata": {"dataset": "scanqa", "question_type": "what", "answers": ["t42"]}}
+        n_words = 40
+        while len(E.build_prompt_ids(question(0, n_words), tok)[0]) - 1 < TEXT_PRE + TEXT_POST and n_words < 64:
+            n_words += 1
+        qs = [question(i, n_words) for i in range(n_questions)]
+        S = len(E.build_prompt_ids(qs[0], tok)[0]) - 1 + FRAMES * 210
+        model = types.SimpleNamespace(engine=eng, device=dev, dtype=eng.dtype, _eos=lambda: None)
+        stats = {}
+        fn = E.model_answer_fn(model, tok, SigLipImageProcessor(), vp, "bench", FRAMES, NEW_TOKENS, pipeline=True, group_size=16, stats=stats)
+        fn(qs[: min(4, n_questions)])                     # warm-up: page cache, kernels' first launches, pinned pools
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs = fn(qs)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        assert len(recs) == n_questions and all(r["sample_id"] == q["id"] for r, q in zip(recs, qs))
+        per_q = {k: v / n_questions * 1e3 for k, v in stats["host_thread_seconds"].items()}
+        return {"what": "the product's eval loop (v3d.eval_scanqa.model_answer_fn, pipelined) end to end on a synthetic ON-DISK scene set: per question "
+                        "32 x (1296x968 JPEG + 640x480 16-bit PNG + pose txt) decoded by the asynchronous host loader, uploaded, back-projected, resized "
+                        "(Pillow-exact, on the device), then the same ViT -> projector -> fusion -> Qwen2 prefill S=%d -> %d greedy tokens as the headline; "
+                        "every question about another scene than the eight before it (no reuse), files in the page cache" % (S, NEW_TOKENS),
+                "value": n_questions / dt_s, "unit": "scenes/s", "ms_per_step": dt_s / n_questions * 1e3, "questions": n_questions, "seq_len": S,
+                "loader_threads": E.default_workers(), "host_cores": os.cpu_count(),
+                "host_thread_ms_per_question": per_q, "gpu_waited_for_loader_ms_per_question": stats["loader_wait_seconds"] / n_questions * 1e3,
+                "upload_enqueue_ms_per_question": stats["upload_enqueue_seconds"] / n_questions * 1e3,
+                "upload_mb_per_question": (FRAMES * (1296 * 968 * 3 + 640 * 480 * 2)) / 1e6, "dataset_write_s": t_write}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def measure_train_step(dev, steps=2, answer_tokens=64):
     """BASELINE configs[4] on ONE GPU (no ZeRO exchange): one training sample end to end - SigLIP-so400m (26 layers, 32 frames) ->
     mlp2x_gelu -> pool + 3-D PE + newline rows spliced between the text rows -> Qwen2-7B with labels, backward of all of it, AdamW on every
@@ -330,6 +386,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements appended to the default N=1 line (fp8, cached questions, grounding)")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip only the configs[3] extra")
     ap.add_argument("--no-train-extra", action="store_true", help="skip only the configs[4] (language-model training step) extra")
+    ap.add_argument("--eval-runner-only", action="store_true", help="after the headline run only the eval_runner extra (development)")
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes resident in HBM, cycled over the steps")
     a = ap.parse_args()
 
@@ -356,6 +413,7 @@ def main():
     from v3d import distributed as v3dist
     from v3d import ops
     from v3d.engine import Engine, EngineConfig, random_state_dict
+    from v3d.pipeline import ScenePipeline, SceneSample
     dtype = torch.bfloat16
     cfg = EngineConfig()
     sd = random_state_dict(cfg, dtype, dev, seed=0, ground_head=True)
@@ -363,39 +421,30 @@ def main():
     # the rank's share of the (scene, question) list: the reference's stride sharding, model_scanqa.py:245
     n_scenes = max(1, min(a.scenes, a.steps))
     my_ids = v3dist.shard(list(range(world * a.steps)), rank, world)
-    scenes = [ids_on_device(synth_inputs(dev, dtype, seed=1000 + world * i + rank), dev) for i in range(n_scenes)]
+    scenes = [synth_inputs(dev, dtype, seed=1000 + world * i + rank) for i in range(n_scenes)]
     torch.cuda.synchronize()
 
     def new_stamps():
         return {"pe": Stamp(), "gemm": Stamp(), "attn": Stamp()}
     stamps = new_stamps()
-    null = {"pe": (lambda f: f()), "gemm": (lambda f: f()), "attn": (lambda f: f())}
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-    G_ALL = max(1, min(16, a.decode_group))
+    G_ALL = 1 if a.no_overlap else max(1, min(16, a.decode_group))
 
     def measure(eng, stamps):
-        """W untimed warm-up scenes, then EXACTLY `steps` scenes between barrier + synchronize; max over ranks."""
-        G = G_ALL
-        sets = [[eng.ctx] + [eng.new_context() for _ in range(G - 1)], [eng.new_context() for _ in range(G)]]
-        groups = [eng.new_group(G), eng.new_group(G)]
-        for w in range(a.warmup):
-            eng.use(sets[0][0])
-            scene_step(eng, ops, scenes[w % n_scenes], null)
-        if a.warmup and not a.no_overlap:                       # warm the grouped kernels' code paths too
-            run_grouped(eng, ops, scenes, null, null, min(G, a.steps), sets, groups, streams, G)
+        """W untimed warm-up scenes, then EXACTLY `steps` scenes between barrier + synchronize; max over ranks.  The timed region IS the
+        product's scene pipeline (v3d.pipeline.ScenePipeline.run - the eval runners call the same function): prefill per scene on stream A,
+        decode groups on stream B, two context sets."""
+        pipe = ScenePipeline(eng, G_ALL)
+        if a.warmup:
+            pipe.run(samples_of(scenes, max(a.warmup, min(G_ALL, a.steps)), SceneSample), NEW_TOKENS, overlap=not a.no_overlap, trim=False)
         barrier()
         t0 = time.perf_counter()
-        if a.no_overlap:
-            eng.use(sets[0][0])
-            answers = torch.stack([scene_step(eng, ops, scenes[i % n_scenes], stamps) for i in range(a.steps)])
-        else:
-            answers = run_grouped(eng, ops, scenes, stamps, null, a.steps, sets, groups, streams, G)
+        answers = torch.cat(pipe.run(samples_of(scenes, a.steps, SceneSample), NEW_TOKENS, overlap=not a.no_overlap, stamps=stamps, trim=False), 0)
         merged = None
         if world > 1:   # eval collation: ONE variable-length gather of the answer records to rank 0 (replaces Ray + file lock)
             recs = [{"sample_id": sid, "pred_token_ids": row} for sid, row in zip(my_ids, answers.tolist())]
@@ -408,18 +457,25 @@ def main():
             dt_s = tt.item()
             if rank == 0:
                 assert [r["sample_id"] for r in merged] == list(range(world * a.steps)), "gathered records are not in question order"
-        eng.use(sets[0][0])
+        assert answers.shape == (a.steps, NEW_TOKENS)
+        eng.use(pipe.sets[0][0])
         return dt_s
 
     dt_s = measure(eng, stamps)
     extras = {}
-    if world == 1 and not a.no_extras:
+    if world == 1 and a.eval_runner_only:
+        extras["eval_runner"] = measure_eval_runner(eng, dev, max(16, a.steps))
+    elif world == 1 and not a.no_extras:
         nq, scene_ms = measure_cached_questions(eng, ops, scenes[0], dev, n_groups=max(1, a.steps // 4))
         extras["cached_questions"] = {
             "what": "scene-level reuse (SURVEY 8 f1; not the headline): further questions about an ALREADY prefilled scene - %d question rows "
                     "per question run over the cached prefix of %d rows, 16 questions per batch, %d new tokens each; the one-off scene prefill "
                     "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, NEW_TOKENS),
             "value": nq, "unit": "questions/s", "scene_prefill_ms": scene_ms}
+        try:
+            extras["eval_runner"] = measure_eval_runner(eng, dev, max(16, a.steps))
+        except Exception as e:                          # an extra must never take the headline line down with it
+            extras["eval_runner"] = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["ground_config2"] = {
             "what": "BASELINE configs[2] on one GPU: ScanRefer / Multi3DRefer grounding forward, 32 frames, 50 object proposals, "
                     "infonce head (prefill only, no decode)",

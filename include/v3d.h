@@ -297,6 +297,11 @@ int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, void* worksp
 /* M rows x + m*ldx in one launch pair; out_index[M]; workspace >= M KiB. */
 int v3d_argmax_rows(const void* x, int64_t ldx, int M, int n, int dtype, int64_t* out_index, void* workspace, void* stream);
 
+/* The stop test of greedy decoding on the device (generate(..., eos_token_id), llava_qwen.py:208-236 -> HF greedy search):
+ * done[m] |= tokens[m] in eos_ids[0:n_eos] (device int64 arrays; done: device int32 [M], kept across steps), *n_done = number
+ * of rows that have finished.  The host polls n_done asynchronously instead of synchronising on every token. */
+int v3d_eos_update(const int64_t* tokens, int M, const int64_t* eos_ids, int n_eos, int32_t* done, int32_t* n_done, void* stream);
+
 /* ------------------------------------------------------------------ grounding (K19, K20) - */
 
 /* K19  llava_arch.py:357-372, object_feature_type 'patch14': mask[o, f, py, px] = 1 iff at least `thresh`

@@ -51,15 +51,17 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, shard="stride"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     qs = _questions(11)
+    if shard == "scene":                       # interleave the scenes' questions: a scene's questions are NOT consecutive
+        qs = qs[0::2] + qs[1::2]
 
     def answer_fn(lines):                      # stands in for the model: what matters here is who answers what, and the order
         return [E.make_record(l, f"rank{rank}:{l['id']}", "stub") for l in lines]
 
-    recs = E.evaluate(qs, answer_fn, rank, world, torch.device("cpu"))
+    recs = E.evaluate(qs, answer_fn, rank, world, torch.device("cpu"), shard=shard)
     if rank == 0:
         with open(out_path, "w") as f:
             for r in recs:
@@ -82,3 +84,44 @@ def test_evaluate_shards_by_stride_and_collates_in_question_order(tmp_path):
     recs = [json.loads(l) for l in open(out)]
     assert [r["sample_id"] for r in recs] == [f"q{i}" for i in range(11)]
     assert [r["pred_response"] for r in recs] == [f"rank{i % 2}:q{i}" for i in range(11)]        # questions[rank::world]
+
+
+def test_evaluate_shards_whole_scenes_and_collates_in_question_order(tmp_path):
+    """--shard scene: every scene's questions go to ONE rank (so one prefill per scene survives data parallelism), the
+    blocks are balanced by question count, and rank 0 still writes the records in question order."""
+    ctx = mp.get_context("spawn")
+    port, out = _free_port(), str(tmp_path / "answers.jsonl")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, "scene")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    qs = _questions(11)
+    qs = qs[0::2] + qs[1::2]
+    recs = [json.loads(l) for l in open(out)]
+    assert [r["sample_id"] for r in recs] == [q["id"] for q in qs]
+    owner = {}
+    for q, r in zip(qs, recs):
+        owner.setdefault(q["video"], set()).add(r["pred_response"].split(":")[0])
+    assert all(len(v) == 1 for v in owner.values()), owner                   # one rank per scene
+    counts = [sum(r["pred_response"].startswith(f"rank{k}:") for r in recs) for k in range(2)]
+    assert min(counts) >= 3 and sum(counts) == 11, counts
+
+
+def test_scene_sharding_partition_properties():
+    from v3d import distributed as D
+    import random
+    rnd = random.Random(1)
+    for world in (1, 2, 3, 8):
+        for _ in range(20):
+            n_scenes = rnd.randint(1, 30)
+            keys = [f"s{rnd.randrange(n_scenes)}" for _ in range(rnd.randint(1, 200))]
+            parts = [D.shard_scene_indices(keys, r, world) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(len(keys)))                                  # a partition
+            for r, p in enumerate(parts):
+                for s_ in {keys[i] for i in p}:
+                    assert all((keys[i] != s_) or (i in p) for i in range(len(keys)))     # whole scenes
+            biggest = max(keys.count(k) for k in set(keys))
+            assert max(len(p) for p in parts) <= len(keys) / world + biggest          # balanced up to one scene

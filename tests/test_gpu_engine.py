@@ -300,3 +300,62 @@ def test_generate_group_matches_group_decode_and_cuts_at_eos():
         n = row.index(eos) + 1 if eos in row else len(row)
         assert cut[m].tolist() == row[:n]
     assert eng.generate_group(scenes[:1], max_new_tokens=3)[0].shape[0] == 3
+
+
+def test_device_side_stop_test_ends_the_group_early_and_keeps_the_tokens():
+    """decode_group with eos_token_id: the stop test runs on the device (v3d_eos_update) and the host reads it a step late - the
+    group stops at most one step after its LAST row produced an EOS, every row's tokens up to its first EOS are those of the run
+    without a stop test, and the single-scene loop (decode_loop) ends exactly at its EOS."""
+    from v3d.engine import Engine, random_state_dict
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=15, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    scenes = _scenes(3, 16)
+    want = _group_decode(eng, scenes, 12)                      # [3, 12], no stop test
+    rows = [w.tolist() for w in want]
+    # an "EOS" set such that every row hits one: row m's own token at step 2 + m
+    eos = [rows[m][2 + m] for m in range(3)]
+    first = [min(i for i, t in enumerate(r) if t in eos) for r in rows]
+    cut = eng.generate_group(scenes, max_new_tokens=12, eos_token_id=eos)
+    for m in range(3):
+        assert cut[m].tolist() == rows[m][: first[m] + 1]
+    # steps actually run: <= last EOS step + lookahead (2) - and well short of 12
+    pool, grp = eng._group_ctxs, eng._group_rows
+    lens = []
+    for c, (ids, im, wc) in zip(pool, scenes):
+        eng.use(c)
+        x = eng.build_inputs_embeds(ids, eng.encode_images(im), eng.voxel_ids(wc.to(eng.dtype)))
+        eng.llm_forward(x, 0)
+        lens.append(x.shape[0])
+    toks = eng.decode_group(grp, pool[:3], lens, 12, eos_token_id=eos)
+    assert max(first) + 1 <= toks.shape[1] <= max(first) + 2 and torch.equal(toks.cpu(), want[:, : toks.shape[1]].cpu())
+    one = eng.generate(*scenes[1], max_new_tokens=12, eos_token_id=eos)
+    solo = eng.generate(*scenes[1], max_new_tokens=12).tolist()
+    n1 = min(i for i, t in enumerate(solo) if t in eos) + 1 if any(t in eos for t in solo) else 12
+    assert one.tolist() == solo[:n1]
+
+
+def test_scene_pipeline_equals_generate_group_and_reuses_scene_inputs():
+    """v3d.pipeline.ScenePipeline.run (two streams, two context sets, groups of 2 over 5 samples, lazy sample iterator) returns, per
+    sample, the tokens generate_group gives for the same group composition - bit for bit - with and without the stream overlap; equal
+    scene keys share one set of device inputs."""
+    from v3d.engine import Engine, random_state_dict
+    from v3d.pipeline import ScenePipeline, SceneSample
+    cfg = tiny_cfg()
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=15, std=0.08)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2)
+    scenes = _scenes(5, 16)
+    want = []
+    for a in range(0, 5, 2):
+        want += [t.cpu() for t in eng.generate_group(scenes[a: a + 2], max_new_tokens=6)]
+    pipe = ScenePipeline(eng, group_size=2)
+    mk = lambda: (SceneSample(input_ids=ids, images=im, world_coords=wc, key=f"scene{i}") for i, (ids, im, wc) in enumerate(scenes))      # noqa: E731
+    for overlap in (True, False):
+        got = pipe.run(mk(), max_new_tokens=6, overlap=overlap)
+        assert len(got) == 5 and all(torch.equal(g, w) for g, w in zip(got, want)), overlap
+    eos = int(want[3][2])
+    cut = pipe.run(mk(), max_new_tokens=6, eos_token_id=eos)
+    for g, w in zip(cut, want):
+        row = w.tolist()
+        assert g.tolist() == (row[: row.index(eos) + 1] if eos in row else row)
+    assert len(pipe.scene_cache) == 3 and "scene4" in pipe.scene_cache          # LRU of the last three scenes' device inputs

@@ -1,7 +1,7 @@
 """The ScanQA eval runner end to end on a tiny synthetic dataset the test writes itself in the dataset's own on-disk form
 (EmbodiedScan-style scene index pickles, 16-bit depth PNGs, pose txt, JPEG frames, box JSONs, a question file) with the tiny
 random checkpoint of tests/golden/tiny_model.npz: loader -> VideoProcessor -> ChatML ids -> generate -> record -> answer file
-(model_scanqa.py:83-206), and the scene-reuse mode (one prefill per scene, questions answered in batches) giving the same
+(model_scanqa.py:83-206) one question at a time, the pipelined default (v3d.pipeline), and the scene-reuse mode (one prefill per scene, questions answered in batches) giving the same
 records.  Every answer is also checked against Engine.generate called directly on the same inputs."""
 import json
 import os
@@ -64,11 +64,13 @@ def test_eval_runner_end_to_end(tmp_path):
     argv = ["--model-path", ckpt, "--video-folder", root, "--embodiedscan-folder", os.path.join(root, "embodiedscan"),
             "--metadata-folder", os.path.join(root, "metadata"), "--question-file", os.path.join(root, "questions.json"),
             "--max_frame_num", "4", "--max-new-tokens", "5"]
-    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl")]) == 0
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl"), "--no-pipeline"]) == 0
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "pipe.jsonl"), "--decode-group", "3", "--loader-workers", "3"]) == 0
     assert E.main(argv + ["--answer-file", os.path.join(root, "out", "reuse.jsonl"), "--reuse-scenes"]) == 0
     plain = [json.loads(l) for l in open(os.path.join(root, "out", "plain.jsonl"))]
+    pipe = [json.loads(l) for l in open(os.path.join(root, "out", "pipe.jsonl"))]
     reuse = [json.loads(l) for l in open(os.path.join(root, "out", "reuse.jsonl"))]
-    for recs in (plain, reuse):
+    for recs in (plain, pipe, reuse):
         assert [r["sample_id"] for r in recs] == [q["id"] for q in qs]
         assert all(list(r) == ["dataset", "sample_id", "prompt", "pred_response", "gt_response", "model_id", "question_type"] for r in recs)
         assert all(r["model_id"] == "llava_qwen_tiny" and r["gt_response"] == "t42" and r["prompt"].startswith(E.EXTRA_PROMPT) for r in recs)
@@ -86,6 +88,10 @@ def test_eval_runner_end_to_end(tmp_path):
         assert E.clean_answer(tokenizer.batch_decode(toks.view(1, -1), skip_special_tokens=True)[0]) == r["pred_response"]
     same = sum(a["pred_response"] == b["pred_response"] for a, b in zip(plain, reuse))
     assert same >= len(qs) - 2, (plain, reuse)
+    # the pipelined default (asynchronous loader, groups of 3 over two context sets, device-side stop test, stream overlap) answers
+    # as the one-question-at-a-time loop does - same caveat: the grouped decode linears sum in another f32 order
+    same = sum(a["pred_response"] == b["pred_response"] for a, b in zip(plain, pipe))
+    assert same >= len(qs) - 2, (plain, pipe)
     # an existing answer file is never overwritten (model_scanqa.py:238-240)
     before = open(os.path.join(root, "out", "plain.jsonl")).read()
     assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl")]) == 0

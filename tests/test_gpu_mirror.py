@@ -137,8 +137,23 @@ def test_video_processor_on_scene_files(golden, tmp_path):
     assert out["video_size"] == V and tuple(out["objects"].shape) == (2, 6)
     want = O.resize_crop_coords(g["world"], crop)
     np.testing.assert_allclose(out["world_coords"].cpu().numpy(), want, rtol=2e-6, atol=2e-6)
-    assert len(out["images"]) == V and all(im.size == (crop, crop) for im in out["images"])
+    # images: ONE uint8 device tensor [V, crop, crop, 3] = the reference's list of PIL crops, byte for byte (r03: Pillow's bicubic
+    # resize runs on the device)
+    assert out["images"].is_cuda and out["images"].dtype == torch.uint8 and tuple(out["images"].shape) == (V, crop, crop, 3)
     from PIL import Image
-    with Image.open(files[1]) as im:
-        ref = im.convert("RGB").resize((32, crop)).crop((4, 0, 4 + crop, crop))
-    assert np.array_equal(np.asarray(out["images"][1]), np.asarray(ref))
+    for v in range(V):
+        with Image.open(files[v]) as im:
+            ref = im.convert("RGB").resize((32, crop)).crop((4, 0, 4 + crop, crop))
+        assert np.array_equal(out["images"][v].cpu().numpy(), np.asarray(ref))
+    # the asynchronous loader's per-frame path fills the same buffers as the one-shot load, and np.loadtxt's values
+    raw = vp.load_raw(vid, files)
+    n, alloc = vp.raw_plan(vid, files, pin=True)
+    buf = alloc()
+    assert n == V and buf["frames"].is_pinned()
+    for i in reversed(range(n)):
+        t = vp.load_frame(vid, files, i, buf)
+        assert set(t) == {"depth_png", "pose_txt", "rgb_decode"}
+    for k in ("depth", "frames", "pose", "K"):
+        assert torch.equal(raw[k], buf[k]), k
+    want_pose = np.stack([g["axis_align"].astype(np.float64) @ np.loadtxt(f.replace("jpg", "txt")) for f in files]).astype(np.float32)
+    assert np.array_equal(buf["pose"].numpy(), want_pose)

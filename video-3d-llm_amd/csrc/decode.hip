@@ -728,3 +728,29 @@ extern "C" int v3d_argmax(const void* x, int n, int dtype, int64_t* out_index, v
 extern "C" int v3d_argmax_rows(const void* x, int64_t ldx, int M, int n, int dtype, int64_t* out_index, void* workspace, void* stream) {
   return argmax_rows(x, ldx, M, n, dtype, out_index, workspace, stream, "v3d_argmax_rows");
 }
+
+// ------------------------------------------------------------------------------------------
+// Greedy decoding's stop test on the device (r03): generate() ends a sequence at its first EOS id (llava_qwen.py:208-236 -> HF
+// greedy search with eos_token_id).  done[m] |= tokens[m] in eos_ids; *n_done = number of finished rows.  The host reads n_done
+// through a pinned copy a step or two later instead of synchronising on every token.
+__global__ __launch_bounds__(64) void eos_update_kernel(const int64_t* __restrict__ tokens, int M, const int64_t* __restrict__ eos, int n_eos,
+                                                        int32_t* __restrict__ done, int32_t* __restrict__ n_done) {
+  int cnt = 0;
+  for (int m = threadIdx.x; m < M; m += 64) {
+    int d = done[m];
+    const int64_t t = tokens[m];
+    for (int e = 0; e < n_eos; ++e) d |= (t == eos[e]) ? 1 : 0;
+    done[m] = d;
+    cnt += d ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (threadIdx.x == 0) *n_done = cnt;
+}
+
+extern "C" int v3d_eos_update(const int64_t* tokens, int M, const int64_t* eos_ids, int n_eos, int32_t* done, int32_t* n_done, void* stream) {
+  V3D_REQUIRE(tokens && done && n_done && (eos_ids || n_eos == 0), "v3d_eos_update: null pointer");
+  V3D_REQUIRE(M > 0 && n_eos >= 0, "v3d_eos_update: bad shape");
+  hipLaunchKernelGGL(eos_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tokens, M, eos_ids, n_eos, done, n_done);
+  return check_launch("v3d_eos_update");
+}

@@ -475,7 +475,7 @@ extern "C" int v3d_preprocess_rgb_u8(const uint8_t* frames, int F, int H, int W,
 // SigLipImageProcessor's rescale / normalise / HWC -> CHW (v3d_preprocess_rgb_u8's arithmetic) so that the 8-bit crops never
 // reach HBM.  One workgroup = a tile of RS_TW x th output pixels: the input rows x columns the tile's taps touch are staged in
 // LDS with coalesced byte loads, pass 1 writes the 8-bit intermediate to LDS, pass 2 reads it back.
-constexpr int RS_TW = 64, RS_RMAX = 64, RS_INB = 512, RS_KMAX = 32;
+constexpr int RS_TW = 64, RS_RMAX = 64, RS_INB = 640, RS_KMAX = 32;
 
 struct ResizeArgs {
   const uint8_t* src; void* out;

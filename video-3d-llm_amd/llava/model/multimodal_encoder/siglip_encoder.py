@@ -42,7 +42,11 @@ class SigLipImageProcessor:
     def preprocess(self, images, return_tensors="pt", device="cuda"):
         if isinstance(images, Image.Image):
             images = [images]
-        frames = torch.from_numpy(np.stack([self._frame(im) for im in images])).to(device)
+        if isinstance(images, torch.Tensor) and images.dim() == 4 and images.dtype == torch.uint8 and \
+                tuple(images.shape[1:3]) == (self.size[0], self.size[1]):
+            frames = images.to(device)          # VideoProcessor.preprocess's crops, already on the device at the tower's size
+        else:
+            frames = torch.from_numpy(np.stack([self._frame(im) for im in images])).to(device)
         pixel_values = ops.preprocess_rgb(frames, torch.float32, self.image_mean, self.image_std, self.rescale_factor)
         return {"pixel_values": pixel_values if return_tensors == "pt" else pixel_values.cpu().numpy()}
 

@@ -95,15 +95,73 @@ class VideoProcessor:
         n = frames_upbound if force_sample else 10
         return [files[i] for i in ops.uniform_frame_indices(len(files), n)]
 
+    # ---- host I/O of one frame (video_utils.py:214-227, 285-290): depth PNG, pose txt, RGB file -> the caller's buffers
+    @staticmethod
+    def _read_depth(path):
+        with Image.open(path.replace(".jpg", ".png")) as im:
+            return np.array(im).astype(np.uint16)
+
+    def _read_pose(self, video_id, path):
+        # np.loadtxt(path) value for value (both parse each field with a correctly rounded decimal -> double conversion), minus its
+        # Python-level overhead; then axis_align @ pose in f64 (:227)
+        return self._align(video_id) @ load_matrix_from_txt(path.replace("jpg", "txt"))
+
+    def _align(self, video_id):
+        return np.array(self.scene[video_id]["axis_align_matrix"], dtype=np.float64)
+
+    @staticmethod
+    def _read_rgb(path):
+        with Image.open(path) as im:
+            return np.asarray(im.convert("RGB"))
+
+    def frame_files(self, video_id, force_sample=False, frames_upbound=0):
+        if "mc" in self.frame_sampling_strategy:
+            return self.sample_frame_files_mc(video_id, frames_upbound, "shift" in self.frame_sampling_strategy)
+        return self.sample_frame_files(video_id, force_sample, frames_upbound)
+
+    def raw_plan(self, video_id, frame_files, pin=True):
+        """(n_frames, alloc): alloc() -> the host buffers one scene's frames are decoded into (pinned, so the upload is one
+        asynchronous copy per array): depth [F,Hd,Wd] int16 view of the 16-bit PNG values, frames [F,Hc,Wc,3] uint8, pose [F,4,4] f32,
+        K [F,4,4] f32.  Sizes come from the first frame's file headers (the colour and depth streams differ: 1296 x 968 / 640 x 480
+        in ScanNet)."""
+        with Image.open(frame_files[0]) as im:
+            Wc, Hc = im.size
+        with Image.open(frame_files[0].replace(".jpg", ".png")) as im:
+            Wd, Hd = im.size
+        n = len(frame_files)
+        K = torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()
+
+        def alloc():
+            mk = (lambda *sh, dtype: torch.empty(sh, dtype=dtype).pin_memory()) if pin and torch.cuda.is_available() else \
+                 (lambda *sh, dtype: torch.empty(sh, dtype=dtype))
+            return {"depth": mk(n, Hd, Wd, dtype=torch.int16), "frames": mk(n, Hc, Wc, 3, dtype=torch.uint8),
+                    "pose": mk(n, 4, 4, dtype=torch.float32), "K": K.unsqueeze(0).repeat(n, 1, 1)}
+        return n, alloc
+
+    def load_frame(self, video_id, frame_files, i, out):
+        """Decode frame i's three files into `out` (thread-safe: every frame writes its own rows); returns the seconds spent
+        per stage (for the eval runner's host-side breakdown)."""
+        import time
+        t0 = time.perf_counter()
+        out["depth"][i] = torch.from_numpy(self._read_depth(frame_files[i]).view(np.int16))
+        t1 = time.perf_counter()
+        out["pose"][i] = torch.from_numpy(self._read_pose(video_id, frame_files[i])).float()        # f64 product, then .float() (:227, 230)
+        t2 = time.perf_counter()
+        out["frames"][i] = torch.from_numpy(self._read_rgb(frame_files[i]))
+        t3 = time.perf_counter()
+        return {"depth_png": t1 - t0, "pose_txt": t2 - t1, "rgb_decode": t3 - t2}
+
+    def load_raw(self, video_id, frame_files, pin=False):
+        n, alloc = self.raw_plan(video_id, frame_files, pin)
+        out = alloc()
+        for i in range(n):
+            self.load_frame(video_id, frame_files, i, out)
+        return out
+
     def _load_depth_pose(self, video_id, frame_files):
-        meta = self.scene[video_id]
-        align = np.array(meta["axis_align_matrix"], dtype=np.float64)
-        K = torch.from_numpy(np.array(meta["depth_cam2img"])).float()
-        depths, poses = [], []
-        for path in frame_files:
-            with Image.open(path.replace(".jpg", ".png")) as im:
-                depths.append(np.array(im).astype(np.uint16))
-            poses.append(align @ np.loadtxt(path.replace("jpg", "txt")))     # f64 product, then .float() (:227,230)
+        K = torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()
+        depths = [self._read_depth(p) for p in frame_files]
+        poses = [self._read_pose(video_id, p) for p in frame_files]
         depth = torch.from_numpy(np.stack(depths).view(np.int16))
         pose = torch.from_numpy(np.stack(poses)).float()
         return depth, K.unsqueeze(0).repeat(len(frame_files), 1, 1), pose
@@ -120,31 +178,26 @@ class VideoProcessor:
         return {"world_coords": wc}
 
     # ---- a4-a6 (video_utils.py:242-321); strategy "center_crop" only (what the eval drivers use)
-    def preprocess(self, video_id, image_processor, force_sample=False, frames_upbound=0, strategy="center_crop"):
+    def preprocess(self, video_id, image_processor, force_sample=False, frames_upbound=0, strategy="center_crop", raw=None):
+        """Returns the reference's dict; "images" are the F centre crops as ONE uint8 device tensor [F,crop,crop,3] - byte for byte the
+        PIL crops the reference returns as a list (Pillow's bicubic resize reproduced on the device: v3d_resize_bicubic_u8) - which
+        SigLipImageProcessor.preprocess takes as it takes a list of PIL images."""
         if strategy != "center_crop":
             raise NotImplementedError("only the center_crop strategy is on the accelerated path")
-        if "mc" in self.frame_sampling_strategy:
-            frame_files = self.sample_frame_files_mc(video_id, frames_upbound, "shift" in self.frame_sampling_strategy)
-        else:
-            frame_files = self.sample_frame_files(video_id, force_sample, frames_upbound)
         if "norm" in self.frame_sampling_strategy:
             raise NotImplementedError("'norm' sampling strategies (clamp to the scene box) are not on the accelerated path")
+        frame_files = self.frame_files(video_id, force_sample, frames_upbound)
         dev = _device()
-        depth, K, pose = self._load_depth_pose(video_id, frame_files)
+        if raw is None:
+            raw = self.load_raw(video_id, frame_files)
         crop = image_processor.crop_size["width"]
-        depth, K, pose = depth.to(dev), K.to(dev), pose.to(dev)
+        depth, K, pose = raw["depth"].to(dev), raw["K"].to(dev), raw["pose"].to(dev)
         coords = ops.unproject_sampled(depth, K, pose, crop, torch.float32)
         boundry = ops.unproject_bounds(depth, K, pose).cpu()      # over the full-resolution back-projection (:268-273)
-        images = []
-        for path in frame_files:
-            with Image.open(path) as im:
-                frame = im.convert("RGB")
-            H, W = frame.height, frame.width
-            new_w = int(W * (crop / H))
-            frame = frame.resize((new_w, crop))
-            left = (new_w - crop) // 2
-            images.append(frame.crop((left, 0, left + crop, crop)))
-        return {"images": images, "world_coords": coords, "video_size": len(images), "boundry": boundry,
+        H, W = depth.shape[1:3]                                   # the DEPTH map's size steers the colour resize too (:269, 298-299)
+        new_w = int(W * (crop / H))
+        images = ops.resize_crop_rgb(raw["frames"].to(dev), (crop, new_w), crop=(0, (new_w - crop) // 2, crop, crop))
+        return {"images": images, "world_coords": coords, "video_size": images.shape[0], "boundry": boundry,
                 "objects": torch.tensor(self.scan2obj[video_id])}
 
     def process_3d_video(self, video_id, image_processor, force_sample=False, frames_upbound=0, strategy="center_crop"):

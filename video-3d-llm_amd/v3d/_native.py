@@ -69,6 +69,7 @@ SIGNATURES = {
                                     ctypes.c_double, c_p, c_i, c_p]),
     "v3d_argmax": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p]),
     "v3d_argmax_rows": (c_i, [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "v3d_eos_update": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p]),
     "v3d_rope_kv_append_rows": (c_i, [c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p]),
     "v3d_attention_decode_rows": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_l, c_l, c_i, c_i, c_i, c_f,
                                         c_p, c_l, c_p]),

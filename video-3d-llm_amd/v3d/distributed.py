@@ -30,6 +30,48 @@ def gather_bytes(payload: bytes, device, dst=0):
     return [bytes(o[: int(s)].cpu().numpy().tobytes()) for o, s in zip(out, sizes)]
 
 
+def shard_indices(n, rank, world):
+    """Indices of `questions[rank::world]` (the reference's sharding, model_scanqa.py:245)."""
+    return list(range(rank, n, world))
+
+
+def shard_scene_indices(keys, rank, world):
+    """Scene-aware sharding: whole scenes per rank, as contiguous blocks of scenes (in order of first appearance)
+    balanced by question count, so that per-scene reuse (one prefill per scene) survives data parallelism - with stride
+    sharding a scene's consecutive questions land on `world` different ranks and every rank prefills every scene.
+    keys[i] = scene of question i.  Returns this rank's question indices (ascending within a scene, scenes in order).  Every rank
+    computes the same partition."""
+    order, by_scene = [], {}
+    for i, k in enumerate(keys):
+        if k not in by_scene:
+            by_scene[k] = []
+            order.append(k)
+        by_scene[k].append(i)
+    n, out, done, r = len(keys), [], 0, 0
+    for k in order:
+        # the scene goes to the rank whose quota [r n / world, (r + 1) n / world) its first question falls into
+        while r < world - 1 and done >= (r + 1) * n / world:
+            r += 1
+        if r == rank:
+            out += by_scene[k]
+        done += len(by_scene[k])
+    return out
+
+
+def gather_indexed(records, indices, device, dst=0):
+    """records[j] answers question indices[j]; rank dst gets every record ordered by question index (any sharding)."""
+    if len(records) != len(indices):
+        raise ValueError("one record per index")
+    blobs = gather_bytes("\n".join(json.dumps([int(i), r]) for i, r in zip(indices, records)).encode(), device, dst)
+    if blobs is None:
+        return None
+    pairs = [json.loads(l) for b in blobs for l in b.decode().split("\n") if l]
+    pairs.sort(key=lambda p: p[0])
+    if [p[0] for p in pairs] != list(range(len(pairs))):
+        raise RuntimeError("gathered records do not cover the question list exactly once")
+    return [p[1] for p in pairs]
+
+
 def gather_records(records, device, dst=0):
     """records: list of JSON-serialisable dicts (the JSONL lines of model_scanqa.py:196-204).  Rank dst
     gets them all re-interleaved into the original question order of stride sharding."""

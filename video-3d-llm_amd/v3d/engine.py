@@ -329,7 +329,7 @@ class Engine:
         _, _, ids = ops.coord_pool_voxel(world_coords, 27, c.min_xyz, c.max_xyz, c.voxel_size, want_avg=False, want_vox=False)
         return ids
 
-    def build_inputs_embeds(self, input_ids, feats, ids, image_token=-200, box_input=None, coord_token_id=None):
+    def build_inputs_embeds(self, input_ids, feats, ids, image_token=-200, box_input=None, coord_token_id=None, stamp=None):
         """prepare_inputs_labels_for_multimodal for one video sample (llava_arch.py:336-836, eval branch):
         text embeddings around the <image> slot, visual tokens written in place.  Returns [S, hidden] view.
         box_input [1,3] + coord_token_id: the PE of the discretised box centre is added to the rows of every <coord> text token
@@ -348,11 +348,16 @@ class Engine:
         if S > self.cfg.llm.max_pos:
             raise V3DError(f"sequence {S} exceeds engine capacity {self.cfg.llm.max_pos}")
         x = self.l_x[:S]
+        up = lambda t: (t if t.is_cuda else t.pin_memory().to(self.device, non_blocking=True))      # noqa: E731  (no host-blocking pageable copy)
         if len(pre):
-            ops.embed_gather(self.embed, pre.to(self.device), out=x[: len(pre)])
-        ops.visual_tokens(feats, ids, self.pe_table, self.newline, side=side, n=n, pool=True, out=x[len(pre): len(pre) + n_vis])
+            ops.embed_gather(self.embed, up(pre), out=x[: len(pre)])
+        vt = lambda: ops.visual_tokens(feats, ids, self.pe_table, self.newline, side=side, n=n, pool=True, out=x[len(pre): len(pre) + n_vis])      # noqa: E731
+        if stamp is not None:
+            stamp(vt)             # bench: HIP events around the north-star kernel
+        else:
+            vt()
         if len(post):
-            ops.embed_gather(self.embed, post.to(self.device), out=x[len(pre) + n_vis:])
+            ops.embed_gather(self.embed, up(post), out=x[len(pre) + n_vis:])
         if coord_token_id is not None and box_input is not None and len(box_input):
             rows = [r if r < at else r + n_vis - 1 for r, t in enumerate(ids_list) if t == coord_token_id]
             if rows:
@@ -660,14 +665,10 @@ class Engine:
         for c, n in zip(ctxs, lens):
             c.kv_len = P + n
         share = 0 if os.environ.get("V3D_SHARED_PREFIX", "1") == "0" else P          # (0: every question reads its own copy - A/B and tests)
-        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True, shared_prefix=share)
+        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True, shared_prefix=share,
+                                 eos_token_id=eos_token_id)
         self.use(scene)
-        eos = () if eos_token_id is None else ((eos_token_id,) if isinstance(eos_token_id, int) else tuple(eos_token_id))
-        out = []
-        for row in toks.cpu():
-            hit = [i for i, t in enumerate(row.tolist()) if t in eos]
-            out.append((row[: hit[0] + 1] if hit else row).to(self.device))
-        return out
+        return [r.to(self.device) for r in self.trim_at_eos(toks, eos_token_id)]
 
     @torch.no_grad()
     def generate_group(self, samples, max_new_tokens=16, eos_token_id=None):
@@ -696,15 +697,8 @@ class Engine:
                 lens.append(x.shape[0])
         finally:
             self.use(keep)
-        toks = self.decode_group(grp, pool[:n], lens, max_new_tokens)
-        out = []
-        for row in toks.cpu():
-            if eos_token_id is not None:
-                hit = (row == eos_token_id).nonzero()
-                if hit.numel():
-                    row = row[: int(hit[0]) + 1]
-            out.append(row.to(self.device))
-        return out
+        toks = self.decode_group(grp, pool[:n], lens, max_new_tokens, eos_token_id=eos_token_id)
+        return [r.to(self.device) for r in self.trim_at_eos(toks, eos_token_id)]
 
     # ------------------------------------------------------------------ scenes decoding together
     def new_group(self, n_scenes):
@@ -761,9 +755,14 @@ class Engine:
             ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
         return g.logits[:M, : l.vocab]
 
-    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False, shared_prefix=0):
+    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False, shared_prefix=0, eos_token_id=None, lookahead=2):
         """Greedy decoding of M prefilled scenes together (their prefill logits are in ctx.logits[0], or already in g.logits
-        with logits_ready); returns the token ids [M, max_new_tokens] (device).  No EOS stop: callers trim per scene."""
+        with logits_ready); returns the token ids [M, n_steps] (device), n_steps <= max_new_tokens.
+        eos_token_id (int or ints): the stop test runs on the device (v3d_eos_update: a done mask per row and their count); the
+        host reads the count through a pinned copy `lookahead` steps behind the step it is queueing, so the launch queue never
+        drains and the group stops at most `lookahead` - 1 steps after its last row has produced an EOS.  Rows that finished
+        earlier keep decoding (their columns are independent); callers cut every row after its first EOS (trim_at_eos).
+        Without eos_token_id all max_new_tokens steps run."""
         l = self.cfg.llm
         M = len(ctxs)
         if M > g.n:
@@ -774,25 +773,80 @@ class Engine:
             for m, c in enumerate(ctxs):
                 ops.copy_rows(c.logits[:1], g.logits[m: m + 1])
         logits = g.logits[:M, : l.vocab]
+        eos = () if eos_token_id is None else ((int(eos_token_id),) if isinstance(eos_token_id, int) else tuple(int(e) for e in eos_token_id))
+        if eos:
+            st = self._eos_state(g, eos, max_new_tokens)
+            st.done[:M].zero_()
+        n_steps = max_new_tokens
         for step in range(max_new_tokens):
             ops.argmax_rows(logits, toks[step], g.amax_ws)
+            if eos:
+                ops.eos_update(toks[step], st.eos, st.done[:M], st.n_done)
+                st.host[step].copy_(st.n_done, non_blocking=True)
+                st.events[step].record()
+                back = step - (lookahead - 1)
+                if back >= 0:
+                    st.events[back].synchronize()
+                    if int(st.host[back]) >= M:           # every row had finished by step `back`: the steps queued since are the overshoot
+                        n_steps = step + 1
+                        break
             if step + 1 == max_new_tokens:
                 break
             ops.embed_gather(self.embed, toks[step], out=g.x[:M])
             logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens], shared_prefix=shared_prefix)
-        return toks.t()
+        return toks[:n_steps].t()
 
-    def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None, stopping=None):
-        """Greedy loop; token ids stay on the device (argmax kernel -> embedding gather), the host only
-        synchronises per step when an EOS id or a stopping callback has to be checked."""
+    def _eos_state(self, g, eos, max_new_tokens):
+        """Device / pinned buffers of the stop test, kept on the decode group."""
+        st = getattr(g, "eos_state", None)
+        if st is None or st.ids != eos or len(st.events) < max_new_tokens:
+            st = g.eos_state = SceneContext()
+            st.ids = eos
+            st.eos = torch.tensor(eos, dtype=torch.int64, device=self.device)
+            st.done = torch.zeros(getattr(g, "n", 1), dtype=torch.int32, device=self.device)
+            st.n_done = torch.zeros(1, dtype=torch.int32, device=self.device)
+            st.host = torch.zeros((max_new_tokens, 1), dtype=torch.int32).pin_memory()
+            st.events = [torch.cuda.Event() for _ in range(max_new_tokens)]
+        return st
+
+    @staticmethod
+    def trim_at_eos(rows, eos_token_id):
+        """rows [M, n] (host or device) -> list of 1-D host LongTensors, each cut after its first EOS id (generate's contract)."""
+        eos = () if eos_token_id is None else ((int(eos_token_id),) if isinstance(eos_token_id, int) else tuple(int(e) for e in eos_token_id))
+        out = []
+        for row in rows.cpu():
+            if eos:
+                hit = [i for i, t in enumerate(row.tolist()) if t in eos]
+                if hit:
+                    row = row[: hit[0] + 1]
+            out.append(row)
+        return out
+
+    def decode_loop(self, logits, S, max_new_tokens, eos_token_id=None, stopping=None, lookahead=2):
+        """Greedy loop of one scene; token ids stay on the device (argmax kernel -> embedding gather).  EOS: the stop test runs on
+        the device and the host reads it `lookahead` - 1 steps late (as decode_group does), so the launch queue never drains; the
+        returned ids end with the first EOS.  A stopping callback (HF stopping_criteria) forces one host synchronisation per step."""
         self._check_room(S, max_new_tokens)
-        eos = () if eos_token_id is None else ((eos_token_id,) if isinstance(eos_token_id, int) else tuple(eos_token_id))
+        eos = () if eos_token_id is None else ((int(eos_token_id),) if isinstance(eos_token_id, int) else tuple(int(e) for e in eos_token_id))
         toks = torch.empty(max_new_tokens, dtype=torch.int64, device=self.device)
+        st = None
+        if eos and stopping is None:
+            st = self._eos_state(self.ctx, eos, max_new_tokens)
+            st.done[:1].zero_()
         n = 0
         for step in range(max_new_tokens):
             ops.argmax(logits, toks[step: step + 1])
             n = step + 1
-            if eos and int(toks[step]) in eos:
+            if st is not None:
+                ops.eos_update(toks[step: step + 1], st.eos, st.done[:1], st.n_done)
+                st.host[step].copy_(st.n_done, non_blocking=True)
+                st.events[step].record()
+                back = step - (lookahead - 1)
+                if back >= 0:
+                    st.events[back].synchronize()
+                    if int(st.host[back]) >= 1:
+                        break
+            elif eos and int(toks[step]) in eos:
                 break
             if stopping is not None and stopping(toks[:n]):
                 break
@@ -800,4 +854,7 @@ class Engine:
                 break
             xe = ops.embed_gather(self.embed, toks[step: step + 1], out=self.l_x[S + step: S + step + 1])
             logits = self.decode_forward(xe, S + step)
-        return toks[:n]
+        out = toks[:n]
+        if st is not None:
+            out = self.trim_at_eos(out[None], eos)[0].to(self.device)
+        return out

@@ -97,21 +97,38 @@ def _video_inputs(video_processor, image_processor, video_id, model, max_frame_n
     return images, vd
 
 
-def evaluate(questions, answer_fn, rank, world, device):
+def evaluate(questions, answer_fn, rank, world, device, shard="stride"):
     """Shard, answer, collate.  answer_fn(list of question records of ONE rank) -> list of output records in the same order.
-    Returns on rank 0 every record in the original question order, on the other ranks None."""
-    mine = D.shard(questions, rank, world)
-    recs = answer_fn(mine)
-    if len(recs) != len(mine):
+    shard "stride": `questions[rank::world]` (model_scanqa.py:245); "scene": whole scenes per rank (v3d.distributed.shard_scene_indices;
+    what --reuse-scenes needs to keep one prefill per scene under data parallelism).  Returns on rank 0 every record in the
+    original question order, on the other ranks None."""
+    if shard == "scene":
+        idx = D.shard_scene_indices([q["video"] for q in questions], rank, world)
+    elif shard == "stride":
+        idx = D.shard_indices(len(questions), rank, world)
+    else:
+        raise ValueError(f"unknown sharding {shard!r}")
+    recs = answer_fn([questions[i] for i in idx])
+    if len(recs) != len(idx):
         raise RuntimeError("answer_fn must return one record per question")
     if world == 1:
         return recs
-    return D.gather_records(recs, device)
+    return D.gather_indexed(recs, idx, device)
+
+
+def default_workers():
+    """Loader threads per process: the host cores divided among the ranks of this node, at most 16."""
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    return max(2, min(16, (os.cpu_count() or 8) // max(1, local)))
 
 
 def model_answer_fn(model, tokenizer, image_processor, video_processor, model_name, max_frame_num=32, max_new_tokens=512,
-                    reuse_scenes=False, times=None):
-    """The per-rank loop of model_scanqa.py:130-206 around `model` (the loader-produced LlavaQwenForCausalLM)."""
+                    reuse_scenes=False, times=None, pipeline=True, group_size=16, workers=None, stats=None, record_fn=None):
+    """The per-rank loop of model_scanqa.py:130-206 around `model` (the loader-produced LlavaQwenForCausalLM).
+    pipeline (default): v3d.pipeline - asynchronous host loader, prefill / grouped-decode overlap, device-side stop test; the
+    records are those of the one-question-at-a-time loop (`pipeline=False`, the reference's own order of operations) up to the
+    f32 summation order of the decode linears (tests/test_gpu_eval_harness.py).  stats: dict that receives the host-stage seconds."""
+    record_fn = record_fn or (lambda line, text: make_record(line, text, model_name))
 
     def decode(ids):
         return clean_answer(tokenizer.batch_decode(ids.view(1, -1), skip_special_tokens=True)[0])
@@ -130,7 +147,7 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
             if times is not None:
                 torch.cuda.synchronize()
                 times.append(time.time() - t0)
-            out.append(make_record(line, decode(toks[0]), model_name))
+            out.append(record_fn(line, decode(toks[0])))
         return out
 
     def scene_batches(lines):
@@ -153,11 +170,58 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
                     qs = [x[at + 1:] for x in ids[b - i: min(j, b + 16) - i]]
                     room = eng.cfg.llm.max_pos - P - max(len(q) for q in qs) + 1
                     answers = eng.answer_group(qs, max_new_tokens=min(max_new_tokens, room), eos_token_id=eos)
-                    out += [make_record(l, decode(a), model_name) for l, a in zip(lines[b: b + len(qs)], answers)]
+                    out += [record_fn(l, decode(a)) for l, a in zip(lines[b: b + len(qs)], answers)]
             i = j
         return out
 
-    return scene_batches if reuse_scenes else one_by_one
+    def pipelined(lines):
+        """v3d.pipeline.ScenePipeline over this rank's questions (module docstring there)."""
+        from .pipeline import AsyncSceneLoader, ScenePipeline, SceneSample
+        eng = model.engine
+        pipe = model.__dict__.get("_v3d_pipeline")
+        if pipe is None or pipe.G != group_size:
+            pipe = model.__dict__["_v3d_pipeline"] = ScenePipeline(
+                eng, group_size, crop=image_processor.crop_size["width"], image_mean=image_processor.image_mean,
+                image_std=image_processor.image_std, rescale=image_processor.rescale_factor)
+        prompts = []
+        for line in lines:
+            ids = build_prompt_ids(line, tokenizer)[0]
+            if int((ids == IMAGE_TOKEN_INDEX).sum()) != 1:
+                raise ValueError("exactly one <image> placeholder per prompt (model_scanqa.py:61)")
+            prompts.append(ids)
+        files = {}
+
+        def plan(vid):
+            files[vid] = video_processor.frame_files(vid, True, max_frame_num)
+            return video_processor.raw_plan(vid, files[vid])
+
+        loader = AsyncSceneLoader([l["video"] for l in lines], plan, lambda vid, i, out: video_processor.load_frame(vid, files[vid], i, out),
+                                  workers=workers or default_workers())
+        waited = [0.0]
+
+        def samples():
+            for j, line in enumerate(lines):
+                raw, w = loader.get(j)
+                waited[0] += w
+                yield SceneSample(input_ids=prompts[j], raw=raw, key=line["video"])
+
+        n_vis = max_frame_num * eng.cfg.pool_out * (eng.cfg.pool_out + 1)
+        room = eng.cfg.llm.max_pos - (max((len(p) for p in prompts), default=1) - 1 + n_vis) + 1
+        t0 = time.time()
+        try:
+            toks = pipe.run(samples(), min(max_new_tokens, room), eos_token_id=model._eos())
+        finally:
+            loader.close()
+        if times is not None and lines:
+            times += [(time.time() - t0) / len(lines)] * len(lines)
+        if stats is not None:
+            stats.update({"host_thread_seconds": dict(loader.stage_seconds), "loader_wait_seconds": waited[0],
+                          "upload_enqueue_seconds": pipe.upload_seconds, "questions": len(lines), "wall_seconds": time.time() - t0})
+        return [record_fn(l, decode(t)) for l, t in zip(lines, toks)]
+
+    if reuse_scenes:
+        return scene_batches
+    return pipelined if pipeline else one_by_one
 
 
 def load_model(model_path, overwrite_cfg=False):
@@ -188,6 +252,11 @@ def main(argv=None):
     ap.add_argument("--frame_sampling_strategy", default="uniform")
     ap.add_argument("--overwrite_cfg", action="store_true")
     ap.add_argument("--reuse-scenes", action="store_true", help="share one scene prefill between consecutive questions of a scene")
+    ap.add_argument("--no-pipeline", action="store_true", help="one question at a time on one stream (the reference's order of operations)")
+    ap.add_argument("--decode-group", type=int, default=16, help="scenes whose decode steps share a pass over the weights (1..16)")
+    ap.add_argument("--loader-workers", type=int, default=0, help="host threads decoding frames ahead of the GPU (0: cores / ranks, at most 16)")
+    ap.add_argument("--shard", choices=("stride", "scene"), default=None,
+                    help="stride: questions[rank::world] (the reference); scene: whole scenes per rank (default with --reuse-scenes)")
     a = ap.parse_args(argv)
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
     with open(os.path.expanduser(a.question_file)) as f:
@@ -205,8 +274,9 @@ def main(argv=None):
     vp = VideoProcessor(video_folder=a.video_folder, annotation_dir=a.embodiedscan_folder, frame_sampling_strategy=a.frame_sampling_strategy,
                         metadata_dir=a.metadata_folder)
     times = []
-    fn = model_answer_fn(model, tokenizer, image_processor, vp, name, a.max_frame_num, a.max_new_tokens, a.reuse_scenes, times)
-    records = evaluate(questions, fn, rank, world, dev)
+    fn = model_answer_fn(model, tokenizer, image_processor, vp, name, a.max_frame_num, a.max_new_tokens, a.reuse_scenes, times,
+                         pipeline=not a.no_pipeline, group_size=a.decode_group, workers=a.loader_workers or None)
+    records = evaluate(questions, fn, rank, world, dev, shard=a.shard or ("scene" if a.reuse_scenes else "stride"))
     if rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(a.answer_file)), exist_ok=True)
         with open(a.answer_file, "w") as f:

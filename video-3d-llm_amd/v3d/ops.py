@@ -543,6 +543,13 @@ def argmax_rows(x, out, workspace):
     return out
 
 
+def eos_update(tokens, eos_ids, done, n_done):
+    """tokens int64 [M] (device), eos_ids int64 [n] (device), done int32 [M], n_done int32 [1]: done |= tokens in eos_ids;
+    n_done = done.sum() (v3d_eos_update)."""
+    check(lib().v3d_eos_update(_p(tokens), tokens.numel(), _p(eos_ids), eos_ids.numel(), _p(done), _p(n_done), _stream()), "v3d_eos_update")
+    return n_done
+
+
 _argmax_ws = {}
 
 
