@@ -145,15 +145,24 @@ def test_video_processor_on_scene_files(golden, tmp_path):
         with Image.open(files[v]) as im:
             ref = im.convert("RGB").resize((32, crop)).crop((4, 0, 4 + crop, crop))
         assert np.array_equal(out["images"][v].cpu().numpy(), np.asarray(ref))
-    # the asynchronous loader's per-frame path fills the same buffers as the one-shot load, and np.loadtxt's values
+    # the asynchronous loader (worker processes writing a pinned shared-memory block, and its inline form) delivers the same arrays
+    # as the one-shot load, and np.loadtxt's pose values
+    from v3d.pipeline import AsyncSceneLoader
     raw = vp.load_raw(vid, files)
-    n, alloc = vp.raw_plan(vid, files, pin=True)
-    buf = alloc()
-    assert n == V and buf["frames"].is_pinned()
-    for i in reversed(range(n)):
-        t = vp.load_frame(vid, files, i, buf)
-        assert set(t) == {"depth_png", "pose_txt", "rgb_decode"}
-    for k in ("depth", "frames", "pose", "K"):
-        assert torch.equal(raw[k], buf[k]), k
+    vp.sample_frame_files = lambda video_id, force_sample=False, frames_upbound=0: files
+    for workers in (2, 0):
+        loader = AsyncSceneLoader([vid, vid, vid], lambda v: vp.describe_scene(v, True, V), workers=workers, ahead=1, keep=2)
+        try:
+            for j in range(3):
+                got, _ = loader.get(j)
+                assert got["frames"].is_pinned() or not loader.blocks[0].pinned
+                for k in ("depth", "frames", "pose", "K"):
+                    assert torch.equal(raw[k], got[k]), (workers, j, k)
+                ev = torch.cuda.current_stream().record_event()
+                got["_done"](ev)
+            assert len(loader.blocks) == 1                                   # the three questions shared one decode
+            assert set(loader.stage_seconds) == {"depth_png", "pose_txt", "rgb_decode"}
+        finally:
+            loader.close()
     want_pose = np.stack([g["axis_align"].astype(np.float64) @ np.loadtxt(f.replace("jpg", "txt")) for f in files]).astype(np.float32)
-    assert np.array_equal(buf["pose"].numpy(), want_pose)
+    assert np.array_equal(raw["pose"].numpy(), want_pose)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 from PIL import Image
 
-from v3d import ops
+from v3d import frame_io, ops
 
 
 def _device():
@@ -27,8 +27,7 @@ def _device():
 
 
 def load_matrix_from_txt(path, shape=(4, 4)):
-    with open(path) as f:
-        return np.array([float(v) for v in f.read().split()]).reshape(shape)
+    return frame_io.read_matrix(path, shape)
 
 
 def unproject(intrinsics, poses, depths):
@@ -95,73 +94,39 @@ class VideoProcessor:
         n = frames_upbound if force_sample else 10
         return [files[i] for i in ops.uniform_frame_indices(len(files), n)]
 
-    # ---- host I/O of one frame (video_utils.py:214-227, 285-290): depth PNG, pose txt, RGB file -> the caller's buffers
-    @staticmethod
-    def _read_depth(path):
-        with Image.open(path.replace(".jpg", ".png")) as im:
-            return np.array(im).astype(np.uint16)
-
-    def _read_pose(self, video_id, path):
-        # np.loadtxt(path) value for value (both parse each field with a correctly rounded decimal -> double conversion), minus its
-        # Python-level overhead; then axis_align @ pose in f64 (:227)
-        return self._align(video_id) @ load_matrix_from_txt(path.replace("jpg", "txt"))
-
+    # ---- host I/O (video_utils.py:214-227, 285-290) lives in v3d.frame_io (torch-free, so loader processes can run it)
     def _align(self, video_id):
         return np.array(self.scene[video_id]["axis_align_matrix"], dtype=np.float64)
-
-    @staticmethod
-    def _read_rgb(path):
-        with Image.open(path) as im:
-            return np.asarray(im.convert("RGB"))
 
     def frame_files(self, video_id, force_sample=False, frames_upbound=0):
         if "mc" in self.frame_sampling_strategy:
             return self.sample_frame_files_mc(video_id, frames_upbound, "shift" in self.frame_sampling_strategy)
         return self.sample_frame_files(video_id, force_sample, frames_upbound)
 
-    def raw_plan(self, video_id, frame_files, pin=True):
-        """(n_frames, alloc): alloc() -> the host buffers one scene's frames are decoded into (pinned, so the upload is one
-        asynchronous copy per array): depth [F,Hd,Wd] int16 view of the 16-bit PNG values, frames [F,Hc,Wc,3] uint8, pose [F,4,4] f32,
-        K [F,4,4] f32.  Sizes come from the first frame's file headers (the colour and depth streams differ: 1296 x 968 / 640 x 480
-        in ScanNet)."""
-        with Image.open(frame_files[0]) as im:
-            Wc, Hc = im.size
-        with Image.open(frame_files[0].replace(".jpg", ".png")) as im:
-            Wd, Hd = im.size
-        n = len(frame_files)
-        K = torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()
+    def describe_scene(self, video_id, force_sample=False, frames_upbound=0):
+        """What v3d.pipeline.AsyncSceneLoader needs to decode a scene's sampled frames off the main thread."""
+        return {"files": self.frame_files(video_id, force_sample, frames_upbound), "axis_align": self._align(video_id).tolist(),
+                "K": torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()}
 
-        def alloc():
-            mk = (lambda *sh, dtype: torch.empty(sh, dtype=dtype).pin_memory()) if pin and torch.cuda.is_available() else \
-                 (lambda *sh, dtype: torch.empty(sh, dtype=dtype))
-            return {"depth": mk(n, Hd, Wd, dtype=torch.int16), "frames": mk(n, Hc, Wc, 3, dtype=torch.uint8),
-                    "pose": mk(n, 4, 4, dtype=torch.float32), "K": K.unsqueeze(0).repeat(n, 1, 1)}
-        return n, alloc
-
-    def load_frame(self, video_id, frame_files, i, out):
-        """Decode frame i's three files into `out` (thread-safe: every frame writes its own rows); returns the seconds spent
-        per stage (for the eval runner's host-side breakdown)."""
-        import time
-        t0 = time.perf_counter()
-        out["depth"][i] = torch.from_numpy(self._read_depth(frame_files[i]).view(np.int16))
-        t1 = time.perf_counter()
-        out["pose"][i] = torch.from_numpy(self._read_pose(video_id, frame_files[i])).float()        # f64 product, then .float() (:227, 230)
-        t2 = time.perf_counter()
-        out["frames"][i] = torch.from_numpy(self._read_rgb(frame_files[i]))
-        t3 = time.perf_counter()
-        return {"depth_png": t1 - t0, "pose_txt": t2 - t1, "rgb_decode": t3 - t2}
-
-    def load_raw(self, video_id, frame_files, pin=False):
-        n, alloc = self.raw_plan(video_id, frame_files, pin)
-        out = alloc()
-        for i in range(n):
-            self.load_frame(video_id, frame_files, i, out)
+    def load_raw(self, video_id, frame_files):
+        """The sampled frames' files -> host arrays: depth [F,Hd,Wd] int16 view of the 16-bit PNG values, frames [F,Hc,Wc,3] uint8,
+        pose [F,4,4] f32 (= f32(axis_align @ pose), :227-230), K [F,4,4] f32.  (The colour and depth streams differ in size: 1296 x 968
+        and 640 x 480 in ScanNet.)"""
+        color_hw, depth_hw = frame_io.image_sizes(frame_files[0])
+        layout, nbytes = frame_io.scene_layout(len(frame_files), color_hw, depth_hw)
+        buf = bytearray(nbytes)
+        arrays = frame_io.views(buf, layout)
+        align = self._align(video_id)
+        for i, f in enumerate(frame_files):
+            frame_io.decode_into(arrays, i, f, align)
+        out = {k: torch.from_numpy(v) for k, v in arrays.items()}
+        out["K"] = torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float().unsqueeze(0).repeat(len(frame_files), 1, 1)
         return out
 
     def _load_depth_pose(self, video_id, frame_files):
         K = torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()
-        depths = [self._read_depth(p) for p in frame_files]
-        poses = [self._read_pose(video_id, p) for p in frame_files]
+        depths = [frame_io.read_depth(p) for p in frame_files]
+        poses = [frame_io.read_pose(p, self._align(video_id)) for p in frame_files]
         depth = torch.from_numpy(np.stack(depths).view(np.int16))
         pose = torch.from_numpy(np.stack(poses)).float()
         return depth, K.unsqueeze(0).repeat(len(frame_files), 1, 1), pose

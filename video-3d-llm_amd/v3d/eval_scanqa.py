@@ -117,17 +117,24 @@ def evaluate(questions, answer_fn, rank, world, device, shard="stride"):
 
 
 def default_workers():
-    """Loader threads per process: the host cores divided among the ranks of this node, at most 16."""
+    """Loader processes per rank: the host cores this process may run on, divided among the ranks of the node, at most 16 (one
+    question's 32 frames cost about half a core-second to decode; a GPU answers ten questions a second)."""
     local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
-    return max(2, min(16, (os.cpu_count() or 8) // max(1, local)))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 8
+    return max(2, min(16, cores // max(1, local)))
 
 
 def model_answer_fn(model, tokenizer, image_processor, video_processor, model_name, max_frame_num=32, max_new_tokens=512,
-                    reuse_scenes=False, times=None, pipeline=True, group_size=16, workers=None, stats=None, record_fn=None):
+                    reuse_scenes=False, times=None, pipeline=True, group_size=16, workers=None, stats=None, record_fn=None, pool=None):
     """The per-rank loop of model_scanqa.py:130-206 around `model` (the loader-produced LlavaQwenForCausalLM).
     pipeline (default): v3d.pipeline - asynchronous host loader, prefill / grouped-decode overlap, device-side stop test; the
     records are those of the one-question-at-a-time loop (`pipeline=False`, the reference's own order of operations) up to the
-    f32 summation order of the decode linears (tests/test_gpu_eval_harness.py).  stats: dict that receives the host-stage seconds."""
+    f32 summation order of the decode linears (tests/test_gpu_eval_harness.py).  stats: dict that receives the host-stage seconds.
+    pool: v3d.frame_io.make_pool(...) of decoding processes (make it BEFORE the process initialises the GPU); default: one per call;
+    workers = 0 decodes on the calling thread."""
     record_fn = record_fn or (lambda line, text: make_record(line, text, model_name))
 
     def decode(ids):
@@ -189,14 +196,8 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
             if int((ids == IMAGE_TOKEN_INDEX).sum()) != 1:
                 raise ValueError("exactly one <image> placeholder per prompt (model_scanqa.py:61)")
             prompts.append(ids)
-        files = {}
-
-        def plan(vid):
-            files[vid] = video_processor.frame_files(vid, True, max_frame_num)
-            return video_processor.raw_plan(vid, files[vid])
-
-        loader = AsyncSceneLoader([l["video"] for l in lines], plan, lambda vid, i, out: video_processor.load_frame(vid, files[vid], i, out),
-                                  workers=workers or default_workers())
+        loader = AsyncSceneLoader([l["video"] for l in lines], lambda vid: video_processor.describe_scene(vid, True, max_frame_num),
+                                  workers=default_workers() if workers is None else workers, pool=pool)
         waited = [0.0]
 
         def samples():
@@ -213,7 +214,7 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
         finally:
             loader.close()
         if times is not None and lines:
-            times += [(time.time() - t0) / len(lines)] * len(lines)
+            times.extend([(time.time() - t0) / len(lines)] * len(lines))
         if stats is not None:
             stats.update({"host_thread_seconds": dict(loader.stage_seconds), "loader_wait_seconds": waited[0],
                           "upload_enqueue_seconds": pipe.upload_seconds, "questions": len(lines), "wall_seconds": time.time() - t0})
@@ -254,7 +255,8 @@ def main(argv=None):
     ap.add_argument("--reuse-scenes", action="store_true", help="share one scene prefill between consecutive questions of a scene")
     ap.add_argument("--no-pipeline", action="store_true", help="one question at a time on one stream (the reference's order of operations)")
     ap.add_argument("--decode-group", type=int, default=16, help="scenes whose decode steps share a pass over the weights (1..16)")
-    ap.add_argument("--loader-workers", type=int, default=0, help="host threads decoding frames ahead of the GPU (0: cores / ranks, at most 16)")
+    ap.add_argument("--loader-workers", type=int, default=0,
+                    help="host processes decoding frames ahead of the GPU (0: cores / ranks, at most 16; -1: none, decode on the main thread)")
     ap.add_argument("--shard", choices=("stride", "scene"), default=None,
                     help="stride: questions[rank::world] (the reference); scene: whole scenes per rank (default with --reuse-scenes)")
     a = ap.parse_args(argv)
@@ -264,6 +266,10 @@ def main(argv=None):
     if os.path.exists(a.answer_file):                                                         # model_scanqa.py:238-240
         print(f"The {a.answer_file} already exists!!!")
         return 0
+    pool = None
+    if not a.no_pipeline and not a.reuse_scenes and a.loader_workers >= 0:
+        from . import frame_io
+        pool = frame_io.make_pool(a.loader_workers or default_workers())        # forked before this process touches the GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -275,7 +281,7 @@ def main(argv=None):
                         metadata_dir=a.metadata_folder)
     times = []
     fn = model_answer_fn(model, tokenizer, image_processor, vp, name, a.max_frame_num, a.max_new_tokens, a.reuse_scenes, times,
-                         pipeline=not a.no_pipeline, group_size=a.decode_group, workers=a.loader_workers or None)
+                         pipeline=not a.no_pipeline, group_size=a.decode_group, workers=(0 if a.loader_workers < 0 else a.loader_workers or None), pool=pool)
     records = evaluate(questions, fn, rank, world, dev, shard=a.shard or ("scene" if a.reuse_scenes else "stride"))
     if rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(a.answer_file)), exist_ok=True)
@@ -284,6 +290,8 @@ def main(argv=None):
                 f.write(json.dumps(r) + "\n")
         if times:
             print(f"time: {sum(times) / len(times)}")                                        # model_scanqa.py:252
+    if pool is not None:
+        pool.shutdown(wait=True, cancel_futures=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -3,9 +3,9 @@
 Reference loop it replaces: llava/eval/model_scanqa.py:130-206 - per question: load the scene's frames on the host, run the whole
 model, decode token by token, all on one thread and one stream.  Here, per GPU:
 
-  * `AsyncSceneLoader`: a thread pool decodes the JPEG / depth-PNG / pose-txt files of the NEXT questions' scenes into pinned
-    buffers while the GPU works (video_utils.py:196-238, 285-290 are host I/O; PIL releases the GIL while it decodes).  A scene
-    asked about again shortly after is not decoded twice.
+  * `AsyncSceneLoader`: worker processes (v3d.frame_io) decode the JPEG / depth-PNG / pose-txt files of the NEXT questions' scenes
+    straight into pinned shared-memory blocks while the GPU works (video_utils.py:196-238, 285-290 are host I/O).  A scene asked
+    about again shortly after is not decoded twice.
   * `ScenePipeline.prefill`: upload (pinned, asynchronous) -> back-projection at the surviving pixels (K1+K2), Pillow-exact RGB
     resize + crop + normalise (a6/a7) -> ViT -> projector -> fusion -> Qwen2 prefill, on stream A, one scene after the other
     (MFMA-bound).  The device tensors of the last few scenes are kept, so consecutive questions about one scene upload once.
@@ -16,8 +16,6 @@ model, decode token by token, all on one thread and one stream.  Here, per GPU:
 Every (scene, question) still takes the complete path; a scene's tokens do not depend on its group (tests/test_gpu_engine.py).
 """
 import collections
-import concurrent.futures as cf
-import threading
 import time
 from dataclasses import dataclass, field
 from typing import Any, Optional
@@ -41,56 +39,136 @@ class SceneSample:
     extra: dict = field(default_factory=dict)
 
 
-class AsyncSceneLoader:
-    """Loads `load_frame(key, i, out)` for the frames of each key on a thread pool, `ahead` scenes in front of the consumer.
-    plan(key) -> (n_frames, alloc) where alloc() returns the dict of pinned buffers load_frame fills; get(j) blocks until scene j
-    (in the order of `keys`) is complete and returns (payload, seconds the consumer waited).  Equal keys within `keep` scenes of each
-    other are loaded once."""
+class _HostBlock:
+    """One scene's frames in a shared-memory block that worker processes write and the GPU reads by DMA (registered as pinned)."""
 
-    def __init__(self, keys, plan, load_frame, workers=8, ahead=6, keep=4):
-        self.keys, self.plan, self.load_frame = list(keys), plan, load_frame
-        self.pool = cf.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="v3d-loader")
+    def __init__(self, nbytes):
+        from multiprocessing import shared_memory
+        self.shm = shared_memory.SharedMemory(create=True, size=nbytes)
+        self.nbytes = self.shm.size
+        self.bytes = torch.frombuffer(self.shm.buf, dtype=torch.uint8)
+        self.pinned = False
+        if torch.cuda.is_available():
+            rc = torch.cuda.cudart().cudaHostRegister(self.bytes.data_ptr(), self.nbytes, 0)
+            self.pinned = int(rc) == 0
+        self.event = None                   # the last upload out of this block
+
+    def tensors(self, layout):
+        out = {}
+        for k, (shape, dt, off) in layout.items():
+            n = 1
+            for d in shape:
+                n *= d
+            tdt = getattr(torch, dt)
+            out[k] = self.bytes[off: off + n * torch.empty(0, dtype=tdt).element_size()].view(tdt).view(shape)
+        return out
+
+    def close(self):
+        try:
+            if self.pinned:
+                torch.cuda.cudart().cudaHostUnregister(self.bytes.data_ptr())
+        finally:
+            self.bytes = None
+            try:
+                self.shm.close()
+            except BufferError:
+                pass
+            self.shm.unlink()
+
+
+class AsyncSceneLoader:
+    """Decodes the frames of the scenes of `keys` (one key per question, in question order) `ahead` scenes in front of the consumer,
+    in worker PROCESSES (v3d.frame_io) that write straight into pinned shared-memory blocks.
+    describe(key) -> dict(files=[colour file of each frame], axis_align=4x4, K=[4,4] f32 tensor) - called on the consumer's thread.
+    get(j) -> (payload, seconds waited): payload = dict(depth int16-view [F,Hd,Wd], frames u8 [F,Hc,Wc,3], pose f32 [F,4,4], K [F,4,4],
+    _done=callback(event)) - the consumer calls payload["_done"](event recorded after its uploads, or None) when it no longer needs
+    the host arrays; the block is then recycled.  Equal keys within `keep` scenes of each other are decoded once.
+    workers = 0: no processes, frames are decoded on the consumer's thread inside get() (tests, tiny runs)."""
+
+    def __init__(self, keys, describe, workers=8, ahead=6, keep=4, pool=None):
+        from . import frame_io
+        self.io = frame_io
+        self.keys, self.describe = list(keys), describe
+        self.own_pool = pool is None and workers > 0
+        self.pool = pool if pool is not None else (frame_io.make_pool(workers) if workers > 0 else None)
         self.ahead, self.keep = ahead, keep
-        self.jobs = {}                      # position -> (payload, [futures])
+        self.jobs = {}
         self.by_key = collections.OrderedDict()
+        self.free, self.blocks = [], []
         self.next_submit = 0
         self.stage_seconds = collections.Counter()
-        self.lock = threading.Lock()
+
+    def _block(self, nbytes):
+        for i, blk in enumerate(self.free):
+            if blk.nbytes >= nbytes:
+                self.free.pop(i)
+                if blk.event is not None:
+                    blk.event.synchronize()         # its last upload has left the block
+                    blk.event = None
+                return blk
+        blk = _HostBlock(nbytes)
+        self.blocks.append(blk)
+        return blk
+
+    def _unref(self, job, event=None):
+        if event is not None:
+            job["block"].event = event
+        job["refs"] -= 1
+        if job["refs"] == 0:
+            self.free.append(job["block"])
 
     def _submit(self, j):
         key = self.keys[j]
-        hit = self.by_key.get(key)
-        if hit is not None:
+        job = self.by_key.get(key)
+        if job is not None:
             self.by_key.move_to_end(key)
-            self.jobs[j] = hit
+            job["refs"] += 1
+            self.jobs[j] = job
             return
-        n, alloc = self.plan(key)
-        payload = alloc()
-
-        def one(i):
-            t = self.load_frame(key, i, payload)
-            if t:
-                with self.lock:
-                    self.stage_seconds.update(t)
-
-        job = (payload, [self.pool.submit(one, i) for i in range(n)])
+        d = self.describe(key)
+        files = list(d["files"])
+        color_hw, depth_hw = self.io.image_sizes(files[0])
+        layout, nbytes = self.io.scene_layout(len(files), color_hw, depth_hw)
+        blk = self._block(nbytes)
+        payload = blk.tensors(layout)
+        payload["K"] = d["K"].float().unsqueeze(0).repeat(len(files), 1, 1)
+        align = [list(map(float, r)) for r in d["axis_align"]]
+        job = {"payload": payload, "block": blk, "refs": 2, "layout": layout, "files": files, "align": align, "futures": None}     # this position + the key table
+        if self.pool is not None:
+            job["futures"] = [self.pool.submit(self.io._worker_decode, blk.shm.name, layout, i, f, align) for i, f in enumerate(files)]
         self.jobs[j] = job
         self.by_key[key] = job
         while len(self.by_key) > self.keep:
-            self.by_key.popitem(last=False)
+            _, old = self.by_key.popitem(last=False)
+            self._unref(old)
 
     def get(self, j):
         while self.next_submit < min(len(self.keys), j + 1 + self.ahead):
             self._submit(self.next_submit)
             self.next_submit += 1
-        payload, futs = self.jobs.pop(j)
+        job = self.jobs.pop(j)
         t0 = time.perf_counter()
-        for f in futs:
-            f.result()                      # re-raises a loader exception here, on the consumer's thread
+        if job["futures"] is not None:
+            for f in job["futures"]:
+                self.stage_seconds.update(f.result())         # re-raises a worker's exception here, on the consumer's thread
+            job["futures"] = []
+        elif job["files"] is not None:                         # inline mode
+            arrays = self.io.views(job["block"].shm.buf, job["layout"])
+            for i, f in enumerate(job["files"]):
+                self.stage_seconds.update(self.io.decode_into(arrays, i, f, job["align"]))
+            job["files"] = None
+        payload = dict(job["payload"])
+        payload["_done"] = lambda event=None, job=job: self._unref(job, event)
         return payload, time.perf_counter() - t0
 
     def close(self):
-        self.pool.shutdown(wait=False, cancel_futures=True)
+        if self.own_pool and self.pool is not None:
+            self.pool.shutdown(wait=True, cancel_futures=True)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for blk in self.blocks:
+            blk.close()
+        self.blocks, self.free = [], []
 
 
 class ScenePipeline:
@@ -115,6 +193,8 @@ class ScenePipeline:
         eng, dt = self.eng, self.eng.dtype
         if sample.key is not None and sample.key in self.scene_cache:
             self.scene_cache.move_to_end(sample.key)
+            if isinstance(sample.raw, dict) and "_done" in sample.raw:
+                sample.raw["_done"](None)          # nothing to upload: the scene's device tensors are still here
             return self.scene_cache[sample.key]
         if sample.images is not None:
             images = sample.images.to(device=eng.device, dtype=dt, non_blocking=True)
@@ -128,6 +208,8 @@ class ScenePipeline:
             K = raw["K"].to(eng.device, non_blocking=True)
             pose = raw["pose"].to(eng.device, non_blocking=True)
             frames = raw["frames"].to(eng.device, non_blocking=True)
+            if "_done" in raw:                     # the loader may recycle the host block once these copies have run
+                raw["_done"](torch.cuda.current_stream().record_event())
             self.upload_seconds += time.perf_counter() - t0
             coords = ops.unproject_sampled(depth, K, pose, self.crop, dt)                                     # K1 + K2
             H, W = frames.shape[1:3]
@@ -169,39 +251,35 @@ class ScenePipeline:
         keep = eng.ctx
         out = []
 
-        def take():
-            batch = []
-            for smp in it:
-                batch.append(smp)
-                if len(batch) == G:
-                    break
-            return batch
-
-        def prefill_group(gi, batch, first):
-            ctxs = self.sets[gi % 2][: len(batch)]
-            lens = []
+        def prefill_group(gi, first):
+            """Pulls up to G samples from the iterator, one at a time (a sample's host block is uploaded before the next one is
+            asked for), and queues their prefills on stream A.  None when the iterator is exhausted."""
+            ctxs_all = self.sets[gi % 2]
+            ctxs, lens = [], []
             with torch.cuda.stream(sA if overlap else torch.cuda.current_stream()):
-                for c, smp in zip(ctxs, batch):
+                for c in ctxs_all:
+                    smp = next(it, None)
+                    if smp is None:
+                        break
                     eng.use(c)
                     # kernel stamps on the first scene only: its prefill runs with nothing else on the chip
                     lens.append(self.prefill(smp, max_new_tokens, stamps if (first and not lens) else None))
+                    ctxs.append(c)
                 done = torch.cuda.current_stream().record_event()
-            return ctxs, lens, done
+            return (ctxs, lens, done) if ctxs else None
 
         try:
             cur = torch.cuda.current_stream()
             if overlap:
                 sA.wait_stream(cur)
                 sB.wait_stream(cur)
-            batch = take()
             gi = 0
-            pending = prefill_group(0, batch, True) if batch else None
+            pending = prefill_group(0, True)
             while pending is not None:
                 ctxs, lens, pre_done = pending
-                nxt = take()
                 # the next group's prefills are queued BEFORE this group's decode: the host then polls the decode's stop test
                 # while stream A stays busy.  Its context set was last used by group gi - 1, whose tokens the host already holds.
-                pending = prefill_group(gi + 1, nxt, False) if nxt else None
+                pending = prefill_group(gi + 1, False)
                 with torch.cuda.stream(sB if overlap else torch.cuda.current_stream()):
                     torch.cuda.current_stream().wait_event(pre_done)
                     toks = eng.decode_group(self.groups[gi % 2], ctxs, lens, max_new_tokens, eos_token_id=eos_token_id)
