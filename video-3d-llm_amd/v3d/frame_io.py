@@ -86,6 +86,13 @@ def _worker_decode(shm_name, layout, i, path_jpg, axis_align):
                 s.close()
             _ATTACHED.clear()
         shm = _ATTACHED[shm_name] = shared_memory.SharedMemory(name=shm_name)
+        # Python < 3.13 registers an ATTACHED block with the attaching process's resource tracker, which would unlink it when this
+        # worker exits; the parent owns the block
+        from multiprocessing import resource_tracker
+        try:
+            resource_tracker.unregister(shm._name, "shared_memory")
+        except Exception:
+            pass
     return decode_into(views(shm.buf, layout), i, path_jpg, axis_align)
 
 

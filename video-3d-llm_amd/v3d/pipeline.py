@@ -73,7 +73,10 @@ class _HostBlock:
                 self.shm.close()
             except BufferError:
                 pass
-            self.shm.unlink()
+            try:
+                self.shm.unlink()
+            except FileNotFoundError:
+                pass
 
 
 class AsyncSceneLoader:
@@ -182,6 +185,7 @@ class ScenePipeline:
         self.groups = [eng.new_group(group_size), eng.new_group(group_size)]
         dev = torch.device(eng.device)
         self.streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        self.copy_stream = torch.cuda.Stream(device=dev)
         self.scene_cache = collections.OrderedDict()
         self.scene_cache_size = scene_cache
         self.upload_seconds = 0.0
@@ -204,12 +208,20 @@ class ScenePipeline:
             if hasattr(raw, "result"):
                 raw = raw.result()
             t0 = time.perf_counter()
-            depth = raw["depth"].to(eng.device, non_blocking=True)
-            K = raw["K"].to(eng.device, non_blocking=True)
-            pose = raw["pose"].to(eng.device, non_blocking=True)
-            frames = raw["frames"].to(eng.device, non_blocking=True)
+            # uploads ride their own stream: the 140 MB of the NEXT scene cross PCIe while this stream still runs the previous scene's
+            # kernels (the host is a scene or more ahead of the GPU)
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(self.copy_stream):
+                depth = raw["depth"].to(eng.device, non_blocking=True)
+                K = raw["K"].to(eng.device, non_blocking=True)
+                pose = raw["pose"].to(eng.device, non_blocking=True)
+                frames = raw["frames"].to(eng.device, non_blocking=True)
+                up = self.copy_stream.record_event()
+            for t in (depth, K, pose, frames):
+                t.record_stream(cur)
+            cur.wait_event(up)
             if "_done" in raw:                     # the loader may recycle the host block once these copies have run
-                raw["_done"](torch.cuda.current_stream().record_event())
+                raw["_done"](up)
             self.upload_seconds += time.perf_counter() - t0
             coords = ops.unproject_sampled(depth, K, pose, self.crop, dt)                                     # K1 + K2
             H, W = frames.shape[1:3]
