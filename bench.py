@@ -402,6 +402,7 @@ def main():
     rehearsal = os.environ.get("V3D_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+        os.environ["V3D_GEMM_STREAMK"] = "0"      # ranks share one card: the GEMM's split-K tail assumes one tail launch on the chip
     loader_pool, n_workers = None, 0
     if world == 1 and (a.eval_runner_only or not a.no_extras):     # the eval_runner extra's decoding processes: forked before the GPU is touched
         from v3d import eval_scanqa as _E, frame_io
@@ -409,7 +410,10 @@ def main():
         loader_pool = frame_io.make_pool(n_workers)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # V3D_BENCH_FORCE_DIST=1: take the N > 1 code path (RCCL process group, record gather, max-over-ranks all-reduce) with ONE rank -
+    # what a one-GPU box can execute of it (launched under torch.distributed.run with --nproc-per-node 1)
+    multi = world > 1 or os.environ.get("V3D_BENCH_FORCE_DIST") == "1"
+    if multi:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -435,7 +439,7 @@ def main():
     stamps = new_stamps()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -452,12 +456,12 @@ def main():
         t0 = time.perf_counter()
         answers = torch.cat(pipe.run(samples_of(scenes, a.steps, SceneSample), NEW_TOKENS, overlap=not a.no_overlap, stamps=stamps, trim=False), 0)
         merged = None
-        if world > 1:   # eval collation: ONE variable-length gather of the answer records to rank 0 (replaces Ray + file lock)
+        if multi:   # eval collation: ONE variable-length gather of the answer records to rank 0 (replaces Ray + file lock)
             recs = [{"sample_id": sid, "pred_token_ids": row} for sid, row in zip(my_ids, answers.tolist())]
             merged = v3dist.gather_records(recs, torch.device("cpu") if rehearsal else dev)
         barrier()
         dt_s = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt_s], device="cpu" if rehearsal else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_s = tt.item()
@@ -562,7 +566,7 @@ def main():
         print(json.dumps(line))
     if loader_pool is not None:
         loader_pool.shutdown(wait=True, cancel_futures=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -437,9 +437,11 @@ int v3d_adamw_step(float* p32, float* m, float* v, const void* grad, int grad_dt
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* Gradient of the embedding lookup for the text rows of a sample (llava_arch.py:650-700 embeds them with embed_tokens):
  * dE[ids[i], :] = sum over the j with ids[j] == ids[i], in order, of dh[rows[j], :] (f32 sums, one rounding); rows / ids: device
- * int64 [n].  Rows of dE that no id names are not touched (the caller zero-fills). */
-int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde, int dtype,
-                   void* stream);
+ * int64 [n].  Rows of dE that no id names are not touched (the caller zero-fills).
+ * dh has n_rows rows, dE vocab rows: ids outside [0, vocab) (a raw prompt's IMAGE_TOKEN_INDEX = -200) and rows outside
+ * [0, n_rows) are skipped - nothing is read or written for them. */
+int v3d_embed_grad(const void* dh, int64_t ld, int64_t n_rows, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde,
+                   int64_t vocab, int dtype, void* stream);
 
 /* GELU as a pass of its own for the training forward (which keeps the pre-activation z) and its gradient dz = dy * gelu'(z):
  * tanh_form 0 = nn.GELU() of the mm_projector (multimodal_projector/builder.py:41-48), 1 = gelu_pytorch_tanh of the SigLIP MLP

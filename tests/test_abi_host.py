@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/v3d.h but not exported"
         assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.v3d_abi_version() == 3
+    assert lib.v3d_abi_version() == 4
 
 
 def test_invalid_arguments_report_an_error():
@@ -181,7 +181,7 @@ def test_training_entry_points_reject_bad_arguments_before_any_launch():
                                  0, 0, 0, 0, 0, 0, 0, 0, 1, 1.0, p, 16, None),                  # workspace too small
         l.v3d_adamw_step(ctypes.cast(p, ctypes.c_void_p), ctypes.cast(p, ctypes.c_void_p), ctypes.cast(p, ctypes.c_void_p), p, bf16, None, 0, 8, 1e-3, 0.9, 0.999,
                          1e-8, 0.0, 0, 1.0, None),                                             # step counts from 1
-        l.v3d_embed_grad(p, 8, None, None, 1, 8, p, 8, bf16, None),                            # null index arrays
+        l.v3d_embed_grad(p, 8, 1, None, None, 1, 8, p, 8, 1, bf16, None),                            # null index arrays
     ]
     assert all(rc < 0 for rc in bad), bad
     assert l.v3d_attention_backward_workspace_bytes(2, 100, 4) == (2 * 4 * 100 + 2 * 2 * 4 * 100 * 128) * 4

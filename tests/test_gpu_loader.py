@@ -147,3 +147,39 @@ def test_plain_and_grounding_forward_match_the_reference(loaded, g):
     lab = tup[5][0].cpu()
     assert lab.shape[0] == tup[4].shape[1] == 432 and int((lab == TM.GROUND_TOKEN).nonzero()[0]) == 10 + 420 - 1
     assert tup[6].shape == (5, 256) and tup[7].shape == (5, 6)
+
+
+def test_vocabulary_growth_and_tied_head(g, tmp_path):
+    """(1) builder.py:282-287 adds <im_patch> (mm_use_im_patch_token defaults to True) before resize_token_embeddings(len(tokenizer)):
+    growing the tables must work - new rows = mean of the old ones, never the argmax, the answers unchanged; the fallback loader
+    (v3d.loader.load_pretrained_model) mirrors the add_tokens step; (2) a checkpoint saved with tied embeddings has no lm_head.weight."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from v3d import loader as L
+    path = TM.write_checkpoint(str(tmp_path / "llava_qwen_grow"), g)
+    cfg = json.load(open(os.path.join(path, "config.json")))
+    cfg["mm_use_im_patch_token"] = True
+    json.dump(cfg, open(os.path.join(path, "config.json"), "w"))
+    tok, model, _, _ = L.load_pretrained_model(path, None, "llava_qwen_grow")
+    assert len(tok) == 321 and model.engine.cfg.llm.vocab == 321 and model.engine.embed.shape[0] == 321
+    base = load_like_builder(TM.write_checkpoint(str(tmp_path / "llava_qwen_base"), g))[1]
+    inp, images, video_dict = _call_args(g, "F2")
+    kw = dict(images=images, modalities="video", do_sample=False, num_beams=1, max_new_tokens=5, use_cache=True, video_dict=video_dict)
+    a = model.generate(inp["ids"][None].cuda(), **kw)
+    b = base.generate(inp["ids"][None].cuda(), **kw)
+    assert torch.equal(a, b) and int(a.max()) < 320
+    assert torch.equal(model.engine.embed[:320], base.engine.embed[:320])
+    assert torch.allclose(model.engine.embed[320].float(), base.engine.embed[:320].float().mean(0), atol=2e-3)
+    # tied checkpoint: drop lm_head.weight from the shards, make it equal to the embedding table
+    tied = TM.write_checkpoint(str(tmp_path / "llava_qwen_tied"), g)
+    idx = json.load(open(os.path.join(tied, "model.safetensors.index.json")))
+    shard = idx["weight_map"].pop("lm_head.weight")
+    sd = load_file(os.path.join(tied, shard))
+    del sd["lm_head.weight"]
+    save_file(sd, os.path.join(tied, shard), metadata={"format": "pt"})
+    json.dump(idx, open(os.path.join(tied, "model.safetensors.index.json"), "w"))
+    cfg = json.load(open(os.path.join(tied, "config.json")))
+    cfg["tie_word_embeddings"] = True
+    json.dump(cfg, open(os.path.join(tied, "config.json"), "w"))
+    m2 = load_like_builder(tied)[1]
+    assert torch.equal(m2.engine.l_head[:320], m2.engine.embed[:320])

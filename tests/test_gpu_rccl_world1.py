@@ -1,0 +1,89 @@
+"""The RCCL code paths, executed (r03): a world-size-1 "nccl" process group on the one GPU of the box runs every collective call site
+of the product on DEVICE tensors - the eval collation (gather_bytes / gather_records / gather_indexed: all_gather + gather), ZeRO-2's
+bucketed reduce-scatter in both algorithms ("ring" = RCCL's reduce_scatter_tensor, "direct" = all_to_all_single + ordered sum), the
+parameter all-gather (copying and in-place forms) and two ZeroAdamW steps, which must equal the plain AdamW bit for bit.  With one
+rank nothing crosses a link, but the code that had only ever run over gloo on host tensors now runs through RCCL in HBM
+(scripts/zero2.json:22-34; model_scanqa.py:194-206, 242-247).  The 8-GPU exchange itself is the driver's to measure."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_eval_collation_over_rccl(nccl_world1):
+    from v3d import distributed as D
+    dev = torch.device("cuda", 0)
+    recs = [{"sample_id": i, "pred_response": "x" * (i % 5)} for i in range(7)]
+    assert D.gather_records(recs, dev) == recs
+    assert D.gather_indexed(recs[::-1], list(range(7))[::-1], dev) == recs
+    assert D.gather_bytes(b"", dev) == [b""] and D.gather_bytes(b"abc", dev) == [b"abc"]
+    with pytest.raises(RuntimeError):
+        D.gather_indexed(recs[:2], [0, 5], dev)                      # the indices must cover the list exactly once
+
+
+@pytest.mark.parametrize("algorithm", ["ring", "direct"])
+def test_zero2_exchanges_over_rccl(nccl_world1, algorithm):
+    from v3d import distributed as D
+    g = torch.Generator(device="cuda").manual_seed(1)
+    flat = torch.randn(1003, generator=g, device="cuda").to(torch.bfloat16)
+    part = D.reduce_scatter_grads(flat, bucket_elems=257, average=True, algorithm=algorithm)         # four buckets, ragged tail
+    assert part.is_cuda and torch.equal(part[:1003], flat)
+    full = D.all_gather_params(part, 1003, bucket_elems=300)
+    assert torch.equal(full, flat)
+    buf = flat.clone()
+    assert D.all_gather_params_into(buf, 0, 1003, bucket_elems=300) is buf and torch.equal(buf, flat)
+
+
+def _tree(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.1).to(torch.bfloat16).to(dev)       # noqa: E731
+    return {"llm": {"layers": [{"qkv": mk(24, 16), "o": mk(16, 16)}, {"qkv": mk(24, 16), "o": mk(16, 16)}], "norm": mk(16), "lm_head": mk(40, 16)},
+            "ground": {"obj": {"w0": mk(16, 16), "b0": mk(16)}, "zero_target": mk(16)}, "newline": mk(16)}
+
+
+def test_zero_adamw_over_rccl_equals_adamw_bitwise_and_flattens_by_key(nccl_world1):
+    """Two steps: (1) a full gradient tree handed over in ANOTHER key order, (2) a grounding-sample tree (no llm.lm_head) - ADVICE r2:
+    the flat gradient is laid out by the PARAMETER tree's keys, absent leaves are zeros, unknown keys / shapes raise."""
+    from v3d import train
+    dev = "cuda:0"
+    params_a, params_b = _tree(dev, 3), _tree(dev, 3)
+    zero = train.ZeroAdamW(params_a, lr=1e-2, weight_decay=0.01, bucket_elems=200)
+    plain = train.AdamW(params_b, lr=1e-2, weight_decay=0.01)
+    g1 = _tree(dev, 10)
+    shuffled = {"newline": g1["newline"], "ground": {"zero_target": g1["ground"]["zero_target"], "obj": dict(reversed(list(g1["ground"]["obj"].items())))},
+                "llm": {"lm_head": g1["llm"]["lm_head"], "norm": g1["llm"]["norm"], "layers": g1["llm"]["layers"]}}
+    pa = zero.step(shuffled)
+    plain.step(params_b, g1)
+    g2 = _tree(dev, 11)
+    del g2["llm"]["lm_head"]
+    pa = zero.step(g2)
+    g2_full = dict(g2, llm=dict(g2["llm"], lm_head=torch.zeros_like(params_b["llm"]["lm_head"])))
+    plain.step(params_b, g2_full)
+    la, lb = train._leaves(pa), train._leaves(params_b)
+    assert len(la) == len(lb) and all(torch.equal(x, y) for x, y in zip(la, lb))
+    with pytest.raises(train.V3DError):
+        zero.step(dict(g1, extra=g1["newline"]))
+    bad = _tree(dev, 12)
+    bad["llm"]["norm"] = bad["llm"]["norm"][:8]
+    with pytest.raises(train.V3DError):
+        zero.step(bad)
+    # a leaf written through grad_views() is taken in place
+    gv = zero.grad_views()
+    gv["newline"].copy_(g1["newline"])
+    assert zero._flatten_grads(dict(g1, newline=gv["newline"])) is zero.flat_g

@@ -290,6 +290,17 @@ def test_embed_grad_sums_repeated_tokens(ops):
     dE = torch.zeros(V, H, dtype=torch.bfloat16, device="cuda")
     ops.embed_grad(dh.cuda(), rows.cuda(), ids.cuda(), dE)
     assert torch.equal(dE.cpu(), ref)                      # f32 sums of at most three 16-bit rows, one rounding: exact against index_add_
+    # ids outside the table (IMAGE_TOKEN_INDEX = -200 of a raw prompt, ids >= vocab) and rows outside dh are skipped, not dereferenced
+    # (ADVICE r2): the rows of dE around the table stay as they were
+    ids_raw = torch.tensor([7, -200, 7, 7, 49, V, 3, 12])
+    rows_raw = torch.tensor([0, 1, 2, 30, 31, 32, 33, S + 5])
+    keep = (ids_raw >= 0) & (ids_raw < V) & (rows_raw < S)
+    ref2 = torch.zeros(V, H).index_add_(0, ids_raw[keep], dh[rows_raw[keep]].float()).to(torch.bfloat16)
+    big = torch.full((V + 2, H), 7.0, dtype=torch.bfloat16, device="cuda")
+    dE2 = big[1:V + 1]
+    dE2.zero_()
+    ops.embed_grad(dh.cuda(), rows_raw.cuda(), ids_raw.cuda(), dE2)
+    assert torch.equal(dE2.cpu(), ref2) and bool((big[0] == 7).all()) and bool((big[V + 1] == 7).all())
 
 
 def test_llm_step_loss_and_gradients_match_autograd(ops, train):

@@ -34,6 +34,7 @@ def _sample(rank, device):
 
 
 def _worker(rank, world, port, out_dir):
+    os.environ["V3D_GEMM_STREAMK"] = "0"      # two PROCESSES on one card: the split-K tail's exchange assumes one tail launch on the chip
     import torch.distributed as dist
     from v3d import train
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

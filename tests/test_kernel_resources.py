@@ -50,12 +50,46 @@ def test_gemm_kernels_without_the_split_k_exchange_do_not_spill(reports):
     assert all(v == 0 for v in reports["gemm_fp8.hip"].values()), reports["gemm_fp8.hip"]
 
 
+def _inner_loop_spills(asm_text, kernel_substr):
+    """scratch (= spill) instructions inside the first innermost loop (the steady-state tile loop) of the kernels whose mangled name contains kernel_substr, not counting
+    those between the `; V3D_RARE_BEGIN` / `; V3D_RARE_END` markers the source puts around its rarely executed blocks."""
+    bad, n_kernels = [], 0
+    for m in re.finditer(r"^(_ZN3v3d\S*%s\S*):[^\n]*\n(.*?)s_endpgm" % kernel_substr, asm_text, re.S | re.M):
+        n_kernels += 1
+        lines = m.group(2).split("\n")
+        in_loop, rare, seen = False, 0, 0
+        for i, ln in enumerate(lines):
+            if "Inner Loop Header" in ln:
+                seen += 1
+                if seen > 1:                 # only the FIRST inner loop is the steady-state tile loop (the second walks the last <= 3 tiles)
+                    break
+                in_loop = True
+                header = re.match(r"^(\.LBB\d+_\d+):", lines[i - 1] if not ln.startswith(".LBB") else ln)
+                label = header.group(1) if header else None
+            if "V3D_RARE_BEGIN" in ln:
+                rare += 1
+            if "V3D_RARE_END" in ln:
+                rare -= 1
+            if in_loop and rare == 0 and re.search(r"\bscratch_(load|store)", ln):
+                bad.append((m.group(1)[:60], i, ln.strip()))
+            if in_loop and label and re.search(r"s_c?branch\S*\s+%s\b" % re.escape(label), ln):
+                in_loop = False
+    return n_kernels, bad
+
+
 def test_attention_and_decode_kernels_do_not_spill_in_their_loops(reports):
     att = reports["attention.hip"]
-    train_fwd = {k: v for k, v in att.items() if "attn_prefill_kernel" in k and k.endswith("ELb1EEEvNS_8AttnArgsE")}      # LSE = true: v3d_attention_train
-    assert len(train_fwd) == 4 and all(v <= 5 for v in train_fwd.values()), train_fwd       # causal + non-causal, two dtypes: + the running maximum kept for the log-sum-exp
-    att = {k: v for k, v in att.items() if k not in train_fwd}
-    assert all(v <= 2 for v in att.values()), {k: v for k, v in att.items() if v > 2}       # two scalars outside the tile loop (prefill, D = 128)
+    # r03: the prefill kernel's rarely taken raise-of-the-maximum block (and code outside the tile loop) may spill; its steady-state
+    # tile loop must not - checked on the generated code below.  The totals stay bounded so that a regression is noticed.
+    prefill = {k: v for k, v in att.items() if "attn_prefill_kernel" in k}
+    assert prefill and all(v <= 24 for v in prefill.values()), prefill
+    att = {k: v for k, v in att.items() if k not in prefill}
     assert all(v == 0 for v in reports["attention_bwd.hip"].values()), reports["attention_bwd.hip"]
     assert all(v == 0 for k, v in att.items() if "attn_prefill64_kernel" in k)
+    assert all(v <= 2 for v in att.values()), att
     assert all(v == 0 for v in reports["decode.hip"].values()), reports["decode.hip"]
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-fno-slp-vectorize",
+                          "-Wno-inline-asm", "-S", "--cuda-device-only", os.path.join(CSRC, "attention.hip"), "-o", "-"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n, bad = _inner_loop_spills(out.stdout, "attn_prefill_kernel")
+    assert n >= 14 and not bad, bad[:10]

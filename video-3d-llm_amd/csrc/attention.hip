@@ -411,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       if (__any(ls0 + ls1 > AT_LS_LIMIT)) {     // wave-uniform, rare: some probability of tile t+1 may exceed 2^AT_RAISE
         // the scores were consumed in place by the exponentials: form them again (K of tile t+1 stays in its ring buffer until
         // the next step; same MFMA chain from the same -m, so the same bits), then decide per lane as the max-first form did
+        asm volatile("; V3D_RARE_BEGIN (tests/test_kernel_resources.py: register spills are tolerated only between these markers)");
         f32x16 s2[2];
         qk_fill(IntC<1 - PAR>{});
         qk_run(IntC<1 - PAR>{}, s2);
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
           l_run *= alpha;
         }
+        asm volatile("; V3D_RARE_END");
       }
       l_run += ls0 + ls1;
     }

@@ -1285,6 +1285,20 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
     }                                                                                                     \
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), PP_LDS_BYTES, st, p);                                    \
   }
+  // in the tail launch a chunk-0 workgroup waits (unbounded) for flags its partner chunks raise.  That is deadlock-free
+  // only while every workgroup of the launch becomes resident - true for ONE tail launch on the chip (grid <= one workgroup per CU),
+  // not for two that interleave their dispatch (two streams): waiting chunk-0 workgroups of both could fill an XCD whose
+  // writers then never start.  So tail launches of this process are CHAINED: each waits for the previous one's completion event,
+  // whatever stream it was on.  (Two PROCESSES sharing one card - the gloo rehearsals - run with V3D_GEMM_STREAMK=0.)
+  struct TailChain { std::mutex mu; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool recorded = false; };
+  static TailChain chain;
+  const bool is_tail = p.sk_dp >= 0;
+  std::unique_lock<std::mutex> tail_lock(chain.mu, std::defer_lock);
+  if (is_tail) {
+    tail_lock.lock();
+    if (!chain.done && hipEventCreateWithFlags(&chain.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); chain.done = nullptr; }
+    if (chain.done && chain.recorded && chain.last != st) (void)hipStreamWaitEvent(st, chain.done, 0);
+  }
 #define V3D_GEMM4_CASE(E)                                                                                 \
   case E: {                                                                                               \
     if constexpr (MT == 8) { if (p.sk_dp >= 0) V3D_GEMM4_LAUNCH(E, true) else V3D_GEMM4_LAUNCH(E, false) } \
@@ -1303,6 +1317,14 @@ static int launch_gemm256pp(GemmArgs p, int epi, hipStream_t st, int sk_allow = 
   }
 #undef V3D_GEMM4_CASE
 #undef V3D_GEMM4_LAUNCH
+  if (is_tail && chain.done) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone && hipEventRecord(chain.done, st) == hipSuccess) {
+      chain.recorded = true; chain.last = st;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   return check_launch("v3d_gemm (256-wide, ping-pong)");
 }
 

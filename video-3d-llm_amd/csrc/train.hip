@@ -475,15 +475,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p32, flo
 // workgroup per listed row, only the first occurrence of an id writes (n is the handful of text tokens of a sample).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_grad_kernel(const T* __restrict__ dh, int64_t ld, const int64_t* __restrict__ rows, const int64_t* __restrict__ ids,
-                                                         int n, int H, T* __restrict__ dE, int64_t lde) {
+                                                         int n, int H, T* __restrict__ dE, int64_t lde, int64_t n_rows, int64_t vocab) {
   const int i = blockIdx.x;
   const int64_t id = ids[i];
+  // ids outside [0, vocab) (IMAGE_TOKEN_INDEX = -200 of a raw prompt, ids >= the table's rows) and rows outside [0, n_rows) take no
+  // part: no write, no read (these used to be unchecked global accesses)
+  if (id < 0 || id >= vocab) return;
   for (int j = 0; j < i; ++j)
     if (ids[j] == id) return;                                        // an earlier workgroup owns this id (uniform branch)
   for (int c = threadIdx.x; c < H; c += 256) {
     float s = 0.f;
-    for (int j = i; j < n; ++j)
-      if (ids[j] == id) s += to_f32(dh[rows[j] * ld + c]);
+    for (int j = i; j < n; ++j) {
+      const int64_t r = rows[j];
+      if (ids[j] == id && r >= 0 && r < n_rows) s += to_f32(dh[r * ld + c]);
+    }
     dE[id * lde + c] = from_f32<T>(s);
   }
 }
@@ -918,11 +923,12 @@ extern "C" int v3d_adamw_step(float* p32, float* m, float* v, const void* grad, 
   return check_launch("v3d_adamw_step");
 }
 
-extern "C" int v3d_embed_grad(const void* dh, int64_t ld, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde, int dtype,
-                              void* stream) {
+extern "C" int v3d_embed_grad(const void* dh, int64_t ld, int64_t n_rows, const int64_t* rows, const int64_t* ids, int n, int H, void* dE, int64_t lde,
+                              int64_t vocab, int dtype, void* stream) {
   V3D_REQUIRE(dh && rows && ids && dE, "v3d_embed_grad: null pointer");
-  V3D_REQUIRE(n > 0 && n <= 65535 && H > 0 && ld >= H && lde >= H, "v3d_embed_grad: bad shape");
-  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(embed_grad_kernel<T>, dim3(n), dim3(256), 0, (hipStream_t)stream, (const T*)dh, ld, rows, ids, n, H, (T*)dE, lde));
+  V3D_REQUIRE(n > 0 && n <= 65535 && H > 0 && ld >= H && lde >= H && n_rows > 0 && vocab > 0, "v3d_embed_grad: bad shape");
+  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(embed_grad_kernel<T>, dim3(n), dim3(256), 0, (hipStream_t)stream, (const T*)dh, ld, rows, ids, n, H, (T*)dE, lde,
+                                              n_rows, vocab));
   return check_launch("v3d_embed_grad");
 }
 

@@ -108,6 +108,10 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
             if not tower_dir or not os.path.isdir(tower_dir):
                 raise V3DError(f"the checkpoint holds no vision tower and config.mm_vision_tower = {tower_dir!r} is not a local directory")
             sd.update(loader.drop_deleted_tower_layer(loader.read_tower_weights(tower_dir), True))
+        if "lm_head.weight" not in sd:                 # tie_word_embeddings checkpoints store the table once
+            if not getattr(config, "tie_word_embeddings", False):
+                raise V3DError("the checkpoint holds no lm_head.weight and config.tie_word_embeddings is not set")
+            sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
         vocab = getattr(config, "vocab_size", None)
         if vocab is not None and vocab != sd["lm_head.weight"].shape[0]:
             # overwrite_config={"vocab_size": ...} (model_scanqa.py:98) on a checkpoint whose tables are larger / smaller
@@ -123,14 +127,17 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
         return model.eval()
 
     def resize_token_embeddings(self, new_num_tokens=None, **kw):
-        """builder.py:275 always calls this with len(tokenizer).  Same size: nothing to do; fewer: the tables are cut (HF keeps
-        the first rows); more would need freshly initialised rows, which an inference checkpoint never needs - refused."""
-        l = self.engine.cfg.llm
+        """builder.py:287 always calls this with len(tokenizer).  Same size: nothing to do; fewer: the tables are cut (HF keeps the
+        first rows); more (builder.py:282-286 adds <im_patch> / <im_start> / <im_end> when the config asks for them): the embedding and
+        LM-head tables grow by rows set to the MEAN of the existing rows - transformers' own initialisation of resized embeddings
+        (mean_resizing) without its covariance noise, so the load is deterministic; an inference prompt never contains the new ids and a
+        mean row's logit cannot win an argmax."""
+        eng = self.engine
+        l = eng.cfg.llm
         if new_num_tokens is None or new_num_tokens == l.vocab:
             return self
         if new_num_tokens > l.vocab:
-            raise NotImplementedError(f"growing the vocabulary ({l.vocab} -> {new_num_tokens}) would add untrained rows; "
-                                      "save the checkpoint with its tokenizer's size")
+            eng.grow_vocab(int(new_num_tokens))
         l.vocab = int(new_num_tokens)
         self.config.vocab_size = int(new_num_tokens)
         return self

@@ -100,7 +100,7 @@ SIGNATURES = {
     "v3d_attention_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
                                      c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_i, c_f, c_p, c_l, c_p]),
     "v3d_adamw_step": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
-    "v3d_embed_grad": (c_i, [c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_i, c_p]),
+    "v3d_embed_grad": (c_i, [c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_l, c_l, c_i, c_p]),
     "v3d_gelu": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
     "v3d_gelu_grad": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
     "v3d_layernorm_grad": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_i, c_p]),

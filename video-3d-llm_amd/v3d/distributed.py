@@ -158,3 +158,16 @@ def all_gather_params(partition, numel, bucket_elems=ZERO2_BUCKET_ELEMS):
         for r in range(world):
             full[r * per + o: r * per + o + n] = parts[r]
     return full[:numel]
+
+
+def all_gather_params_into(flat, rank, per, bucket_elems=ZERO2_BUCKET_ELEMS):
+    """all_gather_params in place: `flat` [world * per] holds this rank's updated partition at [rank * per, (rank + 1) * per) and
+    receives every other rank's, bucket by bucket, without a second buffer of the model's size (ZeroAdamW's parameters are views of
+    `flat`)."""
+    world = dist.get_world_size()
+    chunk = max(1, min(per, bucket_elems // world))
+    for o in range(0, per, chunk):
+        n = min(chunk, per - o)
+        outs = [flat[r * per + o: r * per + o + n] for r in range(world)]
+        dist.all_gather(outs, outs[rank].clone() if world > 1 else outs[rank])
+    return flat

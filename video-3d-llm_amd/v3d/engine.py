@@ -236,6 +236,24 @@ class Engine:
         if self.llm_fp8:
             self.l_head8 = ops.quantize_fp8_rows(self.l_head)
 
+    def grow_vocab(self, n):
+        """resize_token_embeddings(n) with n > vocab (llava_qwen mirror): n - vocab rows equal to the mean of the existing rows are
+        appended to the embedding and LM-head tables; per-context logits buffers are re-made."""
+        l = self.cfg.llm
+        if n <= l.vocab:
+            return
+        add = n - l.vocab
+        emb = self.embed[: l.vocab]
+        self.embed = torch.cat([emb, emb.float().mean(0, keepdim=True).to(emb.dtype).expand(add, -1)], 0).contiguous()
+        head = self.l_head[: l.vocab]
+        self.l_head = _pad2(torch.cat([head, head.float().mean(0, keepdim=True).to(head.dtype).expand(add, -1)], 0), _up(n, 128), l.hidden)
+        if self.llm_fp8:
+            self.l_head8 = ops.quantize_fp8_rows(self.l_head)
+        l.vocab = n
+        for k in ("_group_ctxs", "_group_rows", "_answer_st"):
+            self.__dict__.pop(k, None)
+        self.ctx = self.new_context()
+
     # ------------------------------------------------------------------ workspaces
     def _alloc(self, max_frames):
         v, l = self.cfg.vit, self.cfg.llm

@@ -119,6 +119,12 @@ def load_pretrained_model(model_path, model_base=None, model_name=None, device_m
             setattr(cfg, k, v)
     model = LlavaQwenForCausalLM.from_pretrained(model_path, low_cpu_mem_usage=True, attn_implementation=attn_implementation, config=cfg,
                                                  device_map=device_map, torch_dtype=dt)
+    # builder.py:266-275: the image patch / start / end tokens join the tokenizer before the tables are resized to len(tokenizer)
+    # (mm_use_im_patch_token defaults to True upstream) - mirrored so that both loaders see the same vocabulary size
+    if getattr(model.config, "mm_use_im_patch_token", True):
+        tokenizer.add_tokens(["<im_patch>"], special_tokens=True)
+    if getattr(model.config, "mm_use_im_start_end", False):
+        tokenizer.add_tokens(["<im_start>", "<im_end>"], special_tokens=True)
     model.resize_token_embeddings(len(tokenizer))
     tower = model.get_vision_tower()
     if not tower.is_loaded:

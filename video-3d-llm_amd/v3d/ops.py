@@ -908,12 +908,13 @@ def adamw_step(p32, m, v, grad, p16=None, lr=1e-5, betas=(0.9, 0.999), eps=1e-8,
 
 
 def embed_grad(dh, rows, ids, dE):
-    """dE[ids[i]] = sum of dh[rows[j]] over the j with the same id (text rows of a sample); dE [vocab, H] pre-zeroed by the caller."""
+    """dE[ids[i]] = sum of dh[rows[j]] over the j with the same id (text rows of a sample); dE [vocab, H] pre-zeroed by the caller.
+    ids outside [0, vocab) (e.g. IMAGE_TOKEN_INDEX of a raw prompt) and rows outside dh are skipped."""
     dh = _dev(dh, "dh")
     if rows.dtype != torch.int64 or ids.dtype != torch.int64 or rows.numel() != ids.numel() or not rows.is_cuda or not ids.is_cuda:
         raise V3DError("embed_grad: rows / ids must be device int64 tensors of one length")
-    check(lib().v3d_embed_grad(_p(dh), dh.stride(0), _p(rows), _p(ids), rows.numel(), dh.shape[1], _p(dE), dE.stride(0), _code(dh), _stream()),
-          "v3d_embed_grad")
+    check(lib().v3d_embed_grad(_p(dh), dh.stride(0), dh.shape[0], _p(rows), _p(ids), rows.numel(), dh.shape[1], _p(dE), dE.stride(0), dE.shape[0],
+                               _code(dh), _stream()), "v3d_embed_grad")
     return dE
 
 

@@ -26,6 +26,7 @@ import math
 import torch
 
 from . import ops
+from ._native import V3DError
 
 
 def _pad64(n):
@@ -480,13 +481,66 @@ class ZeroAdamW:
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
 
+    def _flatten_grads(self, grads):
+        """grads -> self.flat_g, walking the PARAMETER tree by key: a leaf the sample has no gradient for (the LM head of a
+        grounding sample, the grounding heads of a QA sample) contributes zeros; a gradient for an unknown key, or of another shape than
+        its parameter, raises; the order of the gradient dict's keys plays no part.  A leaf that already IS its slice of the flat buffer
+        (the backward wrote it through grad_views()) is not copied."""
+        if getattr(self, "flat_g", None) is None:
+            self.flat_g = torch.zeros(self.per * self.world, dtype=self.flat.dtype, device=self.flat.device)
+        views = iter(self._g_views())
+        seen = [0]
+
+        def walk(p, g, path):
+            if isinstance(p, dict):
+                if g is not None:
+                    if not isinstance(g, dict):
+                        raise V3DError(f"ZeroAdamW: gradient at {path or '<root>'} is not a dict like its parameters")
+                    extra = set(g) - set(p)
+                    if extra:
+                        raise V3DError(f"ZeroAdamW: gradient keys {sorted(extra)} at {path or '<root>'} have no parameter")
+                for k in p:
+                    walk(p[k], None if g is None else g.get(k), f"{path}.{k}" if path else str(k))
+            elif isinstance(p, list):
+                if g is not None and (not isinstance(g, list) or len(g) != len(p)):
+                    raise V3DError(f"ZeroAdamW: gradient list at {path} does not match its {len(p)} parameters")
+                for i, x in enumerate(p):
+                    walk(x, None if g is None else g[i], f"{path}[{i}]")
+            else:
+                v = next(views)
+                if g is None:
+                    v.zero_()
+                else:
+                    if tuple(g.shape) != tuple(p.shape):
+                        raise V3DError(f"ZeroAdamW: gradient of {path} has shape {tuple(g.shape)}, its parameter {tuple(p.shape)}")
+                    if g.data_ptr() != v.data_ptr():
+                        v.copy_(g)
+                seen[0] += p.numel()
+
+        walk(self.params, grads, "")
+        if seen[0] != self.numel:
+            raise V3DError(f"ZeroAdamW: flattened {seen[0]} gradient elements for {self.numel} parameters")
+        return self.flat_g
+
+    def _g_views(self):
+        if getattr(self, "_gv", None) is None:
+            if getattr(self, "flat_g", None) is None:
+                self.flat_g = torch.zeros(self.per * self.world, dtype=self.flat.dtype, device=self.flat.device)
+            off, self._gv = 0, []
+            for v in self.views:
+                self._gv.append(self.flat_g[off:off + v.numel()].view(v.shape))
+                off += v.numel()
+        return self._gv
+
+    def grad_views(self):
+        """The parameter tree over views of the flat GRADIENT buffer: a backward that writes its gradients there (out=...) spares
+        step() the copy of that leaf."""
+        it = iter(self._g_views())
+        return _tree_map(lambda _: next(it), self.params)
+
     def step(self, grads, grad_scale=1.0):
         self.t += 1
-        flat_g = torch.zeros(self.per * self.world, dtype=self.flat.dtype, device=self.flat.device)
-        off = 0
-        for g in _leaves(grads):
-            flat_g[off:off + g.numel()].copy_(g.reshape(-1))
-            off += g.numel()
+        flat_g = self._flatten_grads(grads)
         if self.host_staged:
             part = self.D.reduce_scatter_grads(flat_g.cpu(), self.bucket, average=True, algorithm=self.algorithm).to(self.flat.device)
         else:
@@ -495,9 +549,9 @@ class ZeroAdamW:
                        weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale)
         if self.host_staged:
             full = self.D.all_gather_params(self.mine.cpu(), self.per * self.world, self.bucket).to(self.flat.device)
+            self.flat.copy_(full)
         else:
-            full = self.D.all_gather_params(self.mine, self.per * self.world, self.bucket)
-        self.flat.copy_(full)
+            self.D.all_gather_params_into(self.flat, self.rank, self.per, self.bucket)      # in place: no second copy of the model
         return self.params
 
 
