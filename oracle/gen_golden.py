@@ -543,6 +543,58 @@ def g_rgb_resize():
          big_out_rowsum=big_out.astype(np.int64).sum((2, 3)), small=small, small_out=small_out)
 
 
+def g_chatml():
+    """The eval drivers' prompt builder `preprocess_qwen` - model_scanqa.py:29-80 (ids only) and model_scanrefer.py:28-80 (ids + training
+    targets) - executed from the drivers' own source text (read at run time; the modules themselves import ray / fasteners, absent here)
+    on a stand-in word-level tokenizer with the ChatML specials (no Qwen2 tokenizer ships with the reference): pins the STRUCTURE of the
+    id / label sequences the runners build (v3d.eval_scanqa.chatml_ids, v3d.eval_3d.chatml_ids_labels)."""
+    import ast
+    import re as _re
+    from typing import Dict
+    import transformers
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    names = {300: "system", 301: "user", 302: "assistant", 303: "\n", 304: "You", 305: "are", 306: "a", 307: "helpful",
+             308: "assistant.", 309: "<|im_start|>", 310: "<|im_end|>"}
+    vocab = {names.get(i, f"t{i}"): i for i in range(320)}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="t0"))
+    tk.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split("\n", "isolated"), pre_tokenizers.Split(" ", "removed")])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, eos_token="<|im_end|>", pad_token="t0", unk_token="t0",
+                                   additional_special_tokens=["<|im_start|>", "<|im_end|>"])
+
+    class Tok:                                   # the attribute the drivers read (:32), dropped by newer transformers
+        additional_special_tokens_ids = [309, 310]
+
+        def __call__(self, s):
+            return fast(s)
+
+    def load(path):
+        src = open(os.path.join(REF, path)).read()
+        fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "preprocess_qwen")
+        env = {"transformers": transformers, "Dict": Dict, "torch": torch, "re": _re, "IGNORE_INDEX": -100, "IMAGE_TOKEN_INDEX": -200,
+               "DEFAULT_IMAGE_TOKEN": "<image>"}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), env)
+        return env["preprocess_qwen"]
+
+    qa, vg = load("llava/eval/model_scanqa.py"), load("llava/eval/model_scanrefer.py")
+    cases = [
+        [{"from": "human", "value": "<image>\nt1 t2 t3"}, {"from": "gpt", "value": None}],
+        [{"from": "human", "value": "<image>\nt5 t317 t6 t7"}, {"from": "gpt", "value": None}],
+        [{"from": "gpt", "value": "t9"}, {"from": "human", "value": "t4"}, {"from": "gpt", "value": "t5 t6"}],
+    ]
+    vg_cases = [
+        [{"from": "human", "value": "<image>\nt11 t12 t13 t14"}, {"from": "gpt", "value": "t318"}],
+        [{"from": "human", "value": "<image>\nt21"}, {"from": "gpt", "value": "t30 t318 t31"}],
+    ]
+    out = {"qa": [{"turns": c, "ids": qa(c, Tok(), has_image=True)[0].tolist()} for c in cases], "vg": []}
+    for c in vg_cases:
+        ids, labels = vg(c, Tok(), has_image=True)
+        out["vg"].append({"turns": c, "ids": ids[0].tolist(), "labels": labels[0].tolist()})
+    with open(os.path.join(OUT, "chatml.json"), "w") as f:
+        json.dump(out, f)
+    print("  wrote chatml.json")
+
+
 def _bits(t):
     """bf16-representable f32 tensor -> raw bf16 bits (uint16), the compact storage form of the tiny-model weights."""
     b = t.detach().to(torch.bfloat16)

@@ -125,3 +125,35 @@ def test_scene_sharding_partition_properties():
                     assert all((keys[i] != s_) or (i in p) for i in range(len(keys)))     # whole scenes
             biggest = max(keys.count(k) for k in set(keys))
             assert max(len(p) for p in parts) <= len(keys) / world + biggest          # balanced up to one scene
+
+
+def test_prompt_ids_and_labels_equal_the_drivers_own_preprocess_qwen(tmp_path):
+    """tests/golden/chatml.json: `preprocess_qwen` of model_scanqa.py:29-80 and model_scanrefer.py:28-80, executed from the drivers' own
+    source on the stand-in tokenizer (oracle/gen_golden.py g_chatml).  The runners' restatements give the same ids / labels - the
+    tokenizer-DEPENDENT ids stay unpinned (no Qwen2 tokenizer ships with the reference), the structure no longer is."""
+    from transformers import AutoTokenizer
+    from v3d import eval_3d as E3
+    tok = AutoTokenizer.from_pretrained(TM.write_checkpoint(str(tmp_path / "ckpt"), TM.load()))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chatml.json")))
+    for case in g["qa"]:
+        assert E.chatml_ids(case["turns"], tok)[0].tolist() == case["ids"]
+    for case in g["vg"]:
+        ids, labels = E3.chatml_ids_labels(case["turns"], tok)
+        assert ids[0].tolist() == case["ids"] and labels[0].tolist() == case["labels"]
+        assert E.chatml_ids(case["turns"], tok)[0].tolist() == case["ids"]
+
+
+def test_grounding_records_follow_the_drivers():
+    """model_scanrefer.py:174-189 (arg-max box; the zero-target falls back to the best real box) and model_multi3drefer.py:171-181."""
+    from v3d import eval_3d as E3
+    line = {"id": "r0", "video": "scannet/scene0000_00", "box": [1, 2, 3, 4, 5, 6], "conversations": [{"from": "human", "value": "<image>\nt1"}, {"from": "gpt", "value": "t318"}],
+            "metadata": {"dataset": "scanrefer", "question_type": "unique"}}
+    objects = torch.tensor([[0.1, 0.2, 0.3, 1, 1, 1], [1.0, 2.0, 3.0, 0.5, 0.5, 0.5], [3, 3, 3, 2, 2, 2]]).to(torch.float16)
+    r = E3.ground_record("scanrefer", line, torch.tensor([0.1, 0.9, 0.3, 0.2]), objects, "m")
+    assert list(r) == ["dataset", "sample_id", "prompt", "pred_response", "gt_response", "model_id", "question_type"]
+    assert r["pred_response"] == objects[1].tolist() and r["gt_response"] == [1, 2, 3, 4, 5, 6]
+    r = E3.ground_record("scanrefer", line, torch.tensor([0.1, 0.2, 0.3, 0.9]), objects, "m")             # the zero-target wins
+    assert r["pred_response"] == objects[2].tolist()
+    m = E3.ground_record("multi3drefer", line, torch.tensor([0.5, 0.25, 0.125, 0.0]), objects, "m")
+    assert list(m) == ["dataset", "sample_id", "prompt", "scores", "objects", "gt_response", "model_id", "question_type"]
+    assert m["scores"] == [0.5, 0.25, 0.125, 0.0] and m["objects"] == objects.tolist()

@@ -44,7 +44,7 @@ def _dataset(root):
             pickle.dump({"data_list": data_list if split == "val" else []}, f)
     for name in ("scannet_train_gt_box.json", "scannet_val_pred_box.json"):
         with open(os.path.join(root, "metadata", name), "w") as f:
-            json.dump({sid: [[0, 0, 0, 1, 1, 1]] for sid in scenes}, f)
+            json.dump({sid: [[0, 0, 0, 1, 1, 1], [0.5, -0.25, 0.75, 2, 1, 1.5], [-1, 1, 0.25, 0.5, 0.5, 2]] for sid in scenes}, f)
     qs = []
     for i in range(7):                                 # 4 questions on scene 0, 3 on scene 1, of different lengths
         words = " ".join(f"t{(11 * i + k) % 290 + 1}" for k in range(3 + 2 * (i % 3)))
@@ -96,3 +96,71 @@ def test_eval_runner_end_to_end(tmp_path):
     before = open(os.path.join(root, "out", "plain.jsonl")).read()
     assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl")]) == 0
     assert open(os.path.join(root, "out", "plain.jsonl")).read() == before
+
+
+def _argv(root, ckpt, qfile, out, *extra):
+    return ["--model-path", ckpt, "--video-folder", root, "--embodiedscan-folder", os.path.join(root, "embodiedscan"),
+            "--metadata-folder", os.path.join(root, "metadata"), "--question-file", os.path.join(root, qfile),
+            "--max_frame_num", "4", "--max-new-tokens", "5", "--answer-file", os.path.join(root, "out", out), *extra]
+
+
+def test_runners_for_the_other_3d_drivers(tmp_path):
+    """v3d.eval_3d on the synthetic on-disk dataset: Scan2Cap (box_input -> PE on the <coord> rows, `scene` key, annotations as gt, a
+    question without a box is answered "" without a run: model_scan2cap.py:129-212), SQA3D (= the ScanQA contract, model_sqa3d.py),
+    ScanRefer / Multi3DRefer (one prefill with object proposals -> scores: model_scanrefer.py:130-195, model_multi3drefer.py:163-181) -
+    each against the loaded model called directly the way its driver calls it."""
+    from v3d import eval_3d as E3, eval_scanqa as E
+    from llava.video_utils import VideoProcessor, merge_video_dict
+    root = str(tmp_path)
+    qs = _dataset(root)
+    ckpt = TM.write_checkpoint(os.path.join(root, "llava_qwen_tiny"), TM.load())
+    # ---- Scan2Cap
+    caps = []
+    for i, q in enumerate(qs[:5]):
+        c = dict(q, id=f"c{i}", box_input=None if i == 2 else [0.3 * i, -0.2 * i, 0.5, 1, 1, 1], annotations=[f"t{50 + i}", f"t{60 + i}"])
+        c["conversations"] = [{"from": "human", "value": q["conversations"][0]["value"] + " t317 t9"}, q["conversations"][1]]
+        caps.append(c)
+    json.dump(caps, open(os.path.join(root, "caps.json"), "w"))
+    assert E3.main(_argv(root, ckpt, "caps.json", "cap_pipe.jsonl", "--task", "scan2cap", "--decode-group", "2", "--loader-workers", "2")) == 0
+    assert E3.main(_argv(root, ckpt, "caps.json", "cap_plain.jsonl", "--task", "scan2cap", "--no-pipeline")) == 0
+    pipe = [json.loads(l) for l in open(os.path.join(root, "out", "cap_pipe.jsonl"))]
+    plain = [json.loads(l) for l in open(os.path.join(root, "out", "cap_plain.jsonl"))]
+    for recs in (pipe, plain):
+        assert [r["sample_id"] for r in recs] == [c["id"] for c in caps]
+        assert all(list(r) == ["dataset", "sample_id", "prompt", "pred_response", "gt_response", "model_id", "question_type", "scene"] for r in recs)
+        assert recs[2]["pred_response"] == "" and all(r["gt_response"] == c["annotations"] and r["scene"] == c["video"] for r, c in zip(recs, caps))
+    assert sum(a["pred_response"] == b["pred_response"] for a, b in zip(pipe, plain)) >= 4
+    tokenizer, model, image_processor, name = E.load_model(ckpt)
+    vp = VideoProcessor(video_folder=root, annotation_dir=os.path.join(root, "embodiedscan"), metadata_dir=os.path.join(root, "metadata"))
+    c = caps[1]
+    ids = E.build_prompt_ids(c, tokenizer).cuda()
+    assert int((ids == 317).sum()) == 1                                             # the <coord> token is in the prompt
+    images, vd = E._video_inputs(vp, image_processor, c["video"], model, 4, box_input=c["box_input"][:3])
+    with_box = model.generate(ids, images=images, modalities="video", do_sample=False, num_beams=1, max_new_tokens=5, use_cache=True, video_dict=vd)
+    assert E.clean_answer(tokenizer.batch_decode(with_box, skip_special_tokens=True)[0]) == plain[1]["pred_response"]
+    # ---- SQA3D: the ScanQA contract under its own task name
+    assert E3.main(_argv(root, ckpt, "questions.json", "sqa.jsonl", "--task", "sqa3d", "--loader-workers", "-1")) == 0
+    sqa = [json.loads(l) for l in open(os.path.join(root, "out", "sqa.jsonl"))]
+    assert [r["sample_id"] for r in sqa] == [q["id"] for q in qs] and all(len(r) == 7 for r in sqa)
+    # ---- ScanRefer / Multi3DRefer
+    refs = [dict(q, id=f"r{i}", box=[0.1 * i, 0.2, 0.3, 1, 1, 1],
+                 conversations=[q["conversations"][0], {"from": "gpt", "value": "t318"}]) for i, q in enumerate(qs[:4])]
+    json.dump(refs, open(os.path.join(root, "refs.json"), "w"))
+    assert E3.main(_argv(root, ckpt, "refs.json", "refer.jsonl", "--task", "scanrefer", "--loader-workers", "2")) == 0
+    assert E3.main(_argv(root, ckpt, "refs.json", "multi.jsonl", "--task", "multi3drefer", "--loader-workers", "-1")) == 0
+    refer = [json.loads(l) for l in open(os.path.join(root, "out", "refer.jsonl"))]
+    multi = [json.loads(l) for l in open(os.path.join(root, "out", "multi.jsonl"))]
+    assert [r["sample_id"] for r in refer] == [r["id"] for r in refs] == [r["sample_id"] for r in multi]
+    for line, r, m in zip(refs, refer, multi):
+        ids, labels = E3.chatml_ids_labels([line["conversations"][0], line["conversations"][1]], tokenizer)
+        one = vp.process_3d_video(line["video"], image_processor, force_sample=True, frames_upbound=4)
+        vd = merge_video_dict([one])
+        images = vd.pop("images").half().to(model.device)                            # model_scanrefer.py:160-162
+        vd = {k: v.half().to(model.device) for k, v in vd.items()}
+        _, scores = model(ids.cuda(), images=images, modalities="video", video_dict=vd, labels=labels.cuda(), use_object_proposals=True, box_labels=None)
+        assert len(m["scores"]) == 4 and torch.allclose(torch.tensor(m["scores"]), scores.float().cpu(), atol=2e-3, rtol=0)
+        assert m["objects"] == vd["objects"][0].tolist() and m["gt_response"] == line["box"]
+        best = int(torch.argmax(scores))
+        if best == 3:
+            best = int(torch.argmax(scores[:-1]))
+        assert r["pred_response"] == vd["objects"][0][best].tolist() and r["gt_response"] == line["box"]

@@ -6,6 +6,8 @@ torch_dtype=float16), resize_token_embeddings, get_vision_tower().is_loaded / im
 itself does not exist on the GPU box, so the call sequence is restated here; tests/test_overlay_loader.py runs the real
 builder.py over the overlay in the build container.  The weights are those of tests/golden/tiny_model.npz, so generate /
 forward are compared with the REFERENCE model's own outputs."""
+import os
+
 import pytest
 import torch
 

@@ -88,9 +88,12 @@ def clean_answer(text, stop_str=STOP_STR):
     return text.strip()
 
 
-def _video_inputs(video_processor, image_processor, video_id, model, max_frame_num, force_sample=True):
+def _video_inputs(video_processor, image_processor, video_id, model, max_frame_num, force_sample=True, box_input=None):
     from llava.video_utils import merge_video_dict
-    vd = merge_video_dict([video_processor.process_3d_video(video_id, image_processor, force_sample=force_sample, frames_upbound=max_frame_num)])
+    one = video_processor.process_3d_video(video_id, image_processor, force_sample=force_sample, frames_upbound=max_frame_num)
+    if box_input is not None:
+        one["box_input"] = box_input                                                          # model_scan2cap.py:170
+    vd = merge_video_dict([one])
     images = vd.pop("images").to(device=model.device, dtype=model.dtype)                      # :163
     for k in vd:
         vd[k] = vd[k].to(device=model.device, dtype=model.dtype)                              # :164-165
@@ -128,34 +131,47 @@ def default_workers():
 
 
 def model_answer_fn(model, tokenizer, image_processor, video_processor, model_name, max_frame_num=32, max_new_tokens=512,
-                    reuse_scenes=False, times=None, pipeline=True, group_size=16, workers=None, stats=None, record_fn=None, pool=None):
+                    reuse_scenes=False, times=None, pipeline=True, group_size=16, workers=None, stats=None, record_fn=None, pool=None,
+                    box_input_fn=None, skip_fn=None):
     """The per-rank loop of model_scanqa.py:130-206 around `model` (the loader-produced LlavaQwenForCausalLM).
     pipeline (default): v3d.pipeline - asynchronous host loader, prefill / grouped-decode overlap, device-side stop test; the
     records are those of the one-question-at-a-time loop (`pipeline=False`, the reference's own order of operations) up to the
     f32 summation order of the decode linears (tests/test_gpu_eval_harness.py).  stats: dict that receives the host-stage seconds.
     pool: v3d.frame_io.make_pool(...) of decoding processes (make it BEFORE the process initialises the GPU); default: one per call;
-    workers = 0 decodes on the calling thread."""
+    workers = 0 decodes on the calling thread.
+    box_input_fn(line) -> [x, y, z] or None: the Scan2Cap prompt's box centre (model_scan2cap.py:137-139, 170; its PE is added to the
+    <coord> token rows); skip_fn(line) -> True: the question is not run and its answer is "" (:199-200)."""
     record_fn = record_fn or (lambda line, text: make_record(line, text, model_name))
+    coord_ids = getattr(getattr(model, "config", None), "coord_token_ids", None)
+
+    def with_skipped(lines, run):
+        """run(active lines) -> texts; skipped lines get the empty answer (model_scan2cap.py:199-200)."""
+        active = [l for l in lines if not (skip_fn and skip_fn(l))]
+        texts = iter(run(active))
+        return [record_fn(l, "" if (skip_fn and skip_fn(l)) else next(texts)) for l in lines]
 
     def decode(ids):
         return clean_answer(tokenizer.batch_decode(ids.view(1, -1), skip_special_tokens=True)[0])
 
     def one_by_one(lines):
-        out = []
-        for line in lines:
-            ids = build_prompt_ids(line, tokenizer).to(model.device)
-            if int((ids == IMAGE_TOKEN_INDEX).sum()) != 1:
-                raise ValueError("exactly one <image> placeholder per prompt (model_scanqa.py:61)")
-            images, vd = _video_inputs(video_processor, image_processor, line["video"], model, max_frame_num)
-            t0 = time.time()
-            with torch.inference_mode():
-                toks = model.generate(ids, images=images, modalities="video", do_sample=False, temperature=0.0, top_p=None, num_beams=1,
-                                      max_new_tokens=max_new_tokens, use_cache=True, video_dict=vd)
-            if times is not None:
-                torch.cuda.synchronize()
-                times.append(time.time() - t0)
-            out.append(record_fn(line, decode(toks[0])))
-        return out
+        def run(active):
+            out = []
+            for line in active:
+                ids = build_prompt_ids(line, tokenizer).to(model.device)
+                if int((ids == IMAGE_TOKEN_INDEX).sum()) != 1:
+                    raise ValueError("exactly one <image> placeholder per prompt (model_scanqa.py:61)")
+                images, vd = _video_inputs(video_processor, image_processor, line["video"], model, max_frame_num,
+                                           box_input=box_input_fn(line) if box_input_fn else None)
+                t0 = time.time()
+                with torch.inference_mode():
+                    toks = model.generate(ids, images=images, modalities="video", do_sample=False, temperature=0.0, top_p=None, num_beams=1,
+                                          max_new_tokens=max_new_tokens, use_cache=True, video_dict=vd)
+                if times is not None:
+                    torch.cuda.synchronize()
+                    times.append(time.time() - t0)
+                out.append(decode(toks[0]))
+            return out
+        return with_skipped(lines, run)
 
     def scene_batches(lines):
         """Consecutive questions of one scene: ONE scene prefill, answers in batches of up to 16 (Engine.answer_group)."""
@@ -183,7 +199,12 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
 
     def pipelined(lines):
         """v3d.pipeline.ScenePipeline over this rank's questions (module docstring there)."""
+        return with_skipped(lines, _pipelined_texts)
+
+    def _pipelined_texts(lines):
         from .pipeline import AsyncSceneLoader, ScenePipeline, SceneSample
+        if not lines:
+            return []
         eng = model.engine
         pipe = model.__dict__.get("_v3d_pipeline")
         if pipe is None or pipe.G != group_size:
@@ -204,7 +225,10 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
             for j, line in enumerate(lines):
                 raw, w = loader.get(j)
                 waited[0] += w
-                yield SceneSample(input_ids=prompts[j], raw=raw, key=line["video"])
+                box = box_input_fn(line) if box_input_fn else None
+                yield SceneSample(input_ids=prompts[j], raw=raw, key=line["video"],
+                                  box_input=None if box is None else torch.tensor([box], dtype=torch.float32),
+                                  extra={"coord_token_id": coord_ids[0]} if (box is not None and coord_ids) else {})
 
         n_vis = max_frame_num * eng.cfg.pool_out * (eng.cfg.pool_out + 1)
         room = eng.cfg.llm.max_pos - (max((len(p) for p in prompts), default=1) - 1 + n_vis) + 1
@@ -218,7 +242,7 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
         if stats is not None:
             stats.update({"host_thread_seconds": dict(loader.stage_seconds), "loader_wait_seconds": waited[0],
                           "upload_enqueue_seconds": pipe.upload_seconds, "questions": len(lines), "wall_seconds": time.time() - t0})
-        return [record_fn(l, decode(t)) for l, t in zip(lines, toks)]
+        return [decode(t) for t in toks]
 
     if reuse_scenes:
         return scene_batches
