@@ -344,6 +344,19 @@ def measure_train_step(dev, steps=2, answer_tokens=64):
     S = TEXT_PRE + FRAMES * 210 + TEXT_POST
     labels = torch.full((S,), -100, dtype=torch.int64, device=dev)
     labels[S - answer_tokens:] = torch.randint(0, V, (answer_tokens,), device=dev)
+    # the same step with activation re-computation per layer (the reference trains with gradient checkpointing, train_multi.sh:72): memory and time
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    rc_ms = []
+    for i in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, grads = train.sample_forward_backward(params, patches, ids, table, pre_ids, post_ids, labels, rope, FRAMES, n_q, n_kv, hd, recompute=True)
+        torch.cuda.synchronize()
+        rc_ms.append((time.perf_counter() - t0) * 1e3)
+        del grads
+    rc_peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    torch.cuda.reset_peak_memory_stats()
     fb, ad, first_loss = [], [], None
     for i in range(steps + 1):
         torch.cuda.synchronize()
@@ -372,7 +385,9 @@ def measure_train_step(dev, steps=2, answer_tokens=64):
                     "all of it, AdamW on every parameter; random-init bf16 weights, f32 master weights / moments, all activations kept" % (FRAMES, S, answer_tokens),
             "value": 1e3 / ms, "unit": "samples/s", "ms_per_step": ms, "ms_forward_backward": sum(fb) / len(fb) * 1e3, "ms_adamw": sum(ad) / len(ad) * 1e3,
             "llm_tokens_per_s": S / (ms * 1e-3), "model_tflops": flops / (ms * 1e-3) / 1e12, "mfma_peak_tflops": 2500.0, "first_loss": first_loss,
-            "params": n_llm + n_vit + n_proj + V * H + H, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
+            "params": n_llm + n_vit + n_proj + V * H + H, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "recompute": {"what": "forward + backward with per-layer activation re-computation (gradient checkpointing as train_multi.sh:72; gradients bit-identical)",
+                          "ms_forward_backward": rc_ms[-1], "peak_mem_gb": rc_peak}}
 
 
 def main():

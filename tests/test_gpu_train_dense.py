@@ -458,12 +458,16 @@ def test_siglip_layer_forward_and_backward_match_autograd(train):
         _close(real[k], leaves[k].grad, 1.5e-2, 4e-2, "d " + k)
 
 
-def test_whole_sample_step_matches_autograd(ops, train):
-    """SigLIP tower (2 layers at true width, 2 frames) -> mm_projector -> pool + 3-D PE + newline, spliced between text rows -> a 2-layer
-    Qwen2 with labels: loss and the gradient of EVERY parameter group against autograd over the reference's composition in f32
-    (llava_qwen.py:121-205, llava_arch.py:191-210, 307-328, 506-517, 650-836)."""
+@pytest.mark.parametrize("shape", ["narrow-2+2", "true-width-1+1"])
+def test_whole_sample_step_matches_autograd(ops, train, shape):
+    """SigLIP tower (true width, 2 frames) -> mm_projector -> pool + 3-D PE + newline, spliced between text rows -> Qwen2 with labels:
+    loss and the gradient of EVERY parameter group against autograd over the reference's composition in f32
+    (llava_qwen.py:121-205, llava_arch.py:191-210, 307-328, 506-517, 650-836).  "narrow-2+2": 2 SigLIP layers + a 2-layer Qwen2 at
+    hidden 768; "true-width-1+1" (r03): ONE SigLIP layer + ONE Qwen2-7B layer at 3584 / 28 + 4 heads x 128 / 18944 - the widths, tile
+    shapes and GQA ratio of the measured configs[4] step."""
     frames, tokens, Hv, heads, inter, kpad = 2, 729, 1152, 16, 4304, 640
-    H, I, n_q, n_kv, hd, V, L = 768, 1024, 4, 2, 128, 1024, 2
+    H, I, n_q, n_kv, hd, V, L = (768, 1024, 4, 2, 128, 1024, 2) if shape == "narrow-2+2" else (3584, 18944, 28, 4, 128, 1024, 1)
+    n_vit = 2 if shape == "narrow-2+2" else 1
     g = torch.Generator().manual_seed(77)
     mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)
     ln = lambda n_: (1 + 0.1 * torch.randn(n_, generator=g)).to(torch.bfloat16)
@@ -474,7 +478,7 @@ def test_whole_sample_step_matches_autograd(ops, train):
                 "v_w": mk(Hv, Hv, s=Hv ** -0.5), "v_b": mk(Hv, s=0.2), "o_w": mk(Hv, Hv, s=Hv ** -0.5), "o_b": mk(Hv, s=0.2),
                 "fc1_w": mk(inter, Hv, s=Hv ** -0.5), "fc1_b": mk(inter, s=0.2), "fc2_w": mk(Hv, inter, s=inter ** -0.5), "fc2_b": mk(Hv, s=0.2)}
 
-    vit = [vit_layer() for _ in range(2)]
+    vit = [vit_layer() for _ in range(n_vit)]
     patch_w, patch_b, pos = mk(Hv, kpad, s=588 ** -0.5), mk(Hv, s=0.1), mk(tokens, Hv, s=0.5)
     patch_w[:, 588:] = 0                                                     # the k padding of the patch convolution's GEMM
     proj = {"w1": mk(H, Hv, s=Hv ** -0.5), "b1": mk(H, s=0.1), "w2": mk(H, H, s=H ** -0.5), "b2": mk(H, s=0.1)}
@@ -505,6 +509,24 @@ def test_whole_sample_step_matches_autograd(ops, train):
     loss, grads = train.sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), labels.cuda(), rope,
                                                 frames, n_q, n_kv, hd, coord_rows=coord_rows.cuda(), coord_pe=coord_pe.cuda())
 
+    # activation re-computation (the reference's gradient checkpointing, train_multi.sh:72): the same loss and gradients, bit for bit
+    torch.cuda.reset_peak_memory_stats()
+    base_mem = torch.cuda.memory_allocated()
+    loss_r, grads_r = train.sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), labels.cuda(), rope,
+                                                    frames, n_q, n_kv, hd, coord_rows=coord_rows.cuda(), coord_pe=coord_pe.cuda(), recompute=True)
+    peak_r = torch.cuda.max_memory_allocated() - base_mem
+    assert float(loss_r) == float(loss)
+    for a_, b_ in zip(train._leaves(grads_r), train._leaves(grads)):
+        assert torch.equal(a_, b_)
+    del grads_r
+    torch.cuda.reset_peak_memory_stats()
+    base_mem = torch.cuda.memory_allocated()
+    _l, _g = train.sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), labels.cuda(), rope,
+                                           frames, n_q, n_kv, hd, coord_rows=coord_rows.cuda(), coord_pe=coord_pe.cuda())
+    peak_k = torch.cuda.max_memory_allocated() - base_mem
+    del _l, _g
+    assert peak_r < peak_k, (peak_r, peak_k)
+
     # ---- reference (f32 autograd over the same 16-bit parameters)
     f32 = lambda t: train._tree_map(lambda a: a.float().requires_grad_(), t)
     r_vit, r_proj, r_llm = f32(vit), f32(proj), f32(llm)
@@ -534,7 +556,7 @@ def test_whole_sample_step_matches_autograd(ops, train):
     _close(grads["vision"]["pos"], r_pos.grad, *tol, "d position embedding")
     _close(grads["vision"]["patch_w"][:, :588], r_pw.grad[:, :588], *tol, "d patch weight")
     _close(grads["vision"]["patch_b"], r_pb.grad, *tol, "d patch bias")
-    for i in range(2):
+    for i in range(n_vit):
         real = train.siglip_unpad_grads(grads["vision"]["layers"][i])
         for k in vit[i]:
             if k == "k_b":

@@ -93,3 +93,33 @@ def test_true_width_layers_two_frames(dt, tol):
 def test_true_width_layers_full_sequence_bf16():
     """BASELINE configs[1] shape: 32 frames, S = 14 + 6720 + 60 = 6794."""
     _run(torch.bfloat16, 2e-2, F_=32, n_pre=14, n_post=60, max_pos=8192)
+
+
+def test_true_width_grounding_full_size_bf16():
+    """BASELINE configs[2] at its full size on one GPU (r03): Engine.ground_scores with 32 frames and 50 object
+    proposals through ONE true-width SigLIP layer + ONE true-width Qwen2 layer against oracle/pipeline_oracle.scene_ground
+    (llava_arch.py:351-376, 479-501; llava_qwen.py:280-300): patch masks bit for bit, object features per row, cosine scores."""
+    from v3d import ops
+    from v3d.engine import Engine, random_state_dict
+    dt, tol, F_ = torch.bfloat16, 2e-2, 32
+    cfg = true_cfg(8192)
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=31, std=0.02, ground_head=True)
+    eng = Engine(cfg, sd, dtype=dt, device="cuda", max_frames=F_)
+    g = torch.Generator().manual_seed(32)
+    images = torch.randn(F_, 3, 384, 384, generator=g)
+    coords = ((torch.rand(F_, 48, 1, 48, 1, 3, generator=g) - 0.5).expand(F_, 48, 8, 48, 8, 3).reshape(F_, 384, 384, 3) * torch.tensor([8.0, 8.0, 3.0])).contiguous()
+    boxes = torch.cat([(torch.rand(50, 3, generator=g) - 0.5) * torch.tensor([6.0, 6.0, 2.0]), torch.rand(50, 3, generator=g) * 4 + 0.5], 1)
+    t = torch.randint(0, 1024, (74,), generator=g)
+    input_ids = torch.cat([t[:14], torch.tensor([PO.IMAGE_TOKEN_INDEX]), t[14:]])
+    gidx = 14 + 1 + 40                                     # the <ground> label position, after the image token
+    ocfg = dict(OCFG, vit_layers=1, vit_heads=16)
+    want = PO.scene_ground(sd, ocfg, input_ids, gidx, images, coords, boxes, dt)
+    got = eng.ground_scores(input_ids, gidx, images.cuda(), coords.cuda(), boxes)
+    m = ops.object_patch_mask(coords.to(dt).cuda(), boxes.to(dt).cuda())
+    assert np.array_equal(m.cpu().numpy().astype(bool), want["masks"].numpy())
+    assert int(want["masks"].reshape(50, -1).any(1).sum()) >= 25            # the proposals do select patches
+    feats = eng.feat[: F_ * 729].view(F_, 729, -1)
+    objf = eng.object_features(feats, coords.to(dt).cuda(), boxes.to(dt).cuda())
+    assert rel_err(objf, want["objf"]) < tol and row_err(objf, want["objf"]) < 4 * tol
+    assert got.shape == (51,)
+    assert (got.float().cpu() - want["scores"].float()).abs().max().item() < tol      # cosine scores in [-1, 1]: absolute

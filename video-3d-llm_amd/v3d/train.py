@@ -176,14 +176,15 @@ def decoder_layer_backward(dout, saved, p, rope, n_q, n_kv, hd, eps=1e-6, materi
 # ------------------------------------------------------------------------------ the language model's step
 
 
-def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6):
+def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6, recompute=False):
     """Qwen2ForCausalLM.forward with labels (modeling_qwen2.py:1145-1217: decoder layers, final norm, LM head, shifted cross-entropy)
     and its backward for one sequence given as inputs_embeds x [S, H] (what prepare_inputs_labels_for_multimodal hands the LLM,
     llava_qwen.py:121-170).  params: {"layers": [layer dicts of decoder_layer_forward], "norm": [H], "lm_head": [V, H]}; labels [S]
     int64 on the device (-100 = ignored).  Returns (loss (f32 scalar tensor), dx [S, H], grads in params' structure).  All layers'
-    activations are kept (about 1 GB per 7B layer at S = 6.8 k: 28 GB of the 288), where the reference re-computes them under
-    gradient checkpointing (train_multi.sh:72) - same numbers, less work."""
-    h, saved = llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps)
+    activations are kept by default (about 1 GB per 7B layer at S = 6.8 k: 28 GB of the 288); recompute=True keeps only the layers'
+    inputs and runs each layer's forward again in the backward, as the reference does under gradient checkpointing
+    (train_multi.sh:72) - same numbers, a third more work, 27 GB less."""
+    h, saved = llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps, recompute)
     n = ops.rmsnorm(h, params["norm"], eps)
     logits = ops.gemm(n, params["lm_head"])
     loss, st = ops.cross_entropy(logits, labels)
@@ -194,21 +195,34 @@ def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6):
     return loss, dx, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
 
 
-def llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps=1e-6):
+class _LayerInput:
+    """What a layer keeps under activation re-computation (the reference's gradient checkpointing, train_multi.sh:72 ->
+    gradient_checkpointing True): only its input; the backward runs the layer's forward again to regenerate the rest.  The kernels
+    are deterministic, so the regenerated activations - and therefore every gradient - are bit-identical to the keep-all path."""
+
+    def __init__(self, x):
+        self.x = x
+
+
+def llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps=1e-6, recompute=False):
     """Qwen2Model's decoder layers over inputs_embeds x (modeling_qwen2.py:952-1060): returns the residual stream before the final norm
-    and what the backward re-reads."""
+    and what the backward re-reads (recompute: only each layer's input, 49 MB instead of ~1 GB per 7B layer at S = 6.8 k)."""
     saved, h = [], x
     for p in params["layers"]:
-        h, s = decoder_layer_forward(h, p, rope, n_q, n_kv, hd, eps)
-        saved.append(s)
+        h_in = h
+        h, s = decoder_layer_forward(h_in, p, rope, n_q, n_kv, hd, eps)
+        saved.append(_LayerInput(h_in) if recompute else s)
     return h, saved
 
 
 def llm_layers_backward(dh, saved, params, rope, n_q, n_kv, hd, eps=1e-6):
     layer_grads = [None] * len(saved)
     for i in range(len(saved) - 1, -1, -1):
-        dh, layer_grads[i] = decoder_layer_backward(dh, saved[i], params["layers"][i], rope, n_q, n_kv, hd, eps)
-        saved[i] = None                                               # the layer's activations are no longer needed
+        s = saved[i]
+        if isinstance(s, _LayerInput):
+            _, s = decoder_layer_forward(s.x, params["layers"][i], rope, n_q, n_kv, hd, eps)
+        dh, layer_grads[i] = decoder_layer_backward(dh, s, params["layers"][i], rope, n_q, n_kv, hd, eps)
+        saved[i] = s = None                                           # the layer's activations are no longer needed
     return dh, layer_grads
 
 
@@ -364,15 +378,16 @@ def siglip_layer_backward(dout, saved, p, frames, tokens=729, heads=16, eps=1e-6
                 "fc1": d_fc1, "fc1_b": d_b1, "fc2": d_fc2, "fc2_b": d_b2}
 
 
-def siglip_tower_forward(patches, vp, frames, tokens=729):
+def siglip_tower_forward(patches, vp, frames, tokens=729, recompute=False):
     """SigLipVisionEmbeddings (the patch convolution as a GEMM over v3d_patchify's rows + the position embedding, siglip_encoder.py:148-190)
     and the encoder layers the projector reads (hidden_states[-2]: all but the last layer, siglip_encoder.py:576-589).
     vp: {"patch_w" [1152, kpad], "patch_b", "pos" [tokens, 1152], "layers": [siglip_pad_layer dicts]}."""
     h = ops.gemm(patches, vp["patch_w"], bias=vp["patch_b"], res=vp["pos"], res_mod=tokens, epilogue=ops.EPI_BIAS_RES)
     saved = []
     for p in vp["layers"]:
-        h, s = siglip_layer_forward(h, p, frames, tokens)
-        saved.append(s)
+        h_in = h
+        h, s = siglip_layer_forward(h_in, p, frames, tokens)
+        saved.append(_LayerInput(h_in) if recompute else s)
     return h, (patches, saved)
 
 
@@ -380,8 +395,11 @@ def siglip_tower_backward(dh, saved, vp, frames, tokens=729):
     patches, layer_saved = saved
     grads = [None] * len(layer_saved)
     for i in range(len(layer_saved) - 1, -1, -1):
-        dh, grads[i] = siglip_layer_backward(dh, layer_saved[i], vp["layers"][i], frames, tokens)
-        layer_saved[i] = None
+        s = layer_saved[i]
+        if isinstance(s, _LayerInput):
+            _, s = siglip_layer_forward(s.x, vp["layers"][i], frames, tokens)
+        dh, grads[i] = siglip_layer_backward(dh, s, vp["layers"][i], frames, tokens)
+        layer_saved[i] = s = None
     d_pos = ops.colsum(dh.view(frames, -1)).view(tokens, -1)           # the position embedding is added to every frame
     _, d_patch_w, d_patch_b = linear_backward(patches, vp["patch_w"], dh, need_dx=False, need_db=True)
     return {"patch_w": d_patch_w, "patch_b": d_patch_b, "pos": d_pos, "layers": grads}
@@ -405,20 +423,21 @@ def _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, fram
 
 
 def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_ids, labels, rope, frames, n_q, n_kv, hd, tokens=729, side=27, n=14,
-                            coord_rows=None, coord_pe=None):
+                            coord_rows=None, coord_pe=None, recompute=False):
     """One training sample end to end on the device (llava_qwen.py:121-205 -> llava_arch.py:336-836 -> modeling_qwen2.py:1145-1217):
     SigLIP tower -> mm_projector -> bilinear pool + 3-D PE + newline rows, spliced between the embedded text rows -> Qwen2 with labels;
     then the backward of all of it.  params: {"vision", "projector": {w1, b1, w2, b2}, "newline" [H], "embed" [vocab, H], "llm"};
     patches [frames * tokens, kpad] (v3d_patchify of the preprocessed frames), voxel_ids [frames, n, n, 3] int32 (the discretised patch
     coordinates: no gradient, llava_arch.py:515), pre_ids / post_ids: the text token ids around <image> (device int64), labels [S];
     coord_rows (device int64) / coord_pe [H]: Scan2Cap's <coord> rows and the box-centre PE added to them.
+    recompute: activation re-computation per layer in both towers (the reference's gradient checkpointing, train_multi.sh:72).
     Returns (loss, grads in params' structure; "embed" is a dense [vocab, H] gradient with the text rows' sums)."""
-    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens)
+    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens, recompute)
     pj = params["projector"]
     y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
     H = y.shape[1]
     x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n, coord_rows, coord_pe)
-    loss, dx, llm_grads = llm_forward_backward(params["llm"], x, labels, rope, n_q, n_kv, hd)
+    loss, dx, llm_grads = llm_forward_backward(params["llm"], x, labels, rope, n_q, n_kv, hd, recompute=recompute)
     d_embed = torch.zeros_like(params["embed"])
     text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
     dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
@@ -575,7 +594,7 @@ def _ground_head_backward(dout, saved, hp):
 
 
 def ground_sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_ids, ground_row, obj_mask, box_pe, positive, rope, frames,
-                                   n_q, n_kv, hd, temperature=0.07, tokens=729, side=27, n=14, eps=1e-6):
+                                   n_q, n_kv, hd, temperature=0.07, tokens=729, side=27, n=14, eps=1e-6, recompute=False):
     """A grounding sample of the joint training (llava_qwen.py:121-160 -> predict_box :239-310, object features llava_arch.py:351-376,
     479-501): the same tower -> projector -> splice -> decoder as sample_forward_backward, but the loss is the infonce loss between the
     <ground> token's final hidden state and the object proposals' features (masked means of the projector's patch rows + the box-centre
@@ -584,12 +603,12 @@ def ground_sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids
     positive uint8 [n_obj + 1] (the last entry = the zero-target, set when the sample has no target box).
     params additionally holds "ground": {"obj": head, "query": head, "zero_target" [H]} (head = {w0, b0, ln_w, ln_b, w3, b3}).
     Returns (loss, scores f32 [n_obj + 1], grads) - grads["llm"] has no "lm_head" entry (the LM head takes no part)."""
-    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens)
+    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens, recompute)
     pj, gp = params["projector"], params["ground"]
     y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
     H = y.shape[1]
     x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n)
-    h, lsaved = llm_layers_forward(params["llm"], x, rope, n_q, n_kv, hd, eps)
+    h, lsaved = llm_layers_forward(params["llm"], x, rope, n_q, n_kv, hd, eps, recompute)
     # predict_box: the query is the final-norm hidden state of the <ground> row; the objects are masked means of the projector rows
     hq = h[ground_row:ground_row + 1]
     query_in = ops.rmsnorm(hq, params["llm"]["norm"], eps)
