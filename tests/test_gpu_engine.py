@@ -359,3 +359,39 @@ def test_scene_pipeline_equals_generate_group_and_reuses_scene_inputs():
         row = w.tolist()
         assert g.tolist() == (row[: row.index(eos) + 1] if eos in row else row)
     assert len(pipe.scene_cache) == 3 and "scene4" in pipe.scene_cache          # LRU of the last three scenes' device inputs
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_last_layer_runs_for_the_rows_that_are_read_only(fp8):
+    """llm_forward(last_rows=...) (r03): the last decoder layer forms K/V for every row but attention / o_proj / MLP only for the listed
+    rows.  Held to: the K/V cache of every layer bit-identical to the all-rows pass, the listed rows' outputs and the logits equal to
+    it up to the one-row kernels' summation order, greedy tokens equal unless the margin is inside that noise, and an empty list
+    (scene prefill) leaves the complete cache."""
+    from v3d.engine import Engine, EngineConfig, LlmConfig, VitConfig, random_state_dict
+    cfg = EngineConfig(vit=VitConfig(hidden=144, inter=272, layers=1, heads=2),
+                       llm=LlmConfig(hidden=512, inter=1024, layers=3, heads=4, kv_heads=2, vocab=320, max_pos=1024))
+    sd = random_state_dict(cfg, torch.float32, "cpu", seed=19, std=0.06)
+    eng = Engine(cfg, sd, dtype=torch.bfloat16, device="cuda", max_frames=2, llm_fp8=fp8)
+    ids, im, wc = _scenes(1, 23)[0]
+    feats, vox = eng.encode_images(im), eng.voxel_ids(wc.to(eng.dtype))
+    x = eng.build_inputs_embeds(ids, feats, vox)
+    S = x.shape[0]
+    x0 = x.clone()
+    full_logits = eng.llm_forward(x, 0).clone()
+    full_x, full_kv = x.clone(), [k[:S].clone() for k in eng.kv]
+    tol = 1e-1 if fp8 else 2e-2          # e4m3: the all-rows pass quantises the activations too (W8A8), the one-row kernels keep them 16-bit (W8A16)
+    for rows in ([S - 1], [5, S - 1], []):
+        x.copy_(x0)
+        for k in eng.kv:
+            k.zero_()
+        logits = eng.llm_forward(x, 0, last_rows=rows, head=bool(rows))
+        assert all(torch.equal(k[:S], f) for k, f in zip(eng.kv, full_kv))                 # the cache never depends on the pruning
+        for r in rows:
+            assert ((x[r].float() - full_x[r].float()).norm() / full_x[r].float().norm()).item() < tol
+        if rows:
+            assert ((logits.float() - full_logits.float()).norm() / full_logits.float().norm()).item() < tol
+    a = eng.generate(ids, im, wc, max_new_tokens=4).tolist()                             # (pruned) against the all-rows prefill + decode
+    x.copy_(x0)
+    b = eng.decode_loop(eng.llm_forward(x, 0), S, 4).tolist()
+    top2 = torch.topk(full_logits.float(), 2).values
+    assert a == b or fp8 or (top2[0] - top2[1]).item() < 0.05 * full_logits.float().abs().max().item()

@@ -198,7 +198,6 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
             raise V3DError(f"sequence {S} exceeds engine capacity {eng.cfg.llm.max_pos}")
         x = eng.l_x[:S]
         x.copy_(inputs_embeds[0].to(device=eng.device, dtype=eng.dtype))
-        eng.llm_forward(x, 0, head=False)
         if use_object_proposals:
             gt = getattr(self.config, "ground_token_ids", None)
             if gt is None:
@@ -206,7 +205,9 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
             loc = ((new_labels[0] >= gt[0]) & (new_labels[0] <= gt[-1])).nonzero().flatten()
             if loc.numel() != 1:
                 raise ValueError("exactly one <ground> label token expected")
+            eng.llm_forward(x, 0, head=False, last_rows=[int(loc[0])])      # predict_box reads the <ground> row only (llava_qwen.py:280-281)
             return None, eng.predict_box(x, int(loc[0]), object_features)
+        eng.llm_forward(x, 0, head=False)
         logits = eng.logits_all_rows(x)
         loss = None
         if labels is not None:        # the shifted cross-entropy of modeling_qwen2.py:1195-1205 over the re-aligned labels (forward value only)

@@ -387,13 +387,19 @@ class Engine:
         return x
 
     # ------------------------------------------------------------------ Qwen2 decoder (a18-a22)
-    def llm_forward(self, x, pos0, stamps=None, head=True, batch=None):
+    def llm_forward(self, x, pos0, stamps=None, head=True, batch=None, last_rows=None):
         """Runs the decoder over rows x [S, hidden] (in place) at positions pos0.., appends K/V to the
         cache and returns the f32 logits of the LAST row only ([vocab]); the reference materialises all
         S rows of logits (modeling_qwen2.py:1190-1192) but generation reads only the last.
         batch (answer_group): x holds B sequences of Sq rows each, all starting at position pos0 behind the same cached prefix;
         batch.kv[i] is [B, max_pos, 2*kv_width] (sequence b appends to and attends over its own slice), batch.positions /
-        batch.dst_rows give every row's position and flat cache row."""
+        batch.dst_rows give every row's position and flat cache row.
+        last_rows (r03; None = every row): the rows of x whose LAST-layer output the caller will read - [S - 1] for generation,
+        [ground row] for the grounding head, [] for a scene prefill that only leaves K/V behind.  The last layer's keys and values
+        are still formed for every row (the decode steps attend to them), but its attention, o_proj and MLP run for the listed rows
+        only: no later computation reads the other rows' outputs (the reference computes and drops them,
+        modeling_qwen2.py:1048-1070 then :1188 reads hidden_states[:, -1] in effect) - 1 / 28 of the decoder's attention and MLP
+        work.  The listed rows go through the one-row decode kernels (f32 sums in another order than the GEMM tiles: rounding-level)."""
         l = self.cfg.llm
         S = x.shape[0]
         hd, nh, nkv = self.hd, l.heads, l.kv_heads
@@ -422,8 +428,14 @@ class Engine:
             def norm_lin(ln, L, key, out, **kw):
                 ops.rmsnorm(x, ln, l.eps, out=h)
                 return ops.gemm(h, L[key], out=out, **kw)
+        n_layers = len(self.l_layers)
         for i, L in enumerate(self.l_layers):
             norm_lin(L["ln1"], L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.EPI_BIAS)
+            if last_rows is not None and batch is None and i == n_layers - 1 and S > 1:
+                cache = self.kv[i]
+                ops.rope_kv_store(qkv, nh, nkv, hd, self.rope, cache, pos0=pos0)
+                self._last_layer_rows(L, x, qkv, cache, [int(r) for r in last_rows], pos0)
+                continue
             if batch is not None:
                 c3 = batch.kv[i]
                 cache = c3.view(-1, c3.shape[-1])
@@ -459,6 +471,29 @@ class Engine:
             return None
         self.kv_len = pos0 + S
         return self._head(x[S - 1:]) if head else None
+
+    def _last_layer_rows(self, L, x, qkv, cache, rows, pos0):
+        """The last decoder layer after its K/V rows are in the cache, for single rows of the sequence: attention of row r over keys
+        0 .. pos0 + r (the decode kernel), o_proj + residual, RMSNorm + gate/up + SwiGLU, down + residual - decode_forward's per-layer
+        launches with the query taken from the prefill's QKV rows."""
+        l = self.cfg.llm
+        hd, nh, nkv = self.hd, l.heads, l.kv_heads
+        kvw = nkv * hd
+        scale = 1.0 / math.sqrt(hd)
+        att, act = self.ctx.d_att, self.ctx.d_act
+        for r in rows:
+            xr = x[r]
+            ops.attention_decode(qkv[r], cache, cache[:, kvw:], att, pos0 + r + 1, nh, nkv, scale, self.dec_ws)
+            if self.llm_fp8:
+                row = x[r: r + 1]
+                ops.linear_decode_fp8_rows(att[None], *L["wo8"], row, res=row, epilogue=ops.DEC_RES)
+                h1 = ops.rmsnorm(row, L["ln2"], l.eps, out=self.l_h[:1])
+                ops.linear_decode_fp8_rows(h1, *L["wgu8"], act[None], epilogue=ops.DEC_SWIGLU)
+                ops.linear_decode_fp8_rows(act[None], *L["wd8"], row, res=row, epilogue=ops.DEC_RES)
+            else:
+                ops.linear_decode(att, L["wo"], xr, res=xr, epilogue=ops.DEC_RES)
+                ops.linear_decode(xr, L["wgu"], act, norm_weight=L["ln2"], eps=l.eps, epilogue=ops.DEC_SWIGLU)
+                ops.linear_decode(act, L["wd"], xr, res=xr, epilogue=ops.DEC_RES)
 
     def _head(self, x_row):
         """final RMSNorm + LM head on ONE row (K18: only the last position feeds generation)."""
@@ -536,7 +571,7 @@ class Engine:
         at = input_ids.tolist().index(-200)
         n_vis = feats.shape[0] * self.cfg.pool_out * (self.cfg.pool_out + 1)
         gpos = ground_index if ground_index < at else ground_index + n_vis - 1
-        self.llm_forward(x, 0, head=False)
+        self.llm_forward(x, 0, head=False, last_rows=[gpos])
         return self.predict_box(x, gpos, self.object_features(feats, coords, boxes))
 
     def predict_box(self, x, gpos, object_features):
@@ -578,7 +613,7 @@ class Engine:
         x = self.build_inputs_embeds(input_ids, feats, ids, box_input=box_input, coord_token_id=coord_token_id)
         S = x.shape[0]
         self._check_room(S, max_new_tokens)
-        logits = self.llm_forward(x, 0)
+        logits = self.llm_forward(x, 0, last_rows=[S - 1])
         return self.decode_loop(logits, S, max_new_tokens, eos_token_id, stopping)
 
     # ------------------------------------------------------------------ scene-level reuse
@@ -593,7 +628,7 @@ class Engine:
         feats = self.encode_images(images)
         ids = self.voxel_ids(world_coords.to(self.dtype))
         x = self.build_inputs_embeds(prefix_ids, feats, ids)
-        self.llm_forward(x, 0, head=False)
+        self.llm_forward(x, 0, head=False, last_rows=[])          # the prefix only leaves its K/V rows behind
         self.ctx.prefix_len = x.shape[0]
         return self.ctx.prefix_len
 
@@ -612,7 +647,7 @@ class Engine:
             raise V3DError("answer() needs at least one question token")
         self._check_room(P + Q, max_new_tokens)
         x = ops.embed_gather(self.embed, q, out=self.l_x[P: P + Q])
-        logits = self.llm_forward(x, P)
+        logits = self.llm_forward(x, P, last_rows=[Q - 1])
         return self.decode_loop(logits, P + Q, max_new_tokens, eos_token_id, stopping)
 
     def _answer_state(self, n):
@@ -711,7 +746,7 @@ class Engine:
                 ids = self.voxel_ids(world_coords.to(self.dtype))
                 x = self.build_inputs_embeds(input_ids, feats, ids)
                 self._check_room(x.shape[0], max_new_tokens)
-                self.llm_forward(x, 0)
+                self.llm_forward(x, 0, last_rows=[x.shape[0] - 1])
                 lens.append(x.shape[0])
         finally:
             self.use(keep)

@@ -249,7 +249,7 @@ class ScenePipeline:
                                     coord_token_id=sample.extra.get("coord_token_id"), stamp=pe)
         S = x.shape[0]
         eng._check_room(S, max_new_tokens)
-        eng.llm_forward(x, 0, stamps=stamps)
+        eng.llm_forward(x, 0, stamps=stamps, last_rows=[S - 1])
         return S
 
     # ------------------------------------------------------------------ the whole list
