@@ -560,6 +560,9 @@ def main():
                                    % ("fp8 LLM linears (configs[3])" if a.fp8 else "bf16", S, NEW_TOKENS, NEW_TOKENS - 1, n_scenes),
                        "frames": FRAMES, "seq_len": S, "new_tokens": NEW_TOKENS, "decode_weight_passes": NEW_TOKENS - 1,
                        "parallelism": "scene-dp%d" % world, "decode_group": 1 if a.no_overlap else G_ALL,
+                       "dead_work_not_computed": "LM head for the last row only (the reference forms all S rows of logits and reads one); the LAST decoder "
+                                                 "layer's attention / o_proj / MLP for the last row only (its K/V rows are formed for every row; no later "
+                                                 "computation reads the other rows' outputs)",
                        "scheduling": "one scene at a time" if a.no_overlap else
                                      "prefill per scene on stream A; the decode passes of up to %d scenes share each pass over the weights on stream B" % G_ALL},
             "roofline": {"kernel": "%s (Qwen2 gate/up + SwiGLU, M=%d N=37888 K=3584): the largest share of the step" %
