@@ -402,6 +402,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements appended to the default N=1 line (fp8, cached questions, grounding)")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip only the configs[3] extra")
     ap.add_argument("--no-train-extra", action="store_true", help="skip only the configs[4] (language-model training step) extra")
+    ap.add_argument("--prefill-streams", type=int, default=2, help="streams that prefill consecutive scenes side by side (each with its own scratch)")
     ap.add_argument("--eval-runner-only", action="store_true", help="after the headline run only the eval_runner extra (development)")
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes resident in HBM, cycled over the steps")
     a = ap.parse_args()
@@ -464,7 +465,7 @@ def main():
         """W untimed warm-up scenes, then EXACTLY `steps` scenes between barrier + synchronize; max over ranks.  The timed region IS the
         product's scene pipeline (v3d.pipeline.ScenePipeline.run - the eval runners call the same function): prefill per scene on stream A,
         decode groups on stream B, two context sets."""
-        pipe = ScenePipeline(eng, G_ALL)
+        pipe = ScenePipeline(eng, G_ALL, prefill_streams=a.prefill_streams)
         if a.warmup:
             pipe.run(samples_of(scenes, max(a.warmup, min(G_ALL, a.steps)), SceneSample), NEW_TOKENS, overlap=not a.no_overlap, trim=False)
         barrier()
@@ -564,7 +565,8 @@ def main():
                                                  "layer's attention / o_proj / MLP for the last row only (its K/V rows are formed for every row; no later "
                                                  "computation reads the other rows' outputs)",
                        "scheduling": "one scene at a time" if a.no_overlap else
-                                     "prefill per scene on stream A; the decode passes of up to %d scenes share each pass over the weights on stream B" % G_ALL},
+                                     "prefill per scene on %d stream(s) (consecutive scenes side by side); the decode passes of up to %d scenes share each "
+                                     "pass over the weights on another stream" % (a.prefill_streams, G_ALL)},
             "roofline": {"kernel": "%s (Qwen2 gate/up + SwiGLU, M=%d N=37888 K=3584): the largest share of the step" %
                                    ("gemm_fp8_kernel" if a.fp8 else "gemm256pp_kernel", S), "bound": "mfma",
                          "achieved": gemm_flops / gemm_us / 1e6, "peak": gemm_peak, "unit": "TFLOP/s",

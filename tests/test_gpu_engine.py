@@ -353,6 +353,14 @@ def test_scene_pipeline_equals_generate_group_and_reuses_scene_inputs():
     for overlap in (True, False):
         got = pipe.run(mk(), max_new_tokens=6, overlap=overlap)
         assert len(got) == 5 and all(torch.equal(g, w) for g, w in zip(got, want)), overlap
+    # two prefill streams (consecutive scenes side by side, each on its own scratch): the same tokens; a repeated scene key is served
+    # from the device cache across the two streams
+    pipe2 = ScenePipeline(eng, group_size=2, prefill_streams=2)
+    got = pipe2.run(mk(), max_new_tokens=6)
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
+    twice = [SceneSample(input_ids=scenes[i // 2][0], images=scenes[i // 2][1], world_coords=scenes[i // 2][2], key=f"scene{i // 2}") for i in range(4)]
+    got = pipe2.run(iter(twice), max_new_tokens=6)
+    assert torch.equal(got[0], got[1]) and torch.equal(got[2], got[3]) and torch.equal(got[0], want[0]) and torch.equal(got[2], want[1])
     eos = int(want[3][2])
     cut = pipe.run(mk(), max_new_tokens=6, eos_token_id=eos)
     for g, w in zip(cut, want):

@@ -255,21 +255,37 @@ class Engine:
         self.ctx = self.new_context()
 
     # ------------------------------------------------------------------ workspaces
-    def _alloc(self, max_frames):
+    _WS_NAMES = ("v_x", "v_h", "v_qkv", "v_att", "v_mlp", "p_h", "feat", "l_h", "l_qkv", "l_att", "l_act", "l_q8", "l_s8")
+
+    def new_prefill_workspace(self):
+        """The scratch of ONE prefill in flight: the ViT's residual / LN / QKV / attention / MLP rows, the projector's rows, the
+        decoder's norm / QKV / attention / SwiGLU rows (about 1.6 GB at the 7B shapes).  A second set lets a second stream prefill
+        another scene at the same time (use_workspace), so that one scene's kernels fill the idle CUs of the other's last GEMM rounds."""
         v, l = self.cfg.vit, self.cfg.llm
         dt, dev = self.dtype, self.device
-        T = max_frames * (v.image // v.patch) ** 2
-        z = lambda *s: torch.zeros(s, dtype=dt, device=dev)
-        self.max_frames = max_frames
-        self.v_x, self.v_h = z(T, self.v_Hx), z(T, self.v_Hp)
-        self.v_qkv, self.v_att, self.v_mlp = z(T, self.v_nqkv), z(T, self.v_Hp), z(T, self.v_Ip)
-        self.p_h, self.feat = z(T, l.hidden), z(T, l.hidden)
+        T = self.max_frames * (v.image // v.patch) ** 2
         S = l.max_pos
-        self.l_h = z(S, l.hidden)                      # prefill scratch (one prefill runs at a time)
-        self.l_qkv, self.l_att, self.l_act = z(S, self.l_nqkv), z(S, l.hidden), z(S, l.inter)
+        z = lambda *s: torch.zeros(s, dtype=dt, device=dev)     # noqa: E731
+        w = SceneContext()
+        w.v_x, w.v_h = z(T, self.v_Hx), z(T, self.v_Hp)
+        w.v_qkv, w.v_att, w.v_mlp = z(T, self.v_nqkv), z(T, self.v_Hp), z(T, self.v_Ip)
+        w.p_h, w.feat = z(T, l.hidden), z(T, l.hidden)
+        w.l_h = z(S, l.hidden)
+        w.l_qkv, w.l_att, w.l_act = z(S, self.l_nqkv), z(S, l.hidden), z(S, l.inter)
+        w.l_q8 = w.l_s8 = None
         if self.llm_fp8:                               # e4m3 image + row scales of the current GEMM's activations
-            self.l_q8 = torch.zeros((S, max(l.hidden, l.inter)), dtype=torch.uint8, device=dev)
-            self.l_s8 = torch.zeros(S, dtype=torch.float32, device=dev)
+            w.l_q8 = torch.zeros((S, max(l.hidden, l.inter)), dtype=torch.uint8, device=dev)
+            w.l_s8 = torch.zeros(S, dtype=torch.float32, device=dev)
+        return w
+
+    def use_workspace(self, w):
+        """Select the prefill scratch subsequent launches use (host-side pointer switch, like use(ctx))."""
+        self.ws = w
+        return w
+
+    def _alloc(self, max_frames):
+        self.max_frames = max_frames
+        self.ws = self.new_prefill_workspace()
         self.ctx = self.new_context()                  # per-scene state (sequence buffer, KV cache, decode rows)
 
     def new_context(self):
@@ -292,6 +308,19 @@ class Engine:
         self.ctx = ctx
         return ctx
 
+    v_x = property(lambda self: self.ws.v_x)
+    v_h = property(lambda self: self.ws.v_h)
+    v_qkv = property(lambda self: self.ws.v_qkv)
+    v_att = property(lambda self: self.ws.v_att)
+    v_mlp = property(lambda self: self.ws.v_mlp)
+    p_h = property(lambda self: self.ws.p_h)
+    feat = property(lambda self: self.ws.feat)
+    l_h = property(lambda self: self.ws.l_h)
+    l_qkv = property(lambda self: self.ws.l_qkv)
+    l_att = property(lambda self: self.ws.l_att)
+    l_act = property(lambda self: self.ws.l_act)
+    l_q8 = property(lambda self: self.ws.l_q8)
+    l_s8 = property(lambda self: self.ws.l_s8)
     l_x = property(lambda self: self.ctx.l_x)
     kv = property(lambda self: self.ctx.kv)
     l_last = property(lambda self: self.ctx.l_last)

@@ -98,7 +98,7 @@ def ground_answer_fn(task, model, tokenizer, image_processor, video_processor, m
         if pipe is None:
             pipe = model.__dict__["_v3d_pipeline"] = ScenePipeline(
                 eng, 16, crop=image_processor.crop_size["width"], image_mean=image_processor.image_mean,
-                image_std=image_processor.image_std, rescale=image_processor.rescale_factor)
+                image_std=image_processor.image_std, rescale=image_processor.rescale_factor, prefill_streams=2)
         loader = AsyncSceneLoader([l["video"] for l in lines], lambda vid: video_processor.describe_scene(vid, True, max_frame_num),
                                   workers=E.default_workers() if workers is None else workers, pool=pool)
         out, pending = [], []

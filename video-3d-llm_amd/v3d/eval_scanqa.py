@@ -210,7 +210,7 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
         if pipe is None or pipe.G != group_size:
             pipe = model.__dict__["_v3d_pipeline"] = ScenePipeline(
                 eng, group_size, crop=image_processor.crop_size["width"], image_mean=image_processor.image_mean,
-                image_std=image_processor.image_std, rescale=image_processor.rescale_factor)
+                image_std=image_processor.image_std, rescale=image_processor.rescale_factor, prefill_streams=2)
         prompts = []
         for line in lines:
             ids = build_prompt_ids(line, tokenizer)[0]

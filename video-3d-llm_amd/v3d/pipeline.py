@@ -176,7 +176,7 @@ class AsyncSceneLoader:
 
 class ScenePipeline:
     def __init__(self, eng, group_size=16, crop=384, scene_cache=3, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5),
-                 rescale=1 / 255):
+                 rescale=1 / 255, prefill_streams=1):
         if not 1 <= group_size <= 16:
             raise V3DError("decode groups hold 1 to 16 scenes")
         self.eng, self.G, self.crop = eng, group_size, crop
@@ -186,6 +186,10 @@ class ScenePipeline:
         dev = torch.device(eng.device)
         self.streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self.copy_stream = torch.cuda.Stream(device=dev)
+        # prefill_streams = 2: consecutive scenes prefill on two streams with their own scratch, so that one scene's kernels run on the
+        # CUs the other's last GEMM rounds leave idle (a persistent 256-workgroup GEMM ends with a partly filled round)
+        self.pre_streams = [self.streams[0]] + [torch.cuda.Stream(device=dev) for _ in range(prefill_streams - 1)]
+        self.workspaces = [eng.ws] + [eng.new_prefill_workspace() for _ in range(prefill_streams - 1)]
         self.scene_cache = collections.OrderedDict()
         self.scene_cache_size = scene_cache
         self.upload_seconds = 0.0
@@ -199,7 +203,9 @@ class ScenePipeline:
             self.scene_cache.move_to_end(sample.key)
             if isinstance(sample.raw, dict) and "_done" in sample.raw:
                 sample.raw["_done"](None)          # nothing to upload: the scene's device tensors are still here
-            return self.scene_cache[sample.key]
+            images, coords, ready = self.scene_cache[sample.key]
+            torch.cuda.current_stream().wait_event(ready)       # (they may have been produced on the other prefill stream)
+            return images, coords
         if sample.images is not None:
             images = sample.images.to(device=eng.device, dtype=dt, non_blocking=True)
             coords = sample.world_coords.to(device=eng.device, dtype=dt, non_blocking=True)
@@ -232,7 +238,10 @@ class ScenePipeline:
                 images = ops.resize_crop_rgb(frames, (self.crop, new_w), crop=(0, (new_w - self.crop) // 2, self.crop, self.crop),
                                              dtype=dt, mean=self.mean, std=self.std, rescale=self.rescale)
         if sample.key is not None and self.scene_cache_size > 0:
-            self.scene_cache[sample.key] = (images, coords)
+            for t in (images, coords):
+                for st in self.pre_streams:
+                    t.record_stream(st)
+            self.scene_cache[sample.key] = (images, coords, torch.cuda.current_stream().record_event())
             while len(self.scene_cache) > self.scene_cache_size:
                 self.scene_cache.popitem(last=False)
         return images, coords
@@ -267,23 +276,34 @@ class ScenePipeline:
             """Pulls up to G samples from the iterator, one at a time (a sample's host block is uploaded before the next one is
             asked for), and queues their prefills on stream A.  None when the iterator is exhausted."""
             ctxs_all = self.sets[gi % 2]
-            ctxs, lens = [], []
-            with torch.cuda.stream(sA if overlap else torch.cuda.current_stream()):
-                for c in ctxs_all:
-                    smp = next(it, None)
-                    if smp is None:
-                        break
+            ctxs, lens, used, alone = [], [], set(), None
+            n_pre = len(self.pre_streams) if overlap else 1
+            for k, c in enumerate(ctxs_all):
+                smp = next(it, None)
+                if smp is None:
+                    break
+                st = self.pre_streams[k % n_pre] if overlap else torch.cuda.current_stream()
+                with torch.cuda.stream(st):
+                    eng.use_workspace(self.workspaces[k % n_pre])
                     eng.use(c)
+                    stamped = stamps is not None and first and not lens
+                    if stamps is not None and first and len(lens) == 1:
+                        st.wait_event(alone)        # the stamped scene ran with nothing else on the chip
                     # kernel stamps on the first scene only: its prefill runs with nothing else on the chip
-                    lens.append(self.prefill(smp, max_new_tokens, stamps if (first and not lens) else None))
-                    ctxs.append(c)
-                done = torch.cuda.current_stream().record_event()
+                    lens.append(self.prefill(smp, max_new_tokens, stamps if stamped else None))
+                    if stamped:
+                        alone = st.record_event()
+                ctxs.append(c)
+                used.add(st)
+            done = [st.record_event() for st in used]
+            eng.use_workspace(self.workspaces[0])
             return (ctxs, lens, done) if ctxs else None
 
         try:
             cur = torch.cuda.current_stream()
             if overlap:
-                sA.wait_stream(cur)
+                for st in self.pre_streams:
+                    st.wait_stream(cur)
                 sB.wait_stream(cur)
             gi = 0
             pending = prefill_group(0, True)
@@ -293,12 +313,14 @@ class ScenePipeline:
                 # while stream A stays busy.  Its context set was last used by group gi - 1, whose tokens the host already holds.
                 pending = prefill_group(gi + 1, False)
                 with torch.cuda.stream(sB if overlap else torch.cuda.current_stream()):
-                    torch.cuda.current_stream().wait_event(pre_done)
+                    for ev in pre_done:
+                        torch.cuda.current_stream().wait_event(ev)
                     toks = eng.decode_group(self.groups[gi % 2], ctxs, lens, max_new_tokens, eos_token_id=eos_token_id)
                     out += eng.trim_at_eos(toks, eos_token_id) if trim else [toks.cpu()]
                 gi += 1
             if overlap:
-                cur.wait_stream(sA)
+                for st in self.pre_streams:
+                    cur.wait_stream(st)
                 cur.wait_stream(sB)
         finally:
             eng.use(keep)
