@@ -490,7 +490,7 @@ def main():
     dt_s = measure(eng, stamps)
     extras = {}
     if world == 1 and a.eval_runner_only:
-        extras["eval_runner"] = measure_eval_runner(eng, dev, max(16, a.steps), loader_pool, n_workers)
+        extras["eval_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
     elif world == 1 and not a.no_extras:
         nq, scene_ms = measure_cached_questions(eng, ops, scenes[0], dev, n_groups=max(1, a.steps // 4))
         extras["cached_questions"] = {
@@ -499,7 +499,7 @@ def main():
                     "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, NEW_TOKENS),
             "value": nq, "unit": "questions/s", "scene_prefill_ms": scene_ms}
         try:
-            extras["eval_runner"] = measure_eval_runner(eng, dev, max(16, a.steps), loader_pool, n_workers)
+            extras["eval_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
         except Exception as e:                          # an extra must never take the headline line down with it
             extras["eval_runner"] = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["ground_config2"] = {

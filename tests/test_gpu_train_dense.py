@@ -280,6 +280,25 @@ def test_adamw_step_matches_torch_adamw(ops):
     assert torch.allclose(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=2e-6, atol=1e-9)
 
 
+def test_adamw_eight_wide_form_equals_the_scalar_form_bitwise(ops):
+    """r03: 16-bit gradients with n % 8 == 0 take the kernel with 16-byte loads / stores; every element goes through the same
+    arithmetic, so three steps leave p32 / m / v / p16 bit-identical to the scalar kernel's (taken by an odd-length prefix view)."""
+    g = torch.Generator().manual_seed(12)
+    n = 3 * 4096 + 8
+    for gdt, pdt in ((torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16)):
+        p0 = torch.randn(n, generator=g)
+        grads = [torch.randn(n, generator=g).to(gdt).cuda() for _ in range(3)]
+        state = []
+        for length in (n, n - 1):                           # n: eight-wide; n - 1: scalar
+            p32, m, v = p0[:length].clone().cuda(), torch.zeros(length, device="cuda"), torch.zeros(length, device="cuda")
+            p16 = torch.zeros(length, dtype=pdt, device="cuda")
+            for t, gr in enumerate(grads):
+                ops.adamw_step(p32, m, v, gr[:length].contiguous(), p16=p16, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05, step=t + 1, grad_scale=0.5)
+            state.append((p32, m, v, p16))
+        for a_, b_ in zip(*state):
+            assert torch.equal(a_[: n - 1], b_)
+
+
 def test_embed_grad_sums_repeated_tokens(ops):
     g = torch.Generator().manual_seed(5)
     S, H, V = 40, 264, 50
