@@ -731,3 +731,72 @@ def test_grounding_sample_step_matches_autograd(ops, train):
     for k in ("q_w", "o_w", "fc1_w", "fc2_w", "ln1_w"):
         _close(real[k], r_vit[k].grad, *tol, "vit d " + k)
     _close(grads["embed"], r_emb.grad, *tol, "d embed")
+
+
+def test_trainer_surface_loss_backward_and_checkpoint_round_trip(ops, train):
+    """v3d.train_module.LlavaQwenTrainable (r03; VERDICT r2 missing #5): built from a state dict in the REFERENCE's keys, its forward
+    returns a loss whose .backward() fills every parameter's .grad with the device-side backward's gradients (bit-identical to
+    train.sample_forward_backward), a torch optimizer steps it, and reference_state_dict() gives the reference's keys / shapes back -
+    exactly the input before the step."""
+    from v3d.train_module import LlavaQwenTrainable, VIT
+    Hv, heads, inter, H, I, n_q, n_kv, hd, V = 1152, 16, 4304, 512, 768, 4, 2, 128, 512
+    g = torch.Generator().manual_seed(91)
+    mk = lambda *shape, s=1.0: (torch.randn(*shape, generator=g) * s).to(torch.bfloat16)      # noqa: E731
+    ln = lambda n_: (1 + 0.1 * torch.randn(n_, generator=g)).to(torch.bfloat16)                 # noqa: E731
+    sd = {VIT + "embeddings.patch_embedding.weight": mk(Hv, 3, 14, 14, s=588 ** -0.5), VIT + "embeddings.patch_embedding.bias": mk(Hv, s=0.1),
+          VIT + "embeddings.position_embedding.weight": mk(729, Hv, s=0.5)}
+    p = VIT + "encoder.layers.0."
+    for n_ in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        sd[p + f"self_attn.{n_}.weight"], sd[p + f"self_attn.{n_}.bias"] = mk(Hv, Hv, s=Hv ** -0.5), mk(Hv, s=0.2)
+    for n_ in ("layer_norm1", "layer_norm2"):
+        sd[p + n_ + ".weight"], sd[p + n_ + ".bias"] = ln(Hv), mk(Hv, s=0.1)
+    sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = mk(inter, Hv, s=Hv ** -0.5), mk(inter, s=0.2), mk(Hv, inter, s=inter ** -0.5), mk(Hv, s=0.2)
+    sd["model.mm_projector.0.weight"], sd["model.mm_projector.0.bias"] = mk(H, Hv, s=Hv ** -0.5), mk(H, s=0.1)
+    sd["model.mm_projector.2.weight"], sd["model.mm_projector.2.bias"] = mk(H, H, s=H ** -0.5), mk(H, s=0.1)
+    sd["model.image_newline"], sd["model.embed_tokens.weight"] = mk(H, s=0.5), mk(V, H, s=0.5)
+    p = "model.layers.0."
+    sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"] = mk(n_q * hd, H, s=H ** -0.5), mk(n_q * hd, s=0.3)
+    for n_ in ("k_proj", "v_proj"):
+        sd[p + f"self_attn.{n_}.weight"], sd[p + f"self_attn.{n_}.bias"] = mk(n_kv * hd, H, s=H ** -0.5), mk(n_kv * hd, s=0.3)
+    sd[p + "self_attn.o_proj.weight"] = mk(H, n_q * hd, s=(n_q * hd) ** -0.5)
+    sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = mk(I, H, s=H ** -0.5), mk(I, H, s=H ** -0.5), mk(H, I, s=I ** -0.5)
+    sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = ln(H), ln(H)
+    sd["model.norm.weight"], sd["lm_head.weight"] = ln(H), mk(V, H, s=H ** -0.5)
+
+    model = LlavaQwenTrainable.from_reference_state_dict(sd, n_q, n_kv, max_pos=1024)
+    back = model.reference_state_dict()
+    assert set(back) == set(sd) and all(torch.equal(back[k].cpu(), sd[k]) for k in sd)          # exact round trip
+    frames = 2
+    images = torch.randn(frames, 3, 384, 384, generator=g)
+    coords = (torch.rand(frames, 384, 384, 3, generator=g) - 0.5) * torch.tensor([20.0, 20.0, 8.0])
+    t_ = torch.randint(0, V, (30,), generator=g)
+    input_ids = torch.cat([t_[:9], torch.tensor([-200]), t_[9:]])
+    labels = torch.full((31,), -100, dtype=torch.int64)
+    labels[20:] = input_ids[20:]
+    loss = model(input_ids, labels, images, coords)
+    assert loss.requires_grad and loss.dtype == torch.float32
+    loss.backward()
+    # the same gradients as the explicit step on the same tensors
+    tr = model.param_tree()
+    patches = ops.patchify(images.to(torch.bfloat16).cuda(), 14, 640)
+    _, _, vox = ops.coord_pool_voxel(coords.to(torch.bfloat16).cuda(), want_avg=False, want_vox=False)
+    n_vis = frames * 210
+    full = torch.cat([labels[:9], torch.full((n_vis,), -100, dtype=torch.int64), labels[10:]]).cuda()
+    loss2, grads = train.sample_forward_backward(tr, patches, vox, model.pe_table, input_ids[:9].cuda(), input_ids[10:].cuda(), full, model.rope,
+                                                 frames, n_q, n_kv, hd)
+    assert float(loss) == float(loss2)
+    from v3d.train_module import _flatten
+    by_name = dict(_flatten(grads))
+    for name, prm in zip(model.names, model._params):
+        assert prm.grad is not None and torch.equal(prm.grad, by_name[name]), name
+    before = model.reference_state_dict()
+    torch.optim.SGD(model.parameters(), lr=0.5).step()
+    after = model.reference_state_dict()
+    changed = [k for k in sd if not torch.equal(before[k], after[k])]
+    assert len(changed) >= len(sd) - 2, sorted(set(sd) - set(changed))          # (the tower's k_proj bias has no gradient: softmax shift invariance)
+    # loss scaling (gradient accumulation divides the loss): gradients scale with it
+    model.zero_grad()
+    (model(input_ids, labels, images, coords) * 0.5).backward()
+    g_half = model._params[model.names.index("projector.w2")].grad
+    ref = (by_name["projector.w2"].float() * 0.5).to(torch.bfloat16)
+    assert torch.equal(g_half, ref)
