@@ -784,11 +784,11 @@ def test_trainer_surface_loss_backward_and_checkpoint_round_trip(ops, train):
     full = torch.cat([labels[:9], torch.full((n_vis,), -100, dtype=torch.int64), labels[10:]]).cuda()
     loss2, grads = train.sample_forward_backward(tr, patches, vox, model.pe_table, input_ids[:9].cuda(), input_ids[10:].cuda(), full, model.rope,
                                                  frames, n_q, n_kv, hd)
-    assert float(loss) == float(loss2)
+    assert float(loss.detach()) == float(loss2)
     from v3d.train_module import _flatten
     by_name = dict(_flatten(grads))
     for name, prm in zip(model.names, model._params):
-        assert prm.grad is not None and torch.equal(prm.grad, by_name[name]), name
+        assert prm.grad is not None and torch.equal(prm.grad, by_name[name].to(prm.dtype)), name      # (image_newline's gradient is formed in f32)
     before = model.reference_state_dict()
     torch.optim.SGD(model.parameters(), lr=0.5).step()
     after = model.reference_state_dict()

@@ -458,6 +458,9 @@ __global__ __launch_bounds__(256) void softmax_grad_rows_kernel(const T* __restr
 template <typename TG>
 __device__ __forceinline__ float adamw_one(float& p, float& mi, float& vi, float gr, float lr, float beta1, float beta2, float eps, float wd, float bc1,
                                            float bc2_sqrt) {
+  // no fused-multiply-add contraction here: the scalar and the eight-wide kernel (and a partition of ZeRO's flat buffer against the
+  // same elements inside a tensor) must round identically, whatever shape the surrounding loop gives the compiler
+#pragma clang fp contract(off)
   p = p * (1.0f - lr * wd);
   mi = mi + (gr - mi) * (1.0f - beta1);                              // lerp, as torch: exp_avg.lerp_(grad, 1 - beta1)
   vi = vi * beta2 + (1.0f - beta2) * gr * gr;

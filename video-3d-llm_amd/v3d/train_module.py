@@ -57,9 +57,12 @@ class _SampleLoss(torch.autograd.Function):
         out = []
         for g in ctx.grads:
             if scale != 1.0:
-                z = torch.zeros_like(g)
-                ops.axpy(z, g.contiguous(), scale)          # 16-bit scale on the device (v3d_axpy)
-                g = z
+                if g.dtype in (torch.bfloat16, torch.float16):
+                    z = torch.zeros_like(g)
+                    ops.axpy(z, g.contiguous(), scale)      # 16-bit scale on the device (v3d_axpy)
+                    g = z
+                else:
+                    g = g * scale                           # the few f32 leaves (image_newline: one row)
             out.append(g)
         ctx.grads = None
         return (None, None, *out)
