@@ -61,6 +61,16 @@ int v3d_unproject_f32(const float* depth_mm, const float* intrinsics, const floa
 int v3d_unproject_sampled_u16(const uint16_t* depth, const float* intrinsics, const float* poses,
                               void* out, int out_dtype, int V, int H, int W, int crop, void* stream);
 
+/* VideoProcessor.preprocess, strategy "resize" (video_utils.py:293-296): the back-projection at the pixels cv2.resize(coords, (size, size),
+ * INTER_NEAREST) keeps, both axes scaled independently, no crop: out [V,size,size,3].  (Index rule restated as for the centre-crop form:
+ * parity unpinned, cv2 is absent.) */
+int v3d_unproject_resized_u16(const uint16_t* depth, const float* intrinsics, const float* poses, void* out, int out_dtype, int V, int H,
+                              int W, int size, void* stream);
+
+/* calculate_world_coords(do_normalize=True) (video_utils.py:232-236; the "norm" frame-sampling strategies): xyz [n_points, 3] clamped
+ * in place to [lo, hi] per axis (host float[3] each). */
+int v3d_clamp_xyz(void* xyz, int64_t n_points, const float* lo_host, const float* hi_host, int dtype, void* stream);
+
 /* llava/video_utils.py:268-273 `boundry`: [x_min, x_max, y_min, y_max, z_min, z_max] of `unproject` over ALL V*H*W pixels (taken
  * before the resize and crop), computed without materialising the full-resolution tensor: same per-pixel arithmetic as
  * v3d_unproject_f32 on the u16 depth, reduced on the fly.  bounds: 6 floats (device).  workspace: device scratch of at

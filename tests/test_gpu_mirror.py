@@ -145,6 +145,25 @@ def test_video_processor_on_scene_files(golden, tmp_path):
         with Image.open(files[v]) as im:
             ref = im.convert("RGB").resize((32, crop)).crop((4, 0, 4 + crop, crop))
         assert np.array_equal(out["images"][v].cpu().numpy(), np.asarray(ref))
+    # strategy "resize" (video_utils.py:293-296): frames to crop x crop, coordinate maps to 384 x 384 by the nearest rule on both axes
+    rs = vp.preprocess(vid, proc, force_sample=True, frames_upbound=V, strategy="resize")
+    rr = np.minimum(np.floor(np.arange(384) * (H / 384)).astype(int), H - 1)
+    cc = np.minimum(np.floor(np.arange(384) * (W / 384)).astype(int), W - 1)
+    np.testing.assert_allclose(rs["world_coords"].cpu().numpy(), g["world"][:, rr][:, :, cc], rtol=2e-6, atol=2e-6)
+    for v in range(V):
+        with Image.open(files[v]) as im:
+            assert np.array_equal(rs["images"][v].cpu().numpy(), np.asarray(im.convert("RGB").resize((crop, crop))))
+    # the "norm" sampling strategies (calculate_world_coords(do_normalize=True), :232-236): every coordinate clamped to the scene's box
+    vp.frame_sampling_strategy = "uniform-norm"
+    lo, hi = torch.tensor([-0.5, -1.0, 0.2]), torch.tensor([1.5, 0.75, 1.0])
+    vp.pc_min, vp.pc_max = {"scene0000_00": lo}, {"scene0000_00": hi}
+    nm = vp.preprocess(vid, proc, force_sample=True, frames_upbound=V)
+    np.testing.assert_allclose(nm["world_coords"].cpu().numpy(), np.clip(want, lo.numpy(), hi.numpy()), rtol=2e-6, atol=2e-6)
+    clamped = np.clip(g["world"], lo.numpy(), hi.numpy()).reshape(-1, 3)
+    np.testing.assert_allclose(nm["boundry"].numpy(), np.stack([clamped.min(0), clamped.max(0)], 1).reshape(-1), rtol=2e-6, atol=2e-6)
+    wcn = vp.calculate_world_coords(vid, files, do_normalize=True)["world_coords"]
+    np.testing.assert_allclose(wcn.cpu().numpy(), np.clip(g["world"], lo.numpy(), hi.numpy()), rtol=2e-6, atol=2e-6)
+    vp.frame_sampling_strategy = "uniform"
     # the asynchronous loader (worker processes writing a pinned shared-memory block, and its inline form) delivers the same arrays
     # as the one-shot load, and np.loadtxt's pose values
     from v3d.pipeline import AsyncSceneLoader

@@ -385,6 +385,50 @@ extern "C" int v3d_unproject_sampled_u16(const uint16_t* depth, const float* int
   return check_launch("v3d_unproject_sampled_u16");
 }
 
+// VideoProcessor.preprocess, strategy "resize" (video_utils.py:293-296): cv2.resize(coords, (S, S), INTER_NEAREST) of the full-resolution
+// coordinates without a crop - the same gather as the centre-crop form with both axes scaled independently (src = min(floor(dst * src_size /
+// dst_size), src_size - 1); parity unpinned for the index rule itself, as for a6: cv2 is absent).
+extern "C" int v3d_unproject_resized_u16(const uint16_t* depth, const float* intrinsics, const float* poses, void* out, int out_dtype, int V, int H,
+                                         int W, int size, void* stream) {
+  V3D_REQUIRE(depth && intrinsics && poses && out, "v3d_unproject_resized_u16: null pointer");
+  V3D_REQUIRE(V > 0 && H > 0 && W > 0 && size > 0, "v3d_unproject_resized_u16: bad shape");
+  const double inv_fx = (double)W / (double)size, inv_fy = (double)H / (double)size;
+  hipStream_t st = (hipStream_t)stream;
+  if (size % 8 == 0 && aligned16(out)) {
+    const int groups = size * size / 8;
+    V3D_DISPATCH_DTYPE(out_dtype, hipLaunchKernelGGL(unproject_sampled_x8_kernel<T>, dim3((groups + 255) / 256, V), dim3(256), 0, st, depth, intrinsics,
+                                                     poses, (T*)out, H, W, size, 0, inv_fx, inv_fy, groups));
+    return check_launch("v3d_unproject_resized_u16");
+  }
+  int bx = (size * size + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  V3D_DISPATCH_DTYPE(out_dtype, hipLaunchKernelGGL(unproject_sampled_kernel<T>, dim3(bx, V), dim3(256), 0, st, depth, intrinsics, poses, (T*)out, H, W,
+                                                   size, size, 0, inv_fx, inv_fy));
+  return check_launch("v3d_unproject_resized_u16");
+}
+
+// calculate_world_coords(do_normalize=True) (video_utils.py:232-236, the "norm" frame-sampling strategies): every point clamped to the
+// scene's box, x = min(max(x, lo), hi) per axis, in place.
+template <typename T>
+__global__ __launch_bounds__(256) void clamp_xyz_kernel(T* __restrict__ xyz, int64_t n_points, float lx, float ly, float lz, float hx, float hy, float hz) {
+  const float lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_points * 3; i += (int64_t)gridDim.x * 256) {
+    const int a = (int)(i % 3);
+    const float v = to_f32(xyz[i]);
+    xyz[i] = from_f32<T>(fminf(fmaxf(v, lo[a]), hi[a]));
+  }
+}
+
+extern "C" int v3d_clamp_xyz(void* xyz, int64_t n_points, const float* lo_host, const float* hi_host, int dtype, void* stream) {
+  V3D_REQUIRE(xyz && lo_host && hi_host && n_points >= 0, "v3d_clamp_xyz: bad arguments");
+  if (n_points == 0) return V3D_OK;
+  int64_t blocks = (n_points * 3 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(clamp_xyz_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (T*)xyz, n_points, lo_host[0],
+                                               lo_host[1], lo_host[2], hi_host[0], hi_host[1], hi_host[2]));
+  return check_launch("v3d_clamp_xyz");
+}
+
 constexpr int BOUNDS_BLOCKS = 64;       // per frame: 64 x 256 threads, ~19 pixels each at 480 x 640
 
 extern "C" int64_t v3d_unproject_bounds_workspace_bytes(int V) { return (int64_t)(V > 0 ? V : 0) * BOUNDS_BLOCKS * 6 * (int64_t)sizeof(float); }

@@ -137,9 +137,9 @@ class VideoProcessor:
         depth, K, pose = self._load_depth_pose(video_id, frame_files)
         d32 = torch.from_numpy(depth.numpy().view(np.uint16).astype(np.float32))
         wc = ops.unproject(K.to(dev), pose.to(dev), d32.to(dev))
-        if do_normalize:
+        if do_normalize:                                           # video_utils.py:232-236
             scene_id = video_id.split("/")[-1]
-            wc = torch.minimum(torch.maximum(wc, self.pc_min[scene_id].to(dev)), self.pc_max[scene_id].to(dev))
+            ops.clamp_xyz(wc, self.pc_min[scene_id].tolist(), self.pc_max[scene_id].tolist())
         return {"world_coords": wc}
 
     # ---- a4-a6 (video_utils.py:242-321); strategy "center_crop" only (what the eval drivers use)
@@ -147,21 +147,30 @@ class VideoProcessor:
         """Returns the reference's dict; "images" are the F centre crops as ONE uint8 device tensor [F,crop,crop,3] - byte for byte the
         PIL crops the reference returns as a list (Pillow's bicubic resize reproduced on the device: v3d_resize_bicubic_u8) - which
         SigLipImageProcessor.preprocess takes as it takes a list of PIL images."""
-        if strategy != "center_crop":
-            raise NotImplementedError("only the center_crop strategy is on the accelerated path")
-        if "norm" in self.frame_sampling_strategy:
-            raise NotImplementedError("'norm' sampling strategies (clamp to the scene box) are not on the accelerated path")
+        if strategy not in ("center_crop", "resize"):
+            raise NotImplementedError(f"strategy {strategy!r}: the reference knows 'center_crop' and 'resize' (video_utils.py:292-306)")
         frame_files = self.frame_files(video_id, force_sample, frames_upbound)
         dev = _device()
         if raw is None:
             raw = self.load_raw(video_id, frame_files)
         crop = image_processor.crop_size["width"]
         depth, K, pose = raw["depth"].to(dev), raw["K"].to(dev), raw["pose"].to(dev)
-        coords = ops.unproject_sampled(depth, K, pose, crop, torch.float32)
         boundry = ops.unproject_bounds(depth, K, pose).cpu()      # over the full-resolution back-projection (:268-273)
         H, W = depth.shape[1:3]                                   # the DEPTH map's size steers the colour resize too (:269, 298-299)
-        new_w = int(W * (crop / H))
-        images = ops.resize_crop_rgb(raw["frames"].to(dev), (crop, new_w), crop=(0, (new_w - crop) // 2, crop, crop))
+        frames = raw["frames"].to(dev)
+        if strategy == "resize":                                  # :293-296 (the coordinate maps go to 384 x 384 whatever the crop size)
+            coords = ops.unproject_resized(depth, K, pose, 384, torch.float32)
+            images = ops.resize_crop_rgb(frames, (crop, crop))
+        else:
+            coords = ops.unproject_sampled(depth, K, pose, crop, torch.float32)
+            new_w = int(W * (crop / H))
+            images = ops.resize_crop_rgb(frames, (crop, new_w), crop=(0, (new_w - crop) // 2, crop, crop))
+        if "norm" in self.frame_sampling_strategy:                # calculate_world_coords(do_normalize=True): clamp to the scene's box (:232-236)
+            scene_id = video_id.split("/")[-1]
+            lo, hi = self.pc_min[scene_id], self.pc_max[scene_id]
+            ops.clamp_xyz(coords, lo.tolist(), hi.tolist())       # (clamping commutes with the nearest-neighbour gather ...
+            b = boundry.view(3, 2)                                #  ... and with min / max: the bounds of the clamped cloud)
+            boundry = torch.stack([torch.minimum(torch.maximum(b[:, 0], lo), hi), torch.minimum(torch.maximum(b[:, 1], lo), hi)], 1).reshape(6)
         return {"images": images, "world_coords": coords, "video_size": images.shape[0], "boundry": boundry,
                 "objects": torch.tensor(self.scan2obj[video_id])}
 

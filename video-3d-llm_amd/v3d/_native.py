@@ -39,6 +39,8 @@ SIGNATURES = {
     "v3d_last_error": (ctypes.c_char_p, []),
     "v3d_unproject_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "v3d_unproject_sampled_u16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_unproject_resized_u16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_clamp_xyz": (c_i, [c_p, c_l, c_p, c_p, c_i, c_p]),
     "v3d_unproject_bounds_workspace_bytes": (c_l, [c_i]),
     "v3d_unproject_bounds_u16": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "v3d_coord_pool_voxel": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p]),

@@ -83,6 +83,30 @@ def unproject_sampled(depth_u16, intrinsics, poses, crop=384, dtype=torch.float3
     return out
 
 
+def unproject_resized(depth_u16, intrinsics, poses, size=384, dtype=torch.float32):
+    """VideoProcessor.preprocess(strategy="resize") (video_utils.py:293-296): [V,H,W] raw depth -> [V,size,size,3], nearest resize of
+    both axes, no crop."""
+    d = _dev(depth_u16, "depth")
+    if d.dtype not in (torch.uint16, torch.int16):
+        raise V3DError("depth must be a 16-bit integer tensor (raw PNG millimetres)")
+    K = _dev(intrinsics, "intrinsics").float()
+    P = _dev(poses, "poses").float()
+    V, H, W = d.shape
+    out = torch.empty((V, size, size, 3), dtype=dtype, device=d.device)
+    check(lib().v3d_unproject_resized_u16(_p(d), _p(K), _p(P), _p(out), _DT[dtype], V, H, W, size, _stream()), "v3d_unproject_resized_u16")
+    return out
+
+
+def clamp_xyz(xyz, lo, hi):
+    """xyz [..., 3] (contiguous, device) clamped in place to [lo, hi] per axis (calculate_world_coords(do_normalize=True))."""
+    x = _dev(xyz, "xyz")
+    if x.shape[-1] != 3 or not x.is_contiguous():
+        raise V3DError("clamp_xyz wants a contiguous [..., 3] tensor")
+    lo_c, hi_c = (ctypes.c_float * 3)(*[float(v) for v in lo]), (ctypes.c_float * 3)(*[float(v) for v in hi])
+    check(lib().v3d_clamp_xyz(_p(x), x.numel() // 3, lo_c, hi_c, _code(x), _stream()), "v3d_clamp_xyz")
+    return x
+
+
 def unproject_bounds(depth_u16, intrinsics, poses):
     """[x_min, x_max, y_min, y_max, z_min, z_max] of the full-resolution back-projection (video_utils.py:268-273) -> f32 [6] (device)."""
     d = _dev(depth_u16, "depth")
