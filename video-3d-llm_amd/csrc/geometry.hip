@@ -533,7 +533,7 @@ struct ResizeArgs {
 
 template <typename T, bool NORM>
 __global__ __launch_bounds__(256) void resize_bicubic_kernel(ResizeArgs a) {
-  __shared__ uint8_t s_in[RS_RMAX * RS_INB];
+  __shared__ __attribute__((aligned(16))) uint8_t s_in[RS_RMAX * RS_INB];
   __shared__ uint8_t s_tmp[RS_RMAX * RS_TW * 3];
   __shared__ int32_t s_kh[RS_TW * RS_KMAX], s_kv[RS_RMAX * RS_KMAX];
   __shared__ int32_t s_bh[RS_TW * 2], s_bv[RS_RMAX * 2];
@@ -549,13 +549,29 @@ __global__ __launch_bounds__(256) void resize_bicubic_kernel(ResizeArgs a) {
   const int r_lo = s_bv[0], r_hi = s_bv[2 * (th - 1)] + s_bv[2 * (th - 1) + 1];
   const int c_lo = s_bh[0], c_hi = s_bh[2 * (tw - 1)] + s_bh[2 * (tw - 1) + 1];
   const int R = r_hi - r_lo, nb = (c_hi - c_lo) * 3;
-  if (R > RS_RMAX || nb > RS_INB || R <= 0 || nb <= 0) return;      // (the launcher sized the tile so that this cannot happen)
-  // stage the input window: wave w takes rows w, w + 4, ...; lanes walk the row's bytes
+  if (R > RS_RMAX || nb + 4 > RS_INB || R <= 0 || nb <= 0) return;      // (the launcher sized the tile so that this cannot happen)
+  // stage the input window: wave w takes rows w, w + 4, ...; lanes walk the row in 4-byte words from the word that holds the window's
+  // first byte (rows of W * 3 bytes keep their 4-byte phase when W * 3 % 4 == 0: every ScanNet size; other widths go byte by byte)
+  int shift = 0;
   {
     const int wave = tid >> 6, lane = tid & 63;
+    const bool words = ((a.W * 3) & 3) == 0 && ((uintptr_t)a.src & 3) == 0;
+    const int64_t total = (int64_t)a.F * a.H * a.W * 3;
+    if (words) shift = (c_lo * 3) & 3;
     for (int r = wave; r < R; r += 4) {
-      const uint8_t* srow = a.src + (((int64_t)f * a.H + r_lo + r) * a.W + c_lo) * 3;
-      for (int bb = lane; bb < nb; bb += 64) s_in[r * RS_INB + bb] = srow[bb];
+      const int64_t off = (((int64_t)f * a.H + r_lo + r) * a.W + c_lo) * 3 - shift;      // multiple of 4 in the word form
+      const uint8_t* srow = a.src + off;
+      if (words) {
+        const int ndw = (shift + nb + 3) >> 2;
+        for (int dw = lane; dw < ndw; dw += 64) {
+          uint32_t w;
+          if (off + 4 * dw + 4 <= total) w = reinterpret_cast<const uint32_t*>(srow)[dw];
+          else { w = 0; for (int k = 0; k < 4 && off + 4 * dw + k < total; ++k) w |= (uint32_t)srow[4 * dw + k] << (8 * k); }
+          reinterpret_cast<uint32_t*>(s_in + r * RS_INB)[dw] = w;
+        }
+      } else {
+        for (int bb = lane; bb < nb; bb += 64) s_in[r * RS_INB + bb] = srow[bb];
+      }
     }
   }
   __syncthreads();
@@ -565,7 +581,7 @@ __global__ __launch_bounds__(256) void resize_bicubic_kernel(ResizeArgs a) {
     if (x >= tw) continue;
     const int xmin = s_bh[2 * x] - c_lo, n = s_bh[2 * x + 1];
     const int32_t* k = s_kh + x * a.ksh;
-    const uint8_t* px = s_in + r * RS_INB + xmin * 3;
+    const uint8_t* px = s_in + r * RS_INB + shift + xmin * 3;
     int ss0 = 1 << 21, ss1 = 1 << 21, ss2 = 1 << 21;
     for (int t = 0; t < n; ++t) {
       const int c = k[t];
@@ -614,7 +630,7 @@ extern "C" int v3d_resize_bicubic_u8(const uint8_t* frames, int F, int H, int W,
   V3D_REQUIRE(out_dtype == V3D_U8_HWC || mean_host && std_host, "v3d_resize_bicubic_u8: mean / std needed for a normalised output");
   // input window of a tile: (tile extent) x scale + taps; the tile shrinks until the window fits the LDS staging
   auto span = [](int n_out, int in, int out, int ks) { return (int)(((int64_t)n_out * in + out - 1) / out) + ks + 2; };
-  V3D_REQUIRE(span(RS_TW, W, OW, ksize_h) * 3 <= RS_INB, "v3d_resize_bicubic_u8: horizontal reduction %d -> %d too strong for this kernel", W, OW);
+  V3D_REQUIRE(span(RS_TW, W, OW, ksize_h) * 3 + 4 <= RS_INB, "v3d_resize_bicubic_u8: horizontal reduction %d -> %d too strong for this kernel", W, OW);
   int th = 16;
   while (th > 1 && span(th, H, OH, ksize_v) > RS_RMAX) th >>= 1;
   V3D_REQUIRE(span(th, H, OH, ksize_v) <= RS_RMAX, "v3d_resize_bicubic_u8: vertical reduction %d -> %d too strong for this kernel", H, OH);
