@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void resize_bicubic_kernel(ResizeArgs a) {
     int ss0 = 1 << 21, ss1 = 1 << 21, ss2 = 1 << 21;
     for (int t = 0; t < n; ++t) {
       const int c = k[t];
-      ss0 += (int)px[3 * t] * c; ss1 += (int)px[3 * t + 1] * c; ss2 += (int)px[3 * t + 2] * c;
+      ss0 += __mul24((int)px[3 * t], c); ss1 += __mul24((int)px[3 * t + 1], c); ss2 += __mul24((int)px[3 * t + 2], c);      // |c| < 2^23: full-rate 24-bit multiply
     }
     uint8_t* d = s_tmp + (r * RS_TW + x) * 3;
     d[0] = (uint8_t)min(255, max(0, ss0 >> 22)); d[1] = (uint8_t)min(255, max(0, ss1 >> 22)); d[2] = (uint8_t)min(255, max(0, ss2 >> 22));
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void resize_bicubic_kernel(ResizeArgs a) {
     for (int t = 0; t < n; ++t) {
       const uint8_t* px = s_tmp + ((ymin + t) * RS_TW + x) * 3;
       const int c = k[t];
-      ss[0] += (int)px[0] * c; ss[1] += (int)px[1] * c; ss[2] += (int)px[2] * c;
+      ss[0] += __mul24((int)px[0], c); ss[1] += __mul24((int)px[1], c); ss[2] += __mul24((int)px[2], c);
     }
     const int oy = y0 + y - a.top, ox = x0 + x - a.left;
 #pragma unroll
