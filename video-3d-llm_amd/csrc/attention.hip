@@ -470,6 +470,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     float ls0 = 0.f, ls1 = 0.f;
     qk_fill(IntC<0>{});
     qk_run(IntC<0>{}, s);
+    __builtin_amdgcn_s_barrier();      // every wave has read K of tile 0 before step 0 restages its buffer (tile 2)
     mask_scores(s, 0);
     raise_max(s, 0);
 #pragma unroll
@@ -1071,6 +1072,7 @@ __global__ __launch_bounds__(256, 1) void attn_prefill64_kernel(AttnArgs p) {
     qk_fill(0u);
     qk_run(0u, IntC<0>{}, IntC<1>{}, sp);
     qk_run(0u, IntC<1>{}, IntC<0>{}, sp);
+    __builtin_amdgcn_s_barrier();      // every wave has read K of tile 0 before step 0 restages its ring slot (tile 3)
     V3D_MFMA_TO_VALU();
     s0[0] = sp[0][0]; s0[1] = sp[0][1]; s1[0] = sp[1][0]; s1[1] = sp[1][1];
   }
