@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 4   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds */
+#define V3D_ABI_VERSION 5   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds */
 
 enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
 enum { V3D_U8_HWC = 16 };   /* v3d_resize_bicubic_u8 only: 8-bit interleaved output, no normalisation */
@@ -315,10 +315,19 @@ int v3d_eos_update(const int64_t* tokens, int M, const int64_t* eos_ids, int n_e
 /* ------------------------------------------------------------------ grounding (K19, K20) - */
 
 /* K19  llava_arch.py:357-372, object_feature_type 'patch14': mask[o, f, py, px] = 1 iff at least `thresh`
- * (= int(14*14*0.5)) pixels of the cell x cell ViT patch lie inside box o = (centre xyz, size xyz).
+ * (= int(14*14*0.5)) pixels of the cell x cell ViT patch lie inside box o = (centre xyz, size xyz);
+ * 'patch27' (:367-371): cell = 27 (the pooled 14 x 14 token grid), thresh = int(27*27*0.25); cell * cell <= 768.
  * coords [F,S,S,3] dtype (first S-6 rows/cols used), boxes [n,6] dtype -> mask uint8 [n, F*g*g], g = (S-6)/cell. */
 int v3d_object_patch_mask(const void* coords, int dtype, int F, int S, int cell, const void* boxes, int n_obj,
                           int thresh, uint8_t* mask, void* stream);
+
+/* The 'mlp' and 'score' grounding heads (llava_qwen.py:59-86, 283-293; the shipped checkpoints use 'infonce', K20).
+ * v3d_row_dots: out[i] = sum_c x[i,c] * q[c] (+ bias[0]); products_rounded != 0: every product is rounded to the dtype first
+ * (`(ground_hidden * object_features).sum(dim=-1)`, :285), 0: a Linear(C, 1) row (:81-84).
+ * v3d_relu_mul_rows: x[i,c] = relu?(x[i,c]) * (row ? row[c] : 1) in place (nn.ReLU; `obj_feat * query_feat`, :290). */
+int v3d_row_dots(const void* x, int64_t ldx, int n_rows, const void* q, int C, const void* bias, int products_rounded,
+                 void* out, int dtype, void* stream);
+int v3d_relu_mul_rows(void* x, int64_t ldx, int n_rows, int cols, const void* row, int relu, int dtype, void* stream);
 
 /* llava_arch.py:482-501: out[o] = mean of the rows t of feat [T,C] with mask[o,t] != 0 (zeros if none)
  * (+ add[o] if add != NULL: the box-centre PE). */

@@ -757,6 +757,80 @@ def g_world_coords():
          aligned_f32=torch.stack([torch.from_numpy(align) @ torch.from_numpy(p_) for p_ in poses]).float().numpy())
 
 
+def g_ground_variants():
+    """The grounding variants the shipped scripts never select: object_feature_type 'patch27' (llava_arch.py:367-371, 485-486:
+    the reference's own lines, executed as in g_objects) and ground_head_type 'mlp' / 'score' (llava_qwen.py:57-91, 283-292: the
+    reference's own LlavaQwenForCausalLM.predict_box, its decoder replaced by a stub that returns a stored hidden state).  The
+    heads' weights come from seeds (oracle/llm_oracle.py seeded_ground_head); the fixture keeps a checksum of them."""
+    import textwrap
+    from llava.model.language_model import llava_qwen as lq
+    from llava.model.position_encoding import PositionEmbeddingSine3D
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from llm_oracle import seeded_ground_head
+    with open(REF + "/llava/model/llava_arch.py") as f:
+        lines = f.read().split("\n")
+    a0 = next(i for i, l in enumerate(lines) if 'object_boxes = video_dict["objects"][0]' in l)
+    a1 = next(i for i, l in enumerate(lines) if "use_mrope_position_embedding = False" in l)
+    b0 = next(i for i, l in enumerate(lines) if "object_features = []" in l and i > a1)
+    b1 = next(i for i, l in enumerate(lines) if "object_features += box_center_features" in l) + 1
+    blk_a = textwrap.dedent("\n".join(lines[a0:a1]))
+    blk_b = textwrap.dedent("\n".join(lines[b0:b1]))
+    C, Fr = 96, 2
+    g = torch.Generator().manual_seed(61)
+    m = make_arch(dict(DEFAULT_CFG, object_feature_type="patch27-pe"))
+    m.model.world_position_embedding = PositionEmbeddingSine3D(C)
+    out = {}
+    lo = (torch.rand(Fr, 48, 48, 3, generator=g) - 0.5) * torch.tensor([8.0, 8.0, 3.0])
+    coords = lo.repeat_interleave(8, 1).repeat_interleave(8, 2).half().float()            # 8 x 8 constant regions (stored low-res)
+    boxes = torch.cat([(torch.rand(7, 3, generator=g) - 0.5) * torch.tensor([6.0, 6.0, 2.0]), torch.rand(7, 3, generator=g) * 5 + 1.5], 1)
+    boxes[6] = torch.tensor([50.0, 50.0, 50.0, 0.1, 0.1, 0.1])        # selects nothing -> zero feature
+    feats = torch.randn(Fr, 729, C, generator=g).half().float()      # fp16-representable: one stored array serves both dtypes
+    for name, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        ns = dict(torch=torch, self=m, video_dict={"world_coords": coords.to(dt)[None], "objects": boxes.to(dt)[None]}, int=int)
+        exec(compile(blk_a, "<llava_arch object masks>", "exec"), ns)
+        centers = m.discrete_coords(ns["object_boxes_center"], None)
+        enc = feats.to(dt)
+        ns.update(image_features=[m.get_2dPool(enc)], encoded_image_features=[enc], use_mlp_pe=False, use_sin3d_pe=True,
+                  object_boxes_center=centers)
+        exec(compile(blk_b, "<llava_arch object features>", "exec"), ns)
+        out["mask27_" + name] = torch.stack(ns["object_patch"]).numpy()
+        out["objfeat27_" + name] = ns["object_features"].float().numpy()
+    assert out["mask27_f32"].any() and not out["mask27_f32"][6].any()
+    # the heads
+    H, T, n_obj = 128, 12, 9
+    hidden = torch.randn(1, T, H, generator=g).to(torch.bfloat16).float()
+    objf = torch.randn(n_obj, H, generator=g).to(torch.bfloat16).float()
+    labels = torch.full((1, T), -100)
+    labels[0, 7] = 318
+
+    class Trunk(torch.nn.Module):                  # stands in for LlavaQwenModel: predict_box only takes outputs[0] from it
+        def forward(self, **kw):
+            return (self.h,)
+
+    for kind, seed in (("mlp", 811), ("score", 812)):
+        cfg = lq.LlavaQwenConfig(vocab_size=320, hidden_size=H, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1,
+                                 num_key_value_heads=1, max_position_embeddings=64, rms_norm_eps=1e-6, rope_theta=1000000.0,
+                                 use_sliding_window=False, attention_dropout=0.0)
+        cfg.rope_theta = 1000000.0
+        cfg._attn_implementation = "eager"
+        cfg.ground_head_type, cfg.ground_head_temperature, cfg.ground_token_ids = kind, 0.07, [318]
+        model = lq.LlavaQwenForCausalLM(cfg).eval()
+        w = seeded_ground_head(kind, H, seed)
+        missing, unexpected = model.load_state_dict(w, strict=False)
+        assert not unexpected and not [k for k in missing if k.startswith("ground_head")], (missing, unexpected)
+        model.model = Trunk()
+        out[kind + "_seed"] = np.int64(seed)
+        out[kind + "_checksum"] = np.float64(sum(float(v.double().abs().sum()) for v in w.values()))
+        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            model.to(dt)
+            model.model.h = hidden.to(dt)
+            _, scores = model.predict_box(labels=labels, object_features=objf.to(dt), box_labels=None)
+            out[f"{kind}_scores_{name}"] = scores.float().numpy()
+        del model
+    save("ground_variants", coords_lo=lo.half().numpy(), boxes=boxes.numpy(), feats=feats.half().numpy(), hidden=hidden.numpy(),
+         objf=objf.numpy(), ground_row=np.int64(7), **out)
+
+
 GENS = {k[2:]: v for k, v in list(globals().items()) if k.startswith("g_")}
 
 

@@ -185,7 +185,8 @@ def projector(x, w, pfx="model.mm_projector."):
 def object_patch_mask(world_coords, boxes, cell=14, thresh_frac=0.5):
     """llava/model/llava_arch.py:351-376, object_feature_type 'patch14': per proposal box, the ViT patches
     (27 x 27 cells of 14 x 14 pixels over the first 378 rows/cols) with >= int(14*14*0.5) pixels inside the box.
-    world_coords [F,384,384,3], boxes [n,6] (centre, size), both in the model dtype -> bool [n,F,27,27]."""
+    ('patch27', :367-371: cell=27, thresh_frac=0.25 - the 14 x 14 grid of the pooled tokens.)
+    world_coords [F,384,384,3], boxes [n,6] (centre, size), both in the model dtype -> bool [n,F,g,g], g = 378 // cell."""
     F_ = world_coords.shape[0]
     g = 378 // cell
     wc = world_coords[:, :378, :378, :].reshape(-1, g, cell, g, cell, 3).transpose(2, 3).flatten(3, 4)
@@ -204,7 +205,7 @@ def object_features(encoded, masks, centre_pe=None):
     C = encoded.shape[-1]
     feats = []
     for m in masks:
-        sel = encoded[m.view(-1, 729)]
+        sel = encoded[m.view(-1, encoded.shape[1])]          # 729 ViT rows ('patch14') or 196 pooled rows ('patch27', :485-486)
         feats.append(sel.mean(dim=0) if len(sel) else torch.zeros(C, dtype=encoded.dtype))
     f = torch.stack(feats)
     if centre_pe is not None:
@@ -217,6 +218,54 @@ def ground_head(x, w, pfx):
     h = F.relu(F.linear(x, w[pfx + "0.weight"], w[pfx + "0.bias"]))
     h = F.layer_norm(h, (h.shape[-1],), w[pfx + "2.weight"], w[pfx + "2.bias"], 1e-5)
     return F.linear(h, w[pfx + "3.weight"], w[pfx + "3.bias"])
+
+
+def mlp_scores(object_feats, query_hidden, w, pfx="ground_head."):
+    """predict_box, ground_head_type 'mlp', llava_qwen.py:59-71, 283-285: the MLP on the <ground> hidden state, then the
+    elementwise product with the object features summed over the channels -> [n]."""
+    return (ground_head(query_hidden, w, pfx).squeeze(0) * object_feats).sum(dim=-1)
+
+
+def _ln_relu_head(x, w, pfx, last=True):
+    """nn.Sequential(Linear, LayerNorm, ReLU[, Linear]), llava_qwen.py:74-91."""
+    h = F.linear(x, w[pfx + "0.weight"], w[pfx + "0.bias"])
+    h = F.relu(F.layer_norm(h, (h.shape[-1],), w[pfx + "1.weight"], w[pfx + "1.bias"], 1e-5))
+    return F.linear(h, w[pfx + "3.weight"], w[pfx + "3.bias"]) if last else h
+
+
+def score_scores(object_feats, query_hidden, w):
+    """predict_box, ground_head_type 'score', llava_qwen.py:72-91, 286-292: obj and query MLPs (width 1024), their product,
+    the scoring MLP -> [n]."""
+    obj = _ln_relu_head(object_feats.to(query_hidden.dtype), w, "ground_head_obj.")
+    q = _ln_relu_head(query_hidden, w, "ground_head_query.")
+    h = _ln_relu_head(obj * q, w, "ground_head_score.", last=False)
+    return F.linear(h, w["ground_head_score.3.weight"], w["ground_head_score.3.bias"]).squeeze(1)
+
+
+def seeded_ground_head(kind, hidden, seed):
+    """Weights of an 'mlp' / 'score' grounding head from a seed (the 'score' head's three 1024-wide MLPs are too large to store in
+    a fixture): tests/golden/ground_variants.npz holds the seeds, a checksum of what they produced and the REFERENCE's scores."""
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+
+    def lin(name, n_out, n_in, s):
+        w[name + ".weight"] = (torch.randn(n_out, n_in, generator=g) * s).to(torch.bfloat16).float()
+        w[name + ".bias"] = (torch.randn(n_out, generator=g) * 0.1).to(torch.bfloat16).float()
+
+    def ln(name, n):
+        w[name + ".weight"] = (1 + 0.1 * torch.randn(n, generator=g)).to(torch.bfloat16).float()
+        w[name + ".bias"] = (0.1 * torch.randn(n, generator=g)).to(torch.bfloat16).float()
+
+    if kind == "mlp":
+        lin("ground_head.0", hidden, hidden, 0.08); ln("ground_head.2", hidden); lin("ground_head.3", hidden, hidden, 0.08)
+    elif kind == "score":
+        for pfx, n_in in (("ground_head_obj", hidden), ("ground_head_query", hidden), ("ground_head_score", 1024)):
+            lin(pfx + ".0", 1024, n_in, 0.08 if n_in == hidden else 0.03)
+            ln(pfx + ".1", 1024)
+            lin(pfx + ".3", 1 if pfx == "ground_head_score" else 1024, 1024, 0.03)
+    else:
+        raise ValueError(kind)
+    return w
 
 
 def infonce_scores(object_feats, zero_target, query_hidden, w, obj_pfx="ground_head_obj.", q_pfx="ground_head_query."):

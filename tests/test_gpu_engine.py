@@ -100,6 +100,51 @@ def test_grounding_kernels_golden(golden):
     np.testing.assert_allclose(ops.ground_scores(o, q).float().cpu().numpy(), want.numpy(), atol=3e-3)
 
 
+def test_object_features_patch27_golden(golden):
+    """object_feature_type 'patch27' on the device against the reference's own lines (tests/golden/ground_variants.npz): masks of
+    the 27-pixel cells bit-exact, Engine.object_features (pool -> masked mean -> + centre PE) within f16 rounding."""
+    from v3d import ops
+    from v3d.engine import Engine, random_state_dict
+    g = golden("ground_variants")
+    dt = torch.float16
+    coords = torch.from_numpy(g["coords_lo"]).float().repeat_interleave(8, 1).repeat_interleave(8, 2).to(dt).cuda()
+    boxes = torch.from_numpy(g["boxes"]).to(dt).cuda()
+    mask = ops.object_patch_mask(coords, boxes, cell=27, thresh=int(27 * 27 * 0.25))
+    assert np.array_equal(mask.cpu().numpy().astype(bool), g["mask27_f16"])
+    cfg = tiny_cfg()
+    cfg.object_feature_type = "patch27-pe"
+    cfg.llm.hidden = 96                       # only object_features is used: pool + mean + PE at the fixture's width
+    eng = object.__new__(Engine)
+    eng.cfg, eng.device, eng.dtype = cfg, torch.device("cuda"), dt
+    eng.pe_table = ops.Sin3DTable(96, 301, dt, "cuda")
+    objf = eng.object_features(torch.from_numpy(g["feats"]).to(dt).cuda(), coords, boxes)
+    np.testing.assert_allclose(objf.float().cpu().numpy(), g["objfeat27_f16"], rtol=0, atol=3e-3)
+
+
+@pytest.mark.parametrize("kind", ["mlp", "score"])
+def test_ground_head_variants_golden(golden, kind):
+    """ground_head_type 'mlp' / 'score' on the device against the reference's own predict_box (bf16 run of the same seeded weights)."""
+    from oracle import llm_oracle as L
+    from v3d.engine import Engine
+    g = golden("ground_variants")
+    w = L.seeded_ground_head(kind, 128, int(g[kind + "_seed"]))
+    assert abs(sum(float(v.double().abs().sum()) for v in w.values()) - float(g[kind + "_checksum"])) < 1e-6
+    dt = torch.bfloat16
+    cfg = tiny_cfg()
+    cfg.ground_head_type = kind
+    eng = object.__new__(Engine)
+    eng.cfg, eng.device, eng.dtype = cfg, torch.device("cuda"), dt
+    eng.ground = {k: v.to(dt).cuda().contiguous() for k, v in w.items()}
+    query = torch.from_numpy(g["hidden"])[0, int(g["ground_row"])][None].to(dt).cuda().contiguous()
+    got = eng.ground_head(query, torch.from_numpy(g["objf"]).to(dt).cuda())
+    want = g[kind + "_scores_bf16"]
+    assert got.shape == (9,)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=0, atol=4e-2 * max(scale, 1.0))
+    # and tighter against the f32 scores, relative to their spread (bf16 rounding of ~1e3-term sums)
+    assert np.corrcoef(got.float().cpu().numpy(), g[kind + "_scores_f32"])[0, 1] > 0.999
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 4e-2), (torch.float16, 6e-3)])
 def test_scene_grounding_matches_oracle(dt, tol):
     """ScanRefer-style forward on the tiny model: patch masks bit-exact, object features and infonce scores within tolerance."""

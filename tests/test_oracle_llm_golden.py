@@ -84,3 +84,32 @@ def test_infonce_scores(golden):
     s = L.infonce_scores(torch.from_numpy(g["objfeat_f32"]), torch.from_numpy(g["zero_target"]), torch.from_numpy(g["query"]),
                          w, "ho.", "hq.")
     np.testing.assert_allclose(s.numpy(), g["scores"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_object_features_patch27(golden, name, dt):
+    """object_feature_type 'patch27' (llava_arch.py:367-371, 485-486) against the reference's own lines: the masks over the 14 x 14
+    grid of 27-pixel cells bit-exact, the means of the POOLED rows + centre PE to 1 ulp16."""
+    g = golden("ground_variants")
+    coords = torch.from_numpy(g["coords_lo"]).float().repeat_interleave(8, 1).repeat_interleave(8, 2).to(dt)
+    boxes = torch.from_numpy(g["boxes"]).to(dt)
+    masks = L.object_patch_mask(coords, boxes, cell=27, thresh_frac=0.25)
+    assert masks.shape[1:] == (2, 14, 14) and np.array_equal(masks.numpy(), g["mask27_" + name])
+    centres = torch.from_numpy(O.discrete_coords(boxes[:, :3].float().numpy(), name)).to(dt)
+    pe = torch.from_numpy(O.sin3d_pe(centres.float().numpy()[None], 96, name)[0]).to(dt)
+    pooled = torch.from_numpy(O.get_2dpool_bilinear(g["feats"].astype(np.float32), name)).to(dt)
+    f = L.object_features(pooled.view(2, 196, 96), masks, pe)
+    np.testing.assert_allclose(f.float().numpy(), g["objfeat27_" + name], rtol=0, atol=2e-6 if name == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("kind", ["mlp", "score"])
+def test_ground_head_variants(golden, kind):
+    """ground_head_type 'mlp' / 'score' (llava_qwen.py:57-91, 283-292) against the reference's own predict_box on seeded weights."""
+    g = golden("ground_variants")
+    w = L.seeded_ground_head(kind, 128, int(g[kind + "_seed"]))
+    assert abs(sum(float(v.double().abs().sum()) for v in w.values()) - float(g[kind + "_checksum"])) < 1e-6, \
+        "torch's CPU generator no longer reproduces the weights the fixture's scores were made with"
+    query = torch.from_numpy(g["hidden"])[0, int(g["ground_row"])][None]
+    objf = torch.from_numpy(g["objf"])
+    s = L.mlp_scores(objf, query, w) if kind == "mlp" else L.score_scores(objf, query, w)
+    np.testing.assert_allclose(s.numpy(), g[kind + "_scores_f32"], rtol=1e-5, atol=1e-5)

@@ -79,7 +79,12 @@ def test_overlay_alone_exports_registers_and_refuses_unknown_arguments(tmp_path)
         ec = loader.engine_config(cfg, sd)
         print("CFG", ec.vit.hidden, ec.vit.layers, ec.vit.heads, ec.vit.inter, ec.llm.hidden, ec.llm.layers, ec.llm.heads, ec.llm.kv_heads,
               ec.llm.inter, ec.llm.vocab, ec.llm.max_pos)
+        print("GROUND", ec.ground_head_type, ec.object_feature_type)
+        cfg.ground_head_type, cfg.object_feature_type = "score", "patch27-pe"        # the variants no shipped script selects
+        ec = loader.engine_config(cfg, sd)
+        print("GROUND", ec.ground_head_type, ec.object_feature_type)
         """, [OVERLAY])
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.count("REFUSED") == 3, r.stdout
     assert "CFG 144 2 2 272 256 2 2 1 384 320 2048" in r.stdout, r.stdout
+    assert "GROUND infonce patch14-pe" in r.stdout and "GROUND score patch27-pe" in r.stdout, r.stdout

@@ -8,8 +8,9 @@ namespace v3d {
 // llava_arch.py:357-372 ('patch14'): cell (py,px) of frame f is selected for box o iff at least `thresh` of its
 // cell x cell pixels satisfy lo <= xyz <= hi in all three axes (comparisons in the tensor dtype: the bounds
 // lo = c - s/2, hi = c + s/2 are rounded to T like the reference's tensor arithmetic).
-// One wave per cell; pixels over lanes (4 passes for 196), boxes looped, ballot + popcount.
-template <typename T>
+// ('patch27', :367-371: 27 x 27-pixel cells, the grid of the POOLED tokens, thresh = int(27*27*0.25).)
+// One wave per cell; pixels over lanes (ITERS passes of 64: 4 for 196 pixels, 12 for 729), boxes looped, ballot + popcount.
+template <typename T, int ITERS>
 __global__ __launch_bounds__(256) void object_patch_mask_kernel(const T* __restrict__ coords, int F_, int S, int grid, int cell,
                                                                 const T* __restrict__ boxes, int n_obj, int thresh,
                                                                 uint8_t* __restrict__ mask) {
@@ -19,10 +20,10 @@ __global__ __launch_bounds__(256) void object_patch_mask_kernel(const T* __restr
   if (cell_id >= n_cells) return;
   const int f = cell_id / (grid * grid), rem = cell_id - f * grid * grid, py = rem / grid, px = rem - py * grid;
   const int npix = cell * cell;
-  float x[4][3];
-  bool valid[4];
+  float x[ITERS][3];
+  bool valid[ITERS];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < ITERS; ++it) {
     const int idx = it * 64 + lane;
     valid[it] = idx < npix;
     const int r = valid[it] ? idx / cell : 0, c = valid[it] ? idx - (idx / cell) * cell : 0;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void object_patch_mask_kernel(const T* __restr
     }
     int cnt = 0;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
       const bool in = valid[it] && lo[0] <= x[it][0] && x[it][0] <= hi[0] && lo[1] <= x[it][1] && x[it][1] <= hi[1] &&
                       lo[2] <= x[it][2] && x[it][2] <= hi[2];
       cnt += __popcll(__ballot(in));
@@ -108,6 +109,40 @@ __global__ __launch_bounds__(256) void ground_scores_kernel(const T* __restrict_
   if (tid == 0) scores[i] = from_f32<T>(red[2][0] + red[2][1] + red[2][2] + red[2][3]);
 }
 
+
+// The 'mlp' and 'score' grounding heads (llava_qwen.py:59-86, 283-293) beside the shipped 'infonce' one - small row work:
+//   row_dots:       out[i] = sum_c x[i, c] * q[c] (+ bias).  PRODUCTS_ROUNDED: `(ground_hidden * object_features).sum(-1)` of the 'mlp'
+//                   head (an elementwise product in the tensor dtype, then a sum); otherwise a Linear(C, 1) (f32 products).
+//   relu_mul_rows:  x[i, c] = relu?(x[i, c]) * (row ? row[c] : 1), in place (nn.ReLU; `obj_feat * query_feat`).
+template <typename T, bool PRODUCTS_ROUNDED>
+__global__ __launch_bounds__(256) void row_dots_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ q, int C,
+                                                       const T* __restrict__ bias, T* __restrict__ out) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* row = x + (size_t)i * ldx;
+  float dot = 0.f;
+  for (int c = tid; c < C; c += 256) {
+    const float pr = to_f32(row[c]) * to_f32(q[c]);
+    dot += PRODUCTS_ROUNDED ? round_to<T>(pr) : pr;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+  if (lane == 0) red[wave] = dot;
+  __syncthreads();
+  if (tid == 0) out[i] = from_f32<T>(red[0] + red[1] + red[2] + red[3] + (bias ? to_f32(bias[0]) : 0.f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_mul_rows_kernel(T* __restrict__ x, int64_t ldx, int cols, const T* __restrict__ row, int relu) {
+  T* r = x + (size_t)blockIdx.x * ldx;
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float v = to_f32(r[c]);
+    if (relu) v = fmaxf(v, 0.f);
+    if (row) v = v * to_f32(row[c]);
+    r[c] = from_f32<T>(v);
+  }
+}
+
 }  // namespace v3d
 
 using namespace v3d;
@@ -115,13 +150,19 @@ using namespace v3d;
 extern "C" int v3d_object_patch_mask(const void* coords, int dtype, int F_, int S, int cell, const void* boxes, int n_obj,
                                      int thresh, uint8_t* mask, void* stream) {
   V3D_REQUIRE(coords && boxes && mask, "v3d_object_patch_mask: null pointer");
-  V3D_REQUIRE(F_ > 0 && S > 0 && cell > 0 && cell * cell <= 256 && n_obj >= 0, "v3d_object_patch_mask: bad shape");
+  V3D_REQUIRE(F_ > 0 && S > 0 && cell > 0 && cell * cell <= 768 && n_obj >= 0, "v3d_object_patch_mask: bad shape");
   if (n_obj == 0) return V3D_OK;
   const int grid = (S - 6) / cell;                       // [:378,:378] of 384 -> 27 cells of 14 (llava_arch.py:366)
   const int n_cells = F_ * grid * grid;
-  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(object_patch_mask_kernel<T>, dim3((n_cells + 3) / 4), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)coords, F_, S, grid, cell, (const T*)boxes, n_obj,
-                                               thresh, mask));
+  if (cell * cell <= 256) {
+    V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((object_patch_mask_kernel<T, 4>), dim3((n_cells + 3) / 4), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)coords, F_, S, grid, cell, (const T*)boxes, n_obj,
+                                                 thresh, mask));
+  } else {
+    V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((object_patch_mask_kernel<T, 12>), dim3((n_cells + 3) / 4), dim3(256), 0,
+                                                 (hipStream_t)stream, (const T*)coords, F_, S, grid, cell, (const T*)boxes, n_obj,
+                                                 thresh, mask));
+  }
   return check_launch("v3d_object_patch_mask");
 }
 
@@ -144,4 +185,23 @@ extern "C" int v3d_ground_scores(const void* obj, int64_t ldo, int n_rows, const
   else if (dtype == V3D_F16) hipLaunchKernelGGL(ground_scores_kernel<f16_t>, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (const f16_t*)obj, ldo, (const f16_t*)query, C, (f16_t*)scores);
   else { set_error("v3d_ground_scores: dtype must be f16 or bf16"); return V3D_E_INVALID; }
   return check_launch("v3d_ground_scores");
+}
+
+extern "C" int v3d_row_dots(const void* x, int64_t ldx, int n_rows, const void* q, int C, const void* bias, int products_rounded,
+                            void* out, int dtype, void* stream) {
+  V3D_REQUIRE(x && q && out && n_rows > 0 && C > 0 && ldx >= C, "v3d_row_dots: bad arguments");
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_row_dots: dtype must be f16 or bf16");
+#define V3D_RD(T, R) hipLaunchKernelGGL((row_dots_kernel<T, R>), dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, (const T*)q, C, (const T*)bias, (T*)out)
+  if (dtype == V3D_BF16) { if (products_rounded) V3D_RD(bf16_t, true); else V3D_RD(bf16_t, false); }
+  else { if (products_rounded) V3D_RD(f16_t, true); else V3D_RD(f16_t, false); }
+#undef V3D_RD
+  return check_launch("v3d_row_dots");
+}
+
+extern "C" int v3d_relu_mul_rows(void* x, int64_t ldx, int n_rows, int cols, const void* row, int relu, int dtype, void* stream) {
+  V3D_REQUIRE(x && n_rows > 0 && cols > 0 && ldx >= cols, "v3d_relu_mul_rows: bad arguments");
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "v3d_relu_mul_rows: dtype must be f16 or bf16");
+  if (dtype == V3D_BF16) hipLaunchKernelGGL(relu_mul_rows_kernel<bf16_t>, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx, cols, (const bf16_t*)row, relu);
+  else hipLaunchKernelGGL(relu_mul_rows_kernel<f16_t>, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (f16_t*)x, ldx, cols, (const f16_t*)row, relu);
+  return check_launch("v3d_relu_mul_rows");
 }

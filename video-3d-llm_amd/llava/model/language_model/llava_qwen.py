@@ -73,8 +73,8 @@ class LlavaQwenForCausalLM(nn.Module, LlavaMetaForCausalLM):
                              llm_fp8=llm_fp8)
         self._device, self._dtype = device, dtype
         self.ground_head_type = getattr(config, "ground_head_type", None)
-        if self.ground_head_type not in (None, "infonce"):
-            raise NotImplementedError(f"ground_head_type {self.ground_head_type!r}: only 'infonce' (the shipped config) is on the accelerated path")
+        if self.ground_head_type not in (None, "infonce", "mlp", "score"):                      # llava_qwen.py:57-104
+            raise NotImplementedError(f"ground_head_type {self.ground_head_type!r}: the reference defines 'infonce', 'mlp' and 'score'")
         tower = SigLipVisionTower(getattr(config, "mm_vision_tower", "siglip"), vision_tower_cfg=config).bind(self.engine)
         self.model = LlavaQwenModel(config, self.engine, tower)
         self.generation_eos = None

@@ -130,8 +130,9 @@ class LlavaMetaForCausalLM:
         vox = eng.voxel_ids(coords)
         object_features = object_boxes = None
         if use_object_proposals:
-            if "patch14" not in getattr(self.config, "object_feature_type", "patch14-pe"):
-                raise NotImplementedError("only object_feature_type 'patch14-pe' (the shipped config) is on the accelerated path")
+            oft = getattr(self.config, "object_feature_type", "patch14-pe")
+            if "patch14" not in oft and "patch27" not in oft:                                   # llava_arch.py:367-376
+                raise NotImplementedError(f"object_feature_type {oft!r}: the reference defines 'patch14*' and 'patch27*'")
             object_boxes = video_dict["objects"][0]
             object_features = eng.object_features(feats, coords, object_boxes.to(device=eng.device, dtype=eng.dtype).contiguous())
         box_input = video_dict.get("box_input")

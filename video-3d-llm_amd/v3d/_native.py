@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libv3d_hip.so")
 
 _lib = None
-ABI_VERSION = 4      # include/v3d.h V3D_ABI_VERSION
+ABI_VERSION = 5      # include/v3d.h V3D_ABI_VERSION
 
 
 class V3DError(RuntimeError):
@@ -80,6 +80,8 @@ SIGNATURES = {
     "v3d_object_patch_mask": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p]),
     "v3d_masked_mean": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "v3d_ground_scores": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "v3d_row_dots": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "v3d_relu_mul_rows": (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_p]),
     "v3d_rope_kv_store": (c_i, [c_p, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_l, c_p, c_l, c_i, c_p]),
     "v3d_add_row": (c_i, [c_p, c_l, c_p, c_i, c_i, c_p, c_i, c_p]),
     "v3d_copy_rows_bcast": (c_i, [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_l, c_i, c_p]),

@@ -57,6 +57,8 @@ class EngineConfig:
     min_xyz: tuple = (-15, -15, -5)
     max_xyz: tuple = (15, 15, 5)
     voxel_size: float = 0.1
+    ground_head_type: str = "infonce"      # llava_qwen.py:57-104: 'infonce' (the shipped checkpoints), 'mlp', 'score'
+    object_feature_type: str = "patch14-pe"  # llava_arch.py:367-376: 'patch14-*' (ViT patches) or 'patch27-*' (pooled tokens)
 
 
 def random_state_dict(cfg: EngineConfig, dtype, device, seed=0, std=0.02, ground_head=False):
@@ -158,8 +160,15 @@ class Engine:
         self._prep_vit(sd)
         self._prep_llm(sd)
         self.ground = None
-        if "ground_head_obj.0.weight" in sd:         # infonce grounding head (llava_qwen.py:87-104), optional
-            self.ground = {k: sd[k].contiguous() for k in sd if k.startswith("ground_head_")}
+        if any(k.startswith("ground_head") for k in sd):         # grounding head (llava_qwen.py:57-104), optional
+            if cfg.ground_head_type not in ("infonce", "mlp", "score"):
+                raise V3DError(f"ground_head_type {cfg.ground_head_type!r}: the reference has 'infonce', 'mlp' and 'score'")
+            need = {"infonce": "ground_head_obj.0.weight", "mlp": "ground_head.0.weight", "score": "ground_head_score.0.weight"}[cfg.ground_head_type]
+            if need not in sd:
+                raise V3DError(f"ground_head_type {cfg.ground_head_type!r} but the state dict has no {need}")
+            self.ground = {k: sd[k].contiguous() for k in sd if k.startswith("ground_head")}
+        if "patch27" not in cfg.object_feature_type and "patch14" not in cfg.object_feature_type:
+            raise V3DError(f"object_feature_type {cfg.object_feature_type!r}: the reference has 'patch14*' and 'patch27*' (llava_arch.py:367-376)")
         self.newline = sd["model.image_newline"].contiguous()
         self.embed = sd["model.embed_tokens.weight"].contiguous()
         n_ids = int(round((max(cfg.max_xyz[0] - cfg.min_xyz[0], cfg.max_xyz[1] - cfg.min_xyz[1],
@@ -604,29 +613,53 @@ class Engine:
         return self.predict_box(x, gpos, self.object_features(feats, coords, boxes))
 
     def predict_box(self, x, gpos, object_features):
-        """predict_box, ground_head_type 'infonce' (llava_qwen.py:280-300): x = the residual stream after the decoder (before the
-        final norm), gpos = the row of the <ground> label token, object_features [n, H] -> cosine scores [n + 1]."""
+        """predict_box (llava_qwen.py:280-300): x = the residual stream after the decoder (before the final norm), gpos = the row
+        of the <ground> label token, object_features [n, H] -> scores ([n + 1] for 'infonce': the last is the zero-target)."""
         if self.ground is None:
             raise V3DError("this engine was built without ground_head_* weights")
-        l, g = self.cfg.llm, self.ground
-        query = ops.rmsnorm(x[gpos: gpos + 1], self.l_norm, l.eps, out=self.l_last[1:2])        # outputs[0][ground_locations]
-        of = torch.cat([object_features, g["ground_head_zero_target"][None]], 0).contiguous()
+        query = ops.rmsnorm(x[gpos: gpos + 1], self.l_norm, self.cfg.llm.eps, out=self.l_last[1:2])        # outputs[0][ground_locations]
+        return self.ground_head(query, object_features)
 
-        def head(xin, pfx):
+    def ground_head(self, query, object_features):
+        """The grounding head on the normed hidden state of the <ground> token (query [1, H]) and the object features [n, H]:
+        'infonce' (llava_qwen.py:87-104, 294-300) cosine of two MLPs, zero-target appended; 'mlp' (:59-71, 283-285) one MLP on the
+        query, product-and-sum with the raw object features; 'score' (:72-86, 286-292) two MLPs, their product, a scoring MLP."""
+        g, kind = self.ground, self.cfg.ground_head_type
+
+        def relu_ln(xin, pfx):                       # Linear, ReLU, LayerNorm, Linear
             h = ops.gemm(xin, g[pfx + "0.weight"], bias=g[pfx + "0.bias"], epilogue=ops.EPI_BIAS_RELU)
             hn = ops.layernorm(h, g[pfx + "2.weight"], g[pfx + "2.bias"], 1e-5)
             return ops.gemm(hn, g[pfx + "3.weight"], bias=g[pfx + "3.bias"], epilogue=ops.EPI_BIAS)
 
-        return ops.ground_scores(head(of, "ground_head_obj."), head(query, "ground_head_query.")[0])      # K20
+        def ln_relu(xin, pfx, last=True):            # Linear, LayerNorm, ReLU (, Linear)
+            h = ops.gemm(xin, g[pfx + "0.weight"], bias=g[pfx + "0.bias"], epilogue=ops.EPI_BIAS)
+            hn = ops.relu_mul_rows(ops.layernorm(h, g[pfx + "1.weight"], g[pfx + "1.bias"], 1e-5))
+            return ops.gemm(hn, g[pfx + "3.weight"], bias=g[pfx + "3.bias"], epilogue=ops.EPI_BIAS) if last else hn
+
+        if kind == "infonce":
+            of = torch.cat([object_features, g["ground_head_zero_target"][None]], 0).contiguous()
+            return ops.ground_scores(relu_ln(of, "ground_head_obj."), relu_ln(query, "ground_head_query.")[0])      # K20
+        if kind == "mlp":
+            return ops.row_dots(object_features.contiguous(), relu_ln(query, "ground_head.")[0].contiguous(), products_rounded=True)
+        obj = ln_relu(object_features.contiguous(), "ground_head_obj.")
+        qf = ln_relu(query, "ground_head_query.")
+        mul = ops.relu_mul_rows(obj, row=qf[0].contiguous(), relu=False)                      # obj_feat * query_feat
+        hn = ln_relu(mul, "ground_head_score.", last=False)
+        return ops.row_dots(hn, g["ground_head_score.3.weight"][0].contiguous(), bias=g["ground_head_score.3.bias"])
 
     def object_features(self, feats, coords, boxes):
-        """Object-proposal features, object_feature_type 'patch14-pe' (llava_arch.py:351-376, 479-501): per box, the mean of
-        the projector rows of the ViT patches with >= 98 of their 196 pixels inside the box, plus the PE of the discretised box
-        centre.  feats [F,729,H] (encode_images), coords [F,384,384,3] and boxes [n,6] in the model dtype -> [n, H]."""
+        """Object-proposal features (llava_arch.py:351-376, 479-501): per box, the mean of the rows whose image cell has enough of
+        its pixels inside the box, plus the PE of the discretised box centre.  'patch14': the projector rows of the ViT patches
+        (27 x 27 cells of 14 pixels, >= 98 of 196 inside); 'patch27': the POOLED tokens before the PE (14 x 14 cells of 27 pixels,
+        >= 182 of 729).  feats [F,729,H] (encode_images), coords [F,384,384,3] and boxes [n,6] in the model dtype -> [n, H]."""
         H = self.cfg.llm.hidden
-        mask = ops.object_patch_mask(coords, boxes)                                               # K19
         centres = ops.discrete_coords(boxes[:, :3].contiguous(), self.cfg.min_xyz, self.cfg.max_xyz, self.cfg.voxel_size)
         pe = ops.sin3d_pe(centres[None], H, dim_t=self.pe_table.dim_t)[0]
+        if "patch27" in self.cfg.object_feature_type:
+            mask = ops.object_patch_mask(coords, boxes, cell=27, thresh=int(27 * 27 * 0.25))
+            rows = ops.visual_tokens(feats, side=27, n=self.cfg.pool_out, pool=True)          # get_2dPool alone: [F, 196, H]
+            return ops.masked_mean(rows.reshape(-1, H), mask.view(mask.shape[0], -1), add=pe)
+        mask = ops.object_patch_mask(coords, boxes)                                               # K19
         return ops.masked_mean(feats.reshape(-1, H), mask.view(mask.shape[0], -1), add=pe)
 
     # ------------------------------------------------------------------ generate (a23)

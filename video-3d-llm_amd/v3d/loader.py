@@ -88,7 +88,9 @@ def engine_config(hf_config, sd, max_positions=None):
                     rope_theta=float(getattr(c, "rope_theta", None) or (getattr(c, "rope_parameters", None) or {}).get("rope_theta", 1e6)),
                     max_pos=int(cap))
     return EngineConfig(vit=vit, llm=llm, min_xyz=tuple(getattr(c, "min_xyz_range", (-15, -15, -5))),
-                        max_xyz=tuple(getattr(c, "max_xyz_range", (15, 15, 5))), voxel_size=float(getattr(c, "voxel_size", 0.1)))
+                        max_xyz=tuple(getattr(c, "max_xyz_range", (15, 15, 5))), voxel_size=float(getattr(c, "voxel_size", 0.1)),
+                        ground_head_type=getattr(c, "ground_head_type", None) or "infonce",
+                        object_feature_type=getattr(c, "object_feature_type", None) or "patch14-pe")
 
 
 def drop_deleted_tower_layer(sd, tower_from_raw_siglip):

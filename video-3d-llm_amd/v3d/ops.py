@@ -620,6 +620,26 @@ def ground_scores(obj, query):
     return out
 
 
+def row_dots(x, q, bias=None, products_rounded=False):
+    """out[i] = sum_c x[i, c] * q[c] (+ bias[0]) - the 'mlp' head's product-and-sum (products_rounded) or a Linear(C, 1) row."""
+    n, C = x.shape
+    if q.numel() != C or q.dtype != x.dtype or x.stride(1) != 1 or not q.is_contiguous():
+        raise V3DError(f"row_dots: x {tuple(x.shape)} against q {tuple(q.shape)}")
+    out = torch.empty(n, dtype=x.dtype, device=x.device)
+    check(lib().v3d_row_dots(_p(x), x.stride(0), n, _p(q), C, _p(bias) if bias is not None else None, int(products_rounded), _p(out),
+                             _code(x), _stream()), "v3d_row_dots")
+    return out
+
+
+def relu_mul_rows(x, row=None, relu=True):
+    """In place: x[i, c] = relu?(x[i, c]) * (row[c] if row is given)."""
+    if x.dim() != 2 or x.stride(1) != 1 or (row is not None and (row.numel() != x.shape[1] or row.dtype != x.dtype or not row.is_contiguous())):
+        raise V3DError(f"relu_mul_rows: x {tuple(x.shape)}")
+    check(lib().v3d_relu_mul_rows(_p(x), x.stride(0), x.shape[0], x.shape[1], _p(row) if row is not None else None, int(relu), _code(x),
+                                  _stream()), "v3d_relu_mul_rows")
+    return x
+
+
 # ------------------------------------------------------------------------------ data movement
 
 
