@@ -53,6 +53,25 @@ def test_layernorm(ops, kind):
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_layernorm_three_rows_per_wave_form_equals_one_row_form_bitwise(ops, kind):
+    """Rows of at most 1536 elements in launches of >= 4096 rows take layernorm_kernel<3, 3> (three rows in flight per wave):
+    the same rows sent in chunks below 4096 take the one-row form - the outputs must agree bit for bit (ragged last wave,
+    padded row stride as the ViT's 1280)."""
+    g = torch.Generator().manual_seed(15)
+    rows, cols, ld = 4096 + 7, 1152, 1280
+    x = (torch.randn(rows, ld, generator=g) * 2 - 0.3).to(DT[kind]).cuda()[:, :cols]
+    w = (1 + 0.1 * torch.randn(cols, generator=g)).to(DT[kind]).cuda()
+    b = (0.1 * torch.randn(cols, generator=g)).to(DT[kind]).cuda()
+    full = torch.full((rows + 1, ld), 7.0, dtype=DT[kind], device="cuda")
+    ops.layernorm(x, w, b, 1e-6, out=full[:rows, :cols])
+    parts = torch.cat([ops.layernorm(x[i: i + 1024], w, b, 1e-6) for i in range(0, rows, 1024)])
+    assert torch.equal(full[:rows, :cols], parts)
+    assert bool((full[rows] == 7.0).all()) and bool((full[:rows, cols:] == 7.0).all())      # nothing written past the rows / columns
+    want = F.layer_norm(x.float().cpu(), (cols,), w.float().cpu(), b.float().cpu(), 1e-6).to(DT[kind])
+    close(full[:rows, :cols], want, kind, ulps=1.01)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
 def test_rope_table_and_apply(ops, kind):
     dt = DT[kind]
     S, H, KV, D = 700, 4, 2, 128

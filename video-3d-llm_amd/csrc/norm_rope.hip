@@ -52,48 +52,68 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
 }
 
 // nn.LayerNorm (siglip_encoder.py:272,274): f32 statistics, (x-mean)*rstd*w + b, one rounding.
-template <typename T>
+// One wave per R rows of at most MAXV * 512 elements.  R = 1, MAXV = 8 is the general form; SigLIP's 1152-wide rows are 2304 bytes,
+// a third of what a Qwen2 row keeps in flight per wave, so the <3, 3> form loads three rows before it reduces any (the same
+// per-row arithmetic in the same order: results are bit-identical) - the kernel is bound by bytes in flight, not by arithmetic.
+template <typename T, int MAXV, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                         const T* __restrict__ b, T* __restrict__ out, int64_t rows,
                                                         int cols, int64_t ldx, int64_t ldo, float eps) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
   const int nv = cols / 8;
-  const uint4* xr = reinterpret_cast<const uint4*>(x + row * ldx);
-  uint4 v[NORM_MAXV];
-  float s = 0.f;
+  uint4 v[R][MAXV];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < NORM_MAXV; ++i) {
-    const int k = i * 64 + lane;
-    if (k < nv) {
-      v[i] = xr[k];
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+    const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + row * ldx);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += vec_get<T>(v[i], j);
+    for (int i = 0; i < MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) v[r][i] = xr[k];
     }
   }
-  const float mean = wave_sum(s) / (float)cols;
-  float q = 0.f;
+  float mean[R], rstd[R];
 #pragma unroll
-  for (int i = 0; i < NORM_MAXV; ++i) {
-    const int k = i * 64 + lane;
-    if (k < nv) {
+  for (int r = 0; r < R; ++r) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = vec_get<T>(v[i], j) - mean; q = fmaf(d, d, q); }
+    for (int i = 0; i < MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[r] += vec_get<T>(v[r][i], j);
+      }
     }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
-  uint4* orow = reinterpret_cast<uint4*>(out + row * ldo);
+    mean[r] = wave_sum(s[r]) / (float)cols;
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NORM_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
+      const int k = i * 64 + lane;
+      if (k < nv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = vec_get<T>(v[r][i], j) - mean[r]; q = fmaf(d, d, q); }
+      }
+    }
+    rstd[r] = 1.0f / sqrtf(wave_sum(q) / (float)cols + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
     const int k = i * 64 + lane;
     if (k < nv) {
       const uint4 wv = reinterpret_cast<const uint4*>(w)[k];
       const uint4 bv = reinterpret_cast<const uint4*>(b)[k];
-      float y[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = (vec_get<T>(v[i], j) - mean) * rstd * vec_get<T>(wv, j) + vec_get<T>(bv, j);
-      orow[k] = vec_pack<T>(y);
+      for (int r = 0; r < R; ++r) {
+        if (row0 + r < rows) {
+          float y[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = (vec_get<T>(v[r][i], j) - mean[r]) * rstd[r] * vec_get<T>(wv, j) + vec_get<T>(bv, j);
+          reinterpret_cast<uint4*>(out + (row0 + r) * ldo)[k] = vec_pack<T>(y);
+        }
+      }
     }
   }
 }
@@ -326,8 +346,13 @@ extern "C" int v3d_layernorm(const void* x, int64_t ldx, const void* weight, con
   V3D_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= NORM_MAXV * 512, "v3d_layernorm: cols=%d unsupported", cols);
   V3D_REQUIRE(ldx % 8 == 0 && ldo % 8 == 0 && aligned16(x) && aligned16(out) && aligned16(weight) && aligned16(bias), "v3d_layernorm: alignment");
   if (rows == 0) return V3D_OK;
-  V3D_DISPATCH_16(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                                            (hipStream_t)stream, (const T*)x, (const T*)weight, (const T*)bias, (T*)out, rows, cols, ldx, ldo, eps));
+  if (cols <= 3 * 512 && rows >= 4096) {       // short rows, many of them: three rows in flight per wave
+    V3D_DISPATCH_16(dtype, hipLaunchKernelGGL((layernorm_kernel<T, 3, 3>), dim3((unsigned)((rows + 11) / 12)), dim3(256), 0,
+                                              (hipStream_t)stream, (const T*)x, (const T*)weight, (const T*)bias, (T*)out, rows, cols, ldx, ldo, eps));
+  } else {
+    V3D_DISPATCH_16(dtype, hipLaunchKernelGGL((layernorm_kernel<T, NORM_MAXV, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                              (hipStream_t)stream, (const T*)x, (const T*)weight, (const T*)bias, (T*)out, rows, cols, ldx, ldo, eps));
+  }
   return check_launch("v3d_layernorm");
 }
 
