@@ -9,7 +9,7 @@ loss.backward() + the optimizer for one sample (llava_qwen.py:121-205, train_mul
 Every product runs on v3d_gemm (out = A . W^T): with y = x . W^T (nn.Linear),
 
     dx = dy . W    = gemm(dy,   W^T)        W^T [K, N] by v3d_transpose
-    dW = dy^T . x  = gemm(dy^T, x^T)        dy^T [N, Mp], x^T [K, Mp]: the token rows become the k dimension, zero-padded to 64
+    dW = dy^T . x  = gemm(dy^T, x^T)        dy^T [N, Mp], x^T [K, Mp]: the token rows become the k dimension, zero-padded to 128
 
 so the backward costs two more products of the forward's size and three transposes.  Weights are in the checkpoint's layout
 (gate_proj / up_proj stacked as planar [gate | up] rows; the tower's 72-wide heads zero-padded to 128 by siglip_pad_layer), not the
@@ -22,6 +22,7 @@ products on v3d_gemm), kept as an independent cross-check.  Parity: tests/test_g
 f32 over the reference's formulae).  ground_sample_forward_backward is the grounding samples' step (infonce loss over object proposals).
 Not here: the other grounding head types, LoRA, the HF Trainer surface."""
 import math
+import os
 
 import torch
 
@@ -29,26 +30,89 @@ from . import ops
 from ._native import V3DError
 
 
-def _pad64(n):
-    return (n + 63) // 64 * 64
+# Weight gradients beside the backward chain.  Nothing in the backward reads a dW or db before the optimizer, so inside a whole-step
+# function (llm_forward_backward, sample_forward_backward, ground_sample_forward_backward) linear_backward sends them - two
+# transposes, the product, the bias column sums - to a SIDE stream: the HBM-bound transposes run under the main stream's products,
+# and products whose tile count leaves part of the chip idle (the tower's dW: 81-243 tiles of 128 x 128 for 512 slots, k = 23 328;
+# the last, partly filled round of a persistent launch) share it with the other stream's.  The step functions join the side stream
+# before they return.  Called on their own, the block functions stay on the caller's stream.  V3D_TRAIN_WGRAD_STREAM=0: one stream.
+_WGRAD = {"stream": None, "depth": 0, "streams": {}}
+
+
+class _wgrad_overlap:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.entered = False
+
+    def __enter__(self):
+        if self.device.type != "cuda" or os.environ.get("V3D_TRAIN_WGRAD_STREAM", "1") == "0":
+            return self
+        _WGRAD["depth"] += 1
+        if _WGRAD["depth"] == 1:
+            key = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            side = _WGRAD["streams"].get(key)
+            if side is None:
+                side = _WGRAD["streams"][key] = torch.cuda.Stream(device=self.device)
+            _WGRAD["stream"] = side
+        self.entered = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.entered:
+            _WGRAD["depth"] -= 1
+            if _WGRAD["depth"] == 0:
+                torch.cuda.current_stream(self.device).wait_stream(_WGRAD["stream"])      # every dW / db is complete for the caller
+                _WGRAD["stream"] = None
+        return False
+
+
+def _weight_grads(x, dy, need_dw, need_db):
+    """dW = dy^T . x as gemm(dy^T [N, Mp], x^T [K, Mp]) and db = column sums of dy.  Shapes are padded for the product's tiling, never
+    its value: the token rows (the k dimension) to 128, i.e. an EVEN number of 64-wide K-steps, which the 256 x 256 kernel's split-K
+    tail needs; and where K (dW's columns) is not a multiple of 256 but the reduction is long - the tower's 1152-wide operands over
+    23 328 token rows - x^T gets zero rows up to the next multiple of 256: the product then runs on the 256 x 256 kernel with its k
+    range split over the idle workgroups (70-85 tiles x 3 chunks) instead of one under-filled round of 128 x 128 tiles, and the zero
+    columns it produces are dropped."""
+    dw = db = None
+    if need_dw:
+        M, K = x.shape
+        Mp = (M + 127) // 128 * 128
+        dyt = ops.transpose(dy, out_cols=Mp)                          # [N, Mp]
+        Kp = (K + 255) // 256 * 256
+        if Kp != K and M >= 8192 and (Kp - K) * 8 <= K:
+            xt = torch.empty((Kp, Mp), dtype=x.dtype, device=x.device)
+            xt[K:].zero_()
+            ops.transpose(x, out_cols=Mp, out=xt[:K])
+            dw = ops.gemm(dyt, xt)[:, :K].contiguous()                # [N, K]
+        else:
+            xt = ops.transpose(x, out_cols=Mp)                        # [K, Mp]
+            dw = ops.gemm(dyt, xt)                                    # [N, K]
+    if need_db:
+        db = ops.colsum(dy)
+    return dw, db
 
 
 def linear_backward(x, w, dy, res=None, need_dx=True, need_dw=True, need_db=False):
     """y = x . w^T (+ b).  x [M, K], w [N, K], dy [M, N] (16-bit, HBM).  Returns (dx [M, K] (+ res) or None, dw [N, K] or None,
-    db [N] or None).  `res`: a gradient of dx's shape added in the product's epilogue (a residual branch)."""
-    M, K = x.shape
-    N = w.shape[0]
+    db [N] or None).  `res`: a gradient of dx's shape added in the product's epilogue (a residual branch).  Inside a step function
+    dw / db are produced on the side stream (see _wgrad_overlap): complete when that function returns, not before."""
     dx = dw = db = None
+    side = _WGRAD["stream"] if (need_dw or need_db) and x.is_cuda else None
+    if side is not None:
+        main = torch.cuda.current_stream(x.device)
+        side.wait_stream(main)                                        # x and dy are complete
+        with torch.cuda.stream(side):
+            dw, db = _weight_grads(x, dy, need_dw, need_db)
+        x.record_stream(side)                                         # their blocks are not handed out again before the side stream is done
+        dy.record_stream(side)
+        for t in (dw, db):
+            if t is not None:
+                t.record_stream(main)                                 # read (optimizer, accumulation) and freed on the caller's stream
     if need_dx:
         wt = ops.transpose(w)                                         # [K, N]
         dx = ops.gemm(dy, wt, res=res, epilogue=ops.EPI_RES if res is not None else ops.EPI_NONE)
-    if need_dw:
-        Mp = _pad64(M)
-        dyt = ops.transpose(dy, out_cols=Mp)                          # [N, Mp]
-        xt = ops.transpose(x, out_cols=Mp)                            # [K, Mp]
-        dw = ops.gemm(dyt, xt)                                        # [N, K]
-    if need_db:
-        db = ops.colsum(dy)
+    if side is None and (need_dw or need_db):
+        dw, db = _weight_grads(x, dy, need_dw, need_db)
     return dx, dw, db
 
 
@@ -184,15 +248,16 @@ def llm_forward_backward(params, x, labels, rope, n_q, n_kv, hd, eps=1e-6, recom
     activations are kept by default (about 1 GB per 7B layer at S = 6.8 k: 28 GB of the 288); recompute=True keeps only the layers'
     inputs and runs each layer's forward again in the backward, as the reference does under gradient checkpointing
     (train_multi.sh:72) - same numbers, a third more work, 27 GB less."""
-    h, saved = llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps, recompute)
-    n = ops.rmsnorm(h, params["norm"], eps)
-    logits = ops.gemm(n, params["lm_head"])
-    loss, st = ops.cross_entropy(logits, labels)
-    dlogits = ops.cross_entropy_grad(st)
-    dn, dw_head, _ = linear_backward(n, params["lm_head"], dlogits)
-    dh, dnorm = ops.rmsnorm_grad(h, params["norm"], dn, eps)
-    dx, layer_grads = llm_layers_backward(dh, saved, params, rope, n_q, n_kv, hd, eps)
-    return loss, dx, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
+    with _wgrad_overlap(x.device):
+        h, saved = llm_layers_forward(params, x, rope, n_q, n_kv, hd, eps, recompute)
+        n = ops.rmsnorm(h, params["norm"], eps)
+        logits = ops.gemm(n, params["lm_head"])
+        loss, st = ops.cross_entropy(logits, labels)
+        dlogits = ops.cross_entropy_grad(st)
+        dn, dw_head, _ = linear_backward(n, params["lm_head"], dlogits)
+        dh, dnorm = ops.rmsnorm_grad(h, params["norm"], dn, eps)
+        dx, layer_grads = llm_layers_backward(dh, saved, params, rope, n_q, n_kv, hd, eps)
+        return loss, dx, {"layers": layer_grads, "norm": dnorm, "lm_head": dw_head}
 
 
 class _LayerInput:
@@ -432,18 +497,19 @@ def sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids, post_
     coord_rows (device int64) / coord_pe [H]: Scan2Cap's <coord> rows and the box-centre PE added to them.
     recompute: activation re-computation per layer in both towers (the reference's gradient checkpointing, train_multi.sh:72).
     Returns (loss, grads in params' structure; "embed" is a dense [vocab, H] gradient with the text rows' sums)."""
-    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens, recompute)
-    pj = params["projector"]
-    y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
-    H = y.shape[1]
-    x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n, coord_rows, coord_pe)
-    loss, dx, llm_grads = llm_forward_backward(params["llm"], x, labels, rope, n_q, n_kv, hd, recompute=recompute)
-    d_embed = torch.zeros_like(params["embed"])
-    text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
-    dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
-    dfeat_in, pgrads = projector_backward(dfeat.view(frames * tokens, H), psaved, pj["w1"], pj["w2"])
-    vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
-    return loss, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed, "llm": llm_grads}
+    with _wgrad_overlap(patches.device):
+        feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens, recompute)
+        pj = params["projector"]
+        y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
+        H = y.shape[1]
+        x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n, coord_rows, coord_pe)
+        loss, dx, llm_grads = llm_forward_backward(params["llm"], x, labels, rope, n_q, n_kv, hd, recompute=recompute)
+        d_embed = torch.zeros_like(params["embed"])
+        text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
+        dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
+        dfeat_in, pgrads = projector_backward(dfeat.view(frames * tokens, H), psaved, pj["w1"], pj["w2"])
+        vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
+        return loss, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed, "llm": llm_grads}
 
 
 # ------------------------------------------------------------------------------ ZeRO-2 (scripts/zero2.json:22-34)
@@ -603,34 +669,35 @@ def ground_sample_forward_backward(params, patches, voxel_ids, pe_table, pre_ids
     positive uint8 [n_obj + 1] (the last entry = the zero-target, set when the sample has no target box).
     params additionally holds "ground": {"obj": head, "query": head, "zero_target" [H]} (head = {w0, b0, ln_w, ln_b, w3, b3}).
     Returns (loss, scores f32 [n_obj + 1], grads) - grads["llm"] has no "lm_head" entry (the LM head takes no part)."""
-    feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens, recompute)
-    pj, gp = params["projector"], params["ground"]
-    y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
-    H = y.shape[1]
-    x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n)
-    h, lsaved = llm_layers_forward(params["llm"], x, rope, n_q, n_kv, hd, eps, recompute)
-    # predict_box: the query is the final-norm hidden state of the <ground> row; the objects are masked means of the projector rows
-    hq = h[ground_row:ground_row + 1]
-    query_in = ops.rmsnorm(hq, params["llm"]["norm"], eps)
-    obj_feat = ops.masked_mean(y, obj_mask, add=box_pe)
-    of = torch.cat([obj_feat, gp["zero_target"][None].to(obj_feat.dtype)], 0).contiguous()
-    obj_out, osaved = _ground_head_forward(of, gp["obj"])
-    q_out, qsaved = _ground_head_forward(query_in, gp["query"])
-    loss, scores, d_obj_out, d_q_out = ops.ground_infonce(obj_out, q_out[0], positive, temperature)
-    # backward
-    d_of, g_obj = _ground_head_backward(d_obj_out, osaved, gp["obj"])
-    d_qin, g_query = _ground_head_backward(d_q_out[None].contiguous(), qsaved, gp["query"])
-    d_hq, d_norm = ops.rmsnorm_grad(hq, params["llm"]["norm"], d_qin, eps)
-    dh = torch.zeros_like(h)
-    ops.copy_rows(d_hq, dh[ground_row:ground_row + 1])
-    dx, layer_grads = llm_layers_backward(dh, lsaved, params["llm"], rope, n_q, n_kv, hd, eps)
-    d_embed = torch.zeros_like(params["embed"])
-    text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
-    dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
-    dy = dfeat.view(frames * tokens, H)
-    ops.masked_mean_grad(obj_mask, d_of[:-1].contiguous(), dy, accumulate=True)       # the object features' share of the projector rows' gradient
-    dfeat_in, pgrads = projector_backward(dy, psaved, pj["w1"], pj["w2"])
-    vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
-    return loss, scores, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed,
-                          "llm": {"layers": layer_grads, "norm": d_norm},
-                          "ground": {"obj": g_obj, "query": g_query, "zero_target": d_of[-1].contiguous()}}
+    with _wgrad_overlap(patches.device):
+        feat, vsaved = siglip_tower_forward(patches, params["vision"], frames, tokens, recompute)
+        pj, gp = params["projector"], params["ground"]
+        y, psaved = projector_forward(feat, pj["w1"], pj["b1"], pj["w2"], pj["b2"])
+        H = y.shape[1]
+        x, n_pre, n_vis = _build_inputs_embeds(params, y, voxel_ids, pe_table, pre_ids, post_ids, frames, tokens, side, n)
+        h, lsaved = llm_layers_forward(params["llm"], x, rope, n_q, n_kv, hd, eps, recompute)
+        # predict_box: the query is the final-norm hidden state of the <ground> row; the objects are masked means of the projector rows
+        hq = h[ground_row:ground_row + 1]
+        query_in = ops.rmsnorm(hq, params["llm"]["norm"], eps)
+        obj_feat = ops.masked_mean(y, obj_mask, add=box_pe)
+        of = torch.cat([obj_feat, gp["zero_target"][None].to(obj_feat.dtype)], 0).contiguous()
+        obj_out, osaved = _ground_head_forward(of, gp["obj"])
+        q_out, qsaved = _ground_head_forward(query_in, gp["query"])
+        loss, scores, d_obj_out, d_q_out = ops.ground_infonce(obj_out, q_out[0], positive, temperature)
+        # backward
+        d_of, g_obj = _ground_head_backward(d_obj_out, osaved, gp["obj"])
+        d_qin, g_query = _ground_head_backward(d_q_out[None].contiguous(), qsaved, gp["query"])
+        d_hq, d_norm = ops.rmsnorm_grad(hq, params["llm"]["norm"], d_qin, eps)
+        dh = torch.zeros_like(h)
+        ops.copy_rows(d_hq, dh[ground_row:ground_row + 1])
+        dx, layer_grads = llm_layers_backward(dh, lsaved, params["llm"], rope, n_q, n_kv, hd, eps)
+        d_embed = torch.zeros_like(params["embed"])
+        text_rows = torch.cat([torch.arange(n_pre, device=x.device), torch.arange(n_pre + n_vis, x.shape[0], device=x.device)])
+        dfeat, d_newline = inputs_embeds_backward(dx, n_pre, frames, text_rows, torch.cat([pre_ids, post_ids]), d_embed, side=side, n=n)
+        dy = dfeat.view(frames * tokens, H)
+        ops.masked_mean_grad(obj_mask, d_of[:-1].contiguous(), dy, accumulate=True)       # the object features' share of the projector rows' gradient
+        dfeat_in, pgrads = projector_backward(dy, psaved, pj["w1"], pj["w2"])
+        vgrads = siglip_tower_backward(dfeat_in, vsaved, params["vision"], frames, tokens)
+        return loss, scores, {"vision": vgrads, "projector": pgrads, "newline": d_newline, "embed": d_embed,
+                              "llm": {"layers": layer_grads, "norm": d_norm},
+                              "ground": {"obj": g_obj, "query": g_query, "zero_target": d_of[-1].contiguous()}}
