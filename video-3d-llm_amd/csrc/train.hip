@@ -218,22 +218,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
   for (int j = 0; j < 8; ++j) o[j] = s[j];
 }
 
-// out[c] = sum of the partials: thread (c, g) of a 64-column workgroup (16 groups) sums the partials b = g, g + 16, ... in order, the
-// sixteen group sums are added in order (a fixed tree: run-to-run identical)
+// out[c] = sum of the partials: thread (c, g) of a 16-column workgroup (64 groups) sums the partials b = g, g + 64, ... in order, the
+// sixty-four group sums are added in order (a fixed tree: run-to-run identical).  16 columns per workgroup: cols / 16 workgroups
+// (72 for the tower's 1152, 224 for 3584) instead of cols / 64 - the kernel is a latency chain per thread, so it wants the chip.
 template <typename TO>
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int64_t n_part, int cols, TO* __restrict__ out) {
-  __shared__ float red[16][64];
-  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ float red[64][16];
+  const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
   if (c < cols)
-    for (int64_t b = g; b < n_part; b += 16) s += partial[b * cols + c];
+    for (int64_t b = g; b < n_part; b += 64) s += partial[b * cols + c];
   red[g][cl] = s;
   __syncthreads();
   if (g == 0 && c < cols) {
     float t = red[0][cl];
 #pragma unroll
-    for (int i = 1; i < 16; ++i) t += red[i][cl];
+    for (int i = 1; i < 64; ++i) t += red[i][cl];
     out[c] = from_f32<TO>(t);
   }
 }
@@ -854,7 +855,7 @@ extern "C" int64_t v3d_colsum_workspace_bytes(int64_t rows, int cols) {
 }
 
 static int colsum_final(const float* partial, int64_t n_part, int cols, void* out, int out_dtype, hipStream_t st, const char* what) {
-  const dim3 grid((cols + 63) / 64);
+  const dim3 grid((cols + 15) / 16);
   switch (out_dtype) {
     case V3D_F32: hipLaunchKernelGGL(colsum_final_kernel<float>, grid, dim3(1024), 0, st, partial, n_part, cols, (float*)out); break;
     case V3D_F16: hipLaunchKernelGGL(colsum_final_kernel<f16_t>, grid, dim3(1024), 0, st, partial, n_part, cols, (f16_t*)out); break;
