@@ -539,11 +539,18 @@ def main():
         attn_us = stamps["attn"].mean_us()
         attn_flops = 2.0 * S * S * 128 * 28                                   # causal: half of 4*S^2*d*H
         traffic, traffic_note, attn_busy, gemm_busy = None, None, None, None
+        gemm_traffic, attn_traffic, mfma_traffic_note = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             pm = json.load(open(pmc))
             attn_busy = pm.get("attention_mfma_busy_frac")       # PMC: MFMA-busy share of SIMD cycles at the actual clock
             gemm_busy = pm.get("gemm_gate_up_mfma_busy_frac")
+            # the MFMA-bound kernels' memory-side traffic (fabric requests: Infinity-Cache hits included, so an upper bound of HBM bytes)
+            if not a.fp8 and pm.get("gemm_source_sha") == kernel_source_sha("gemm.hip"):
+                gemm_traffic = pm.get("gemm_gate_up_fabric_bytes_per_launch")
+            if pm.get("attention_source_sha") == kernel_source_sha("attention.hip"):
+                attn_traffic = pm.get("attention_fabric_bytes_per_launch")
+            mfma_traffic_note = pm.get("gemm_attention_traffic_note")
             sha = kernel_source_sha("visual_tokens.hip")
             if pm.get("visual_tokens_source_sha") == sha:
                 traffic = pm.get("visual_tokens_hbm_bytes_per_launch")
@@ -570,14 +577,17 @@ def main():
             "roofline": {"kernel": "%s (Qwen2 gate/up + SwiGLU, M=%d N=37888 K=3584): the largest share of the step" %
                                    ("gemm_fp8_kernel" if a.fp8 else "gemm256pp_kernel", S), "bound": "mfma",
                          "achieved": gemm_flops / gemm_us / 1e6, "peak": gemm_peak, "unit": "TFLOP/s",
-                         "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": None, "us_per_launch": gemm_us,
-                         "algorithmic_flops": gemm_flops, "mfma_busy_frac_pmc": None if a.fp8 else gemm_busy},
+                         "frac": gemm_flops / gemm_us / 1e6 / gemm_peak, "traffic": gemm_traffic, "traffic_note": mfma_traffic_note if gemm_traffic else None,
+                         "us_per_launch": gemm_us, "algorithmic_flops": gemm_flops,
+                         "algorithmic_bytes": (S * 3584 + 37888 * 3584) * (1 if a.fp8 else 2) + S * 18944 * 2,
+                         "mfma_busy_frac_pmc": None if a.fp8 else gemm_busy},
             "roofline_north_star": {"kernel": "visual_tokens_kernel (bilinear pool + 3D-PE add + newline, K5-K8)", "bound": "hbm",
                                     "achieved": pe_bytes / pe_us / 1e3, "peak": 8000.0, "unit": "GB/s", "frac": pe_bytes / pe_us / 1e3 / 8000.0,
                                     "traffic": traffic, "traffic_note": traffic_note, "us_per_launch": pe_us, "algorithmic_bytes": pe_bytes},
             "roofline_attention": {"kernel": "attn_prefill_kernel (causal GQA, S=%d, 28q/4kv, hd128)" % S, "bound": "mfma",
                                    "achieved": attn_flops / attn_us / 1e6, "peak": 2500.0, "unit": "TFLOP/s",
-                                   "frac": attn_flops / attn_us / 1e6 / 2500.0, "traffic": None, "us_per_launch": attn_us,
+                                   "frac": attn_flops / attn_us / 1e6 / 2500.0, "traffic": attn_traffic, "us_per_launch": attn_us,
+                                   "algorithmic_bytes": 2 * S * 28 * 128 * 2 + 2 * S * 4 * 128 * 2,
                                    "mfma_busy_frac_pmc": attn_busy},
         }
         line.update(extras)
