@@ -478,7 +478,7 @@ def test_siglip_layer_forward_and_backward_match_autograd(train):
 
 
 @pytest.mark.parametrize("shape", ["narrow-2+2", "true-width-1+1"])
-def test_whole_sample_step_matches_autograd(ops, train, shape):
+def test_whole_sample_step_matches_autograd(ops, train, shape, monkeypatch):
     """SigLIP tower (true width, 2 frames) -> mm_projector -> pool + 3-D PE + newline, spliced between text rows -> Qwen2 with labels:
     loss and the gradient of EVERY parameter group against autograd over the reference's composition in f32
     (llava_qwen.py:121-205, llava_arch.py:191-210, 307-328, 506-517, 650-836).  "narrow-2+2": 2 SigLIP layers + a 2-layer Qwen2 at
@@ -545,6 +545,18 @@ def test_whole_sample_step_matches_autograd(ops, train, shape):
     peak_k = torch.cuda.max_memory_allocated() - base_mem
     del _l, _g
     assert peak_r < peak_k, (peak_r, peak_k)
+
+    # weight gradients on the side stream (the default inside a step function) against the backward's own stream: the same kernels on
+    # the same operands, only their order in time differs - loss and every gradient bit for bit
+    monkeypatch.setenv("V3D_TRAIN_WGRAD_STREAM", "0")
+    loss_1, grads_1 = train.sample_forward_backward(params, patches.cuda(), ids.cuda(), table, pre_ids.cuda(), post_ids.cuda(), labels.cuda(), rope,
+                                                    frames, n_q, n_kv, hd, coord_rows=coord_rows.cuda(), coord_pe=coord_pe.cuda())
+    monkeypatch.delenv("V3D_TRAIN_WGRAD_STREAM")
+    assert train._WGRAD["stream"] is None and train._WGRAD["depth"] == 0
+    assert float(loss_1) == float(loss)
+    for a_, b_ in zip(train._leaves(grads_1), train._leaves(grads)):
+        assert torch.equal(a_, b_)
+    del grads_1
 
     # ---- reference (f32 autograd over the same 16-bit parameters)
     f32 = lambda t: train._tree_map(lambda a: a.float().requires_grad_(), t)
