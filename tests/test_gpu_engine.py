@@ -121,6 +121,56 @@ def test_object_features_patch27_golden(golden):
     np.testing.assert_allclose(objf.float().cpu().numpy(), g["objfeat27_f16"], rtol=0, atol=3e-3)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_row_dots_and_relu_mul_rows_edges(dt):
+    """The small row kernels of the 'mlp' / 'score' heads at awkward sizes: one row, widths that are no multiple of the 256-thread
+    stride, a padded row stride, the product-rounded and the Linear(C, 1) forms, bias, ReLU on / off, no row factor."""
+    from v3d import ops
+    g = torch.Generator().manual_seed(31)
+    for n, C, ld in ((1, 8, 8), (3, 130, 136), (9, 1024, 1024), (50, 3584, 3592)):
+        x = torch.randn(n, ld, generator=g).to(dt).cuda()[:, :C]
+        q = torch.randn(C, generator=g).to(dt).cuda()
+        b = torch.randn(1, generator=g).to(dt).cuda()
+        xf, qf = x.float().cpu(), q.float().cpu()
+        want_lin = (xf * qf).sum(-1) + b.float().cpu()
+        got_lin = ops.row_dots(x, q, bias=b)
+        tol = 2e-2 if dt == torch.bfloat16 else 3e-3
+        assert torch.allclose(got_lin.float().cpu(), want_lin.to(dt).float(), rtol=tol, atol=tol * max(1.0, float(want_lin.abs().max())))
+        want_pr = (x * q).float().cpu().sum(-1)                     # every product rounded to the dtype first
+        got_pr = ops.row_dots(x, q, products_rounded=True)
+        assert torch.allclose(got_pr.float().cpu(), want_pr.to(dt).float(), rtol=tol, atol=tol * max(1.0, float(want_pr.abs().max())))
+        y = x.clone()                                               # a view with the padded stride
+        base = torch.full((n, ld), 3.0, dtype=dt, device="cuda")
+        base[:, :C] = x
+        v = base[:, :C]
+        ops.relu_mul_rows(v, row=q, relu=True)
+        assert torch.equal(v, (torch.relu(y).float() * q.float()).to(dt))
+        assert bool((base[:, C:] == 3.0).all())                     # nothing written past the columns
+        w = x.clone()
+        ops.relu_mul_rows(w, relu=True)
+        assert torch.equal(w, torch.relu(x))
+        z = x.clone()
+        ops.relu_mul_rows(z, row=q, relu=False)
+        assert torch.equal(z, (x.float() * q.float()).to(dt))
+
+
+def test_object_patch_mask_no_objects_and_patch27_threshold():
+    """n_obj = 0 returns an empty mask (no launch); with cell = 27 a cell with exactly 182 of its 729 pixels inside is selected and one
+    with 181 is not (int(27 * 27 * 0.25) = 182, llava_arch.py:370)."""
+    from v3d import ops
+    coords = torch.full((1, 384, 384, 3), 50.0, dtype=torch.float16, device="cuda")
+    assert ops.object_patch_mask(coords, torch.zeros(0, 6, dtype=torch.float16, device="cuda"), cell=27, thresh=182).shape == (0, 1, 14, 14)
+    flat = coords.view(-1, 3)
+    def fill(py, px, count):                                   # `count` pixels of cell (py, px) move to the origin
+        idx = [(py * 27 + r) * 384 + px * 27 + c for r in range(27) for c in range(27)][:count]
+        flat[torch.tensor(idx, device="cuda")] = 0.0
+    fill(2, 3, 182)
+    fill(5, 7, 181)
+    box = torch.tensor([[0.0, 0.0, 0.0, 1.0, 1.0, 1.0]], dtype=torch.float16, device="cuda")
+    m = ops.object_patch_mask(coords, box, cell=27, thresh=int(27 * 27 * 0.25))[0, 0].cpu()
+    assert m[2, 3] == 1 and m[5, 7] == 0 and int(m.sum()) == 1
+
+
 @pytest.mark.parametrize("kind", ["mlp", "score"])
 def test_ground_head_variants_golden(golden, kind):
     """ground_head_type 'mlp' / 'score' on the device against the reference's own predict_box (bf16 run of the same seeded weights)."""

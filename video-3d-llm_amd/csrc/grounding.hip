@@ -149,9 +149,9 @@ using namespace v3d;
 
 extern "C" int v3d_object_patch_mask(const void* coords, int dtype, int F_, int S, int cell, const void* boxes, int n_obj,
                                      int thresh, uint8_t* mask, void* stream) {
-  V3D_REQUIRE(coords && boxes && mask, "v3d_object_patch_mask: null pointer");
   V3D_REQUIRE(F_ > 0 && S > 0 && cell > 0 && cell * cell <= 768 && n_obj >= 0, "v3d_object_patch_mask: bad shape");
-  if (n_obj == 0) return V3D_OK;
+  if (n_obj == 0) return V3D_OK;                        // no proposals: nothing to write (boxes / mask may be empty, i.e. null)
+  V3D_REQUIRE(coords && boxes && mask, "v3d_object_patch_mask: null pointer");
   const int grid = (S - 6) / cell;                       // [:378,:378] of 384 -> 27 cells of 14 (llava_arch.py:366)
   const int n_cells = F_ * grid * grid;
   if (cell * cell <= 256) {
