@@ -125,6 +125,8 @@ def test_scene_sharding_partition_properties():
                     assert all((keys[i] != s_) or (i in p) for i in range(len(keys)))     # whole scenes
             biggest = max(keys.count(k) for k in set(keys))
             assert max(len(p) for p in parts) <= len(keys) / world + biggest          # balanced up to one scene
+    # three scenes for three ranks: one each, whatever their sizes (assigning by the first question left the last rank empty)
+    assert [D.shard_scene_indices(list("aabccc"), r, 3) for r in range(3)] == [[0, 1], [2], [3, 4, 5]]
 
 
 def test_prompt_ids_and_labels_equal_the_drivers_own_preprocess_qwen(tmp_path):

@@ -49,8 +49,10 @@ def shard_scene_indices(keys, rank, world):
         by_scene[k].append(i)
     n, out, done, r = len(keys), [], 0, 0
     for k in order:
-        # the scene goes to the rank whose quota [r n / world, (r + 1) n / world) its first question falls into
-        while r < world - 1 and done >= (r + 1) * n / world:
+        # the scene goes to the rank whose quota [r n / world, (r + 1) n / world) the MIDDLE of its questions falls into: a rank's load
+        # is then within half a scene of n / world on either side (by the first question, a short scene in front of a long one dragged
+        # the long one along and could leave the last ranks empty)
+        while r < world - 1 and done + len(by_scene[k]) / 2 >= (r + 1) * n / world:
             r += 1
         if r == rank:
             out += by_scene[k]
