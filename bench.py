@@ -15,10 +15,17 @@ fusion kernel, HBM), `roofline_attention`, `fp8_config3` (the same step with e4m
 `cached_questions` (scene-level reuse, SURVEY 8 f1: further questions about an already prefilled scene), `ground_config2`
 (the ScanRefer / Multi3DRefer grounding forward at 32 frames / 50 proposals, BASELINE configs[2], one GPU) and `cpu_baseline`.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in the
+environment), or started plainly - then THIS process, before it touches the GPU, starts exactly that command as a child (one rank
+per GPU, rendezvous on 127.0.0.1), relays rank 0's line and exits with the child's code (the reference's driver starts its own workers
+too: model_scanqa.py:242-247, `ray.init(); eval_model.remote(questions[i::n_gpu])`).
 
 Prints ONE JSON line (rank 0).  Scenes shard data-parallel: every rank runs its own scenes, no
 data-path collective; one RCCL gather of the generated token ids at the end (eval collation).
+V3D_BENCH_DRY=1: no GPU at all - ranks over gloo run the sharding, the record gather and the max-over-ranks timing around a stand-in
+for the scene pipeline (CPU test of the launcher and the N > 1 plumbing; the line says so and is not a measurement).
 """
 import argparse
 import json
@@ -40,9 +47,9 @@ DECODE_STEPS = NEW_TOKENS
 IMAGE_TOKEN_INDEX = -200
 
 
-def synth_inputs(dev, dtype, seed):
+def synth_inputs(dev, dtype, seed, frames=FRAMES, text_post=TEXT_POST):
     g = torch.Generator(device=dev).manual_seed(seed)
-    F_ = FRAMES
+    F_ = frames
     depth = torch.randint(400, 5000, (F_, 480, 640), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
     K = torch.zeros(F_, 4, 4, device=dev)
     K[:, 0, 0] = K[:, 1, 1] = 577.87
@@ -53,7 +60,7 @@ def synth_inputs(dev, dtype, seed):
     P[:, 2, 2] = P[:, 3, 3] = 1.0
     P[:, :3, 3] = torch.randn(F_, 3, generator=g, device=dev) * 1.5
     frames = torch.randint(0, 256, (F_, 384, 384, 3), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)   # RGB crops
-    text = torch.randint(0, 151000, (TEXT_PRE + TEXT_POST,), generator=g, device=dev)
+    text = torch.randint(0, 151000, (TEXT_PRE + text_post,), generator=g, device=dev)
     input_ids = torch.cat([text[:TEXT_PRE], torch.tensor([IMAGE_TOKEN_INDEX], device=dev), text[TEXT_PRE:]]).cpu()
     return dict(depth=depth, K=K, pose=P, P=P, frames=frames, input_ids=input_ids)
 
@@ -131,6 +138,32 @@ def cpu_baseline(threads):
                        "add+newline) at full 32-frame shape = %.2f s; one SigLIP layer (%.2f s) and one Qwen2-7B layer at S=%d "
                        "(%.2f s) at full width, extrapolated x26 / x28; projector, LM head and decode not included" % (geom, vit_layer, S, llm_layer)),
             "seconds_measured": geom + vit_layer + llm_layer}
+
+
+def usable_cores():
+    """Host cores this process can actually run on: sched_getaffinity, limited by the cgroup CPU quota (v2 cpu.max / v1 cfs quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    why = "scheduler affinity: %d of %d host cores" % (n, os.cpu_count() or n)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota))
+        why += "; cgroup CPU quota %.1f cores" % quota
+    return n, why
 
 
 def kernel_source_sha(*names):
@@ -390,6 +423,75 @@ def measure_train_step(dev, steps=2, answer_tokens=64):
                           "ms_forward_backward": rc_ms[-1], "peak_mem_gb": rc_peak}}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start `torch.distributed.run` with N ranks of this very file as a
+    CHILD process (never an exec, and before this process has made any GPU call), let rank 0's JSON line through and return the child's
+    exit code.  No retry: a failed child is a failed run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("bench.py: --gpus %d without RANK / WORLD_SIZE: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:                                  # rank 0's one JSON line (anything else a rank printed goes to stderr)
+        if ln.lstrip().startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if rc == 0 and not lines:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 1
+    return rc
+
+
+def dry_run(a, rank, world):
+    """V3D_BENCH_DRY=1: the N > 1 plumbing of main() with a stand-in for the scene pipeline and no GPU - the same sharding
+    (v3d.distributed.shard), record gather (gather_records), barrier + max-over-ranks timing and line, over gloo on the CPU."""
+    import torch.distributed as dist
+    from v3d import distributed as v3dist
+    multi = world > 1 or os.environ.get("V3D_BENCH_FORCE_DIST") == "1"
+    if os.environ.get("V3D_BENCH_DRY_FAIL_RANK") == str(rank):      # (test hook: a rank that dies before the rendezvous)
+        raise SystemExit(3)
+    if multi:
+        dist.init_process_group("gloo")
+    my_ids = v3dist.shard(list(range(world * a.steps)), rank, world)
+    if multi:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.002 * a.steps)
+    answers = [[(7 * sid + k) % 1000 for k in range(NEW_TOKENS)] for sid in my_ids]
+    merged = None
+    if multi:
+        merged = v3dist.gather_records([{"sample_id": sid, "pred_token_ids": row} for sid, row in zip(my_ids, answers)], torch.device("cpu"))
+        dist.barrier()
+    dt_s = time.perf_counter() - t0
+    if multi:
+        tt = torch.tensor([dt_s], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_s = tt.item()
+    if rank == 0:
+        if multi:
+            assert [r["sample_id"] for r in merged] == list(range(world * a.steps)), "gathered records are not in question order"
+            assert all(r["pred_token_ids"] == [(7 * r["sample_id"] + k) % 1000 for k in range(NEW_TOKENS)] for r in merged)
+        print(json.dumps({"metric": "scenes/sec ScanQA @32 frames", "value": world * a.steps / dt_s, "unit": "scenes/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_s / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "DRY RUN (V3D_BENCH_DRY=1): no GPU, a stand-in for the scene pipeline - not a measurement",
+                          "rccl_ranks": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,
+                          "config": {"workload": "dry run of the N > 1 plumbing", "parallelism": "scene-dp%d" % world}}), flush=True)
+    if multi:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -407,12 +509,15 @@ def main():
     ap.add_argument("--scenes", type=int, default=8, help="distinct synthetic scenes resident in HBM, cycled over the steps")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))          # (nothing above has touched the GPU: `import torch` does not)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE is {world}: launch N > 1 with "
-                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus}`")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher's WORLD_SIZE is {world}")
+    if os.environ.get("V3D_BENCH_DRY") == "1":
+        return dry_run(a, rank, world)
     # V3D_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend - exercises the N > 1 code path (sharding, record gather,
     # max-over-ranks timing) on a one-GPU box; its numbers mean nothing (the ranks share one GPU) and the line says so
     rehearsal = os.environ.get("V3D_BENCH_REHEARSAL") == "1"
@@ -489,6 +594,24 @@ def main():
 
     dt_s = measure(eng, stamps)
     extras = {}
+    if world == 1 and not a.no_extras and not a.eval_runner_only:
+        # BASELINE.json's stated synthetic proxy (a 4096-token sequence; SURVEY 8(d) asks for it NEXT to the true shape).  No frame count
+        # of the real path gives 4096 visual rows (a frame is 14 x 15 = 210 rows), so the proxy is 19 frames x 210 = 3990
+        # visual rows + 14 + 92 text ids = exactly 4096; everything else as in the headline.
+        PF, PPOST = 19, 4096 - TEXT_PRE - 19 * 210
+        keep_scenes = scenes
+        scenes = [synth_inputs(dev, dtype, seed=2000 + i, frames=PF, text_post=PPOST) for i in range(min(4, n_scenes))]
+        st4 = new_stamps()
+        t4 = measure(eng, st4)
+        scenes = keep_scenes
+        a_us = st4["attn"].mean_us()
+        extras["s4096_proxy"] = {
+            "what": "BASELINE.json's stated synthetic proxy, a 4096-token sequence: %d frames (384x384; the 3-D code is hard-wired to SigLIP-384, SURVEY F4) "
+                    "x 210 visual rows + %d + %d text ids = 4096, %d greedy tokens; the headline is the TRUE 32-frame shape (S = %d)"
+                    % (PF, TEXT_PRE, PPOST, NEW_TOKENS, TEXT_PRE + FRAMES * 210 + TEXT_POST),
+            "value": a.steps / t4, "unit": "scenes/s", "ms_per_step": t4 / a.steps * 1e3, "frames": PF, "seq_len": 4096,
+            "attention_us_per_layer": a_us, "attention_frac_of_2.5PF": 2.0 * 4096 * 4096 * 128 * 28 / a_us / 1e6 / 2500.0,
+            "gate_up_gemm_us": st4["gemm"].mean_us(), "gate_up_gemm_frac_of_2.5PF": 2.0 * 4096 * 37888 * 3584 / st4["gemm"].mean_us() / 1e6 / 2500.0}
     if world == 1 and a.eval_runner_only:
         extras["eval_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
     elif world == 1 and not a.no_extras:
@@ -562,6 +685,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt_s / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16",
             "data": "synthetic" + (" (REHEARSAL: all ranks share cuda:0 over gloo - not a measurement)" if rehearsal else ""),
+            "rccl_ranks": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,
             "config": {"workload": "ScanQA val, uniform 32 frames, %s, 1xMI355X per rank: 32x(480x640 u16 depth + 384x384 RGB) -> "
                                    "SigLIP-so400m(26L) + mlp2x_gelu + 3D-PE fusion -> Qwen2-7B prefill S=%d + %d greedy tokens (%d decode passes "
                                    "over the weights); random-init weights at true widths; %d distinct synthetic scenes cycled"
@@ -592,7 +716,11 @@ def main():
         }
         line.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))
+            # n = ALL host cores this process may run on (printed in the line as `cores`): the scheduler affinity, cut to
+            # the container's CPU quota where one is set (256 threads on a 16-core quota ran the same sample 2.6x SLOWER than 16)
+            cores, why = usable_cores()
+            line["cpu_baseline"] = cpu_baseline(cores)
+            line["cpu_baseline"].update({"host_cores_total": os.cpu_count(), "cores_note": why})
         print(json.dumps(line))
     if loader_pool is not None:
         loader_pool.shutdown(wait=True, cancel_futures=True)

@@ -99,3 +99,36 @@ def test_zero2_reduce_scatter_and_all_gather_world2():
         assert not isinstance(part_direct, str), part_direct
         assert torch.allclose(part_direct, part) and not bool(part_direct[e - b:].any())
         assert torch.allclose(full, torch.arange(1003, dtype=torch.float32) - 0.1 * mean)
+
+
+def _run_bench(*args, env_extra=None, timeout=300):
+    """`python bench.py ...` as the driver starts it: a plain process, no RANK / WORLD_SIZE in its environment."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"V3D_BENCH_DRY": "1"}, **(env_extra or {}))
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """VERDICT r03 missing #1: the driver runs `python3 bench.py --gpus N ...`; with N > 1 the process must start N ranks itself
+    (torch.distributed.run as a child, before any GPU call), relay rank 0's ONE line and the child's exit code.  Dry mode: gloo, no GPU,
+    a stand-in for the scene pipeline - sharding, record gather, barrier + max-over-ranks timing are the real code."""
+    import json
+    r = _run_bench("--gpus", "2", "--steps", "5", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                                    # exactly one line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo" and line["steps"] == 5
+    assert line["scaling"] == "weak" and line["value"] > 0 and "DRY RUN" in line["data"]
+    assert abs(line["value"] - 2 * 5 / (line["ms_per_step"] * 5e-3)) < 1e-6 * line["value"]      # whole-job aggregate over both ranks
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
+
+
+def test_bench_relays_a_failed_childs_exit_code():
+    """A rank that dies takes the run down with a non-zero exit and no result line (no retry)."""
+    r = _run_bench("--gpus", "2", "--steps", "3", env_extra={"V3D_BENCH_DRY_FAIL_RANK": "1"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]

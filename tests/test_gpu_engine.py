@@ -470,6 +470,7 @@ def test_last_layer_runs_for_the_rows_that_are_read_only(fp8):
     rows.  Held to: the K/V cache of every layer bit-identical to the all-rows pass, the listed rows' outputs and the logits equal to
     it up to the one-row kernels' summation order, greedy tokens equal unless the margin is inside that noise, and an empty list
     (scene prefill) leaves the complete cache."""
+    from v3d import ops as eng_ops
     from v3d.engine import Engine, EngineConfig, LlmConfig, VitConfig, random_state_dict
     cfg = EngineConfig(vit=VitConfig(hidden=144, inter=272, layers=1, heads=2),
                        llm=LlmConfig(hidden=512, inter=1024, layers=3, heads=4, kv_heads=2, vocab=320, max_pos=1024))
@@ -482,7 +483,10 @@ def test_last_layer_runs_for_the_rows_that_are_read_only(fp8):
     x0 = x.clone()
     full_logits = eng.llm_forward(x, 0).clone()
     full_x, full_kv = x.clone(), [k[:S].clone() for k in eng.kv]
-    tol = 1e-1 if fp8 else 2e-2          # e4m3: the all-rows pass quantises the activations too (W8A8), the one-row kernels keep them 16-bit (W8A16)
+    # the ONE fp8 tolerance of this repo ("configs[3]"): 1e-1 relative L2 between two e4m3 evaluations of the same rows
+    # whose activation precision differs - the all-rows pass quantises the activations too (W8A8), the one-row kernels keep them 16-bit
+    # (W8A16); measured 0.024 on this model.  bf16: 2e-2.  The token rule below uses the same figure as its noise level.
+    tol = 1e-1 if fp8 else 2e-2
     for rows in ([S - 1], [5, S - 1], []):
         x.copy_(x0)
         for k in eng.kv:
@@ -496,5 +500,19 @@ def test_last_layer_runs_for_the_rows_that_are_read_only(fp8):
     a = eng.generate(ids, im, wc, max_new_tokens=4).tolist()                             # (pruned) against the all-rows prefill + decode
     x.copy_(x0)
     b = eng.decode_loop(eng.llm_forward(x, 0), S, 4).tolist()
-    top2 = torch.topk(full_logits.float(), 2).values
-    assert a == b or fp8 or (top2[0] - top2[1]).item() < 0.05 * full_logits.float().abs().max().item()
+    # greedy tokens: equal, unless the all-rows pass's own top-2 margin at the first differing step is inside the noise the stated
+    # tolerance allows (fp8 included: r03 skipped the comparison there).  The margin is taken from the all-rows evaluation of exactly the
+    # prefix both runs share up to that step.
+    noise = (2.5 * tol if fp8 else 0.05)
+    for t in range(len(a)):
+        if a[t] == b[t]:
+            continue
+        x.copy_(x0)
+        lg = eng.llm_forward(x, 0)
+        for k, tok in enumerate(a[:t]):                      # replay the shared prefix a[:t] on top of the all-rows prefill
+            xe = eng_ops.embed_gather(eng.embed, torch.tensor([tok], device="cuda"), out=eng.l_x[S + k: S + k + 1])
+            lg = eng.decode_forward(xe, S + k)
+        lg = lg.float().reshape(-1)
+        top2 = torch.topk(lg, 2).values
+        assert (top2[0] - top2[1]).item() < noise * lg.abs().max().item(), (t, a, b, top2.tolist())
+        break

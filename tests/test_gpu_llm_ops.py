@@ -169,6 +169,38 @@ def test_attention_prefill64_optin_kernel_equals_default_kernel_bitwise(ops, kin
     close(outs["1"], want, kind, ulps=4.0, floor=0.3)      # (the spiked row's P is one 16-bit rounding away from one-hot)
 
 
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("Sq,Sk", [(1, 1), (64, 64), (77, 77), (300, 300), (1000, 1000), (2100, 2100), (130, 900), (517, 2048)])
+def test_attention_mfma16_variant_of_the_prefill_kernel(ops, kind, Sq, Sk, monkeypatch):
+    """r04 A/B (V3D_ATTN_MFMA=16): attn_prefill16_kernel = attn_prefill_kernel<128> on v_mfma_f32_16x16x32 (32-wide k chunks, a query's
+    keys over 4 lanes): against the f32 reference at the default kernel's bound, against the default kernel (summation order only:
+    2 ulp16 of |v|), causal GQA, ragged tails, question rows at q_pos0 > 0 over a longer prefix, the rare max-raise branch (spiked
+    key), and the scene-reuse property: a query row's bits do not depend on the rows that share its launch."""
+    dt = DT[kind]
+    H, KV, D = 28, 4, 128
+    g = torch.Generator().manual_seed(Sq * 7 + Sk)
+    q = torch.randn(1, Sq, H, D, generator=g) * 0.5
+    k = torch.randn(1, Sk, KV, D, generator=g) * 0.5
+    v = torch.randn(1, Sk, KV, D, generator=g)
+    if Sk >= 300:
+        k[0, Sk - 90, 1] = q[0, Sq - 10, 9] * 30          # a late spike: the running maximum of one query jumps
+    q, k, v = q.to(dt).cuda(), k.to(dt).cuda(), v.to(dt).cuda()
+    outs = {}
+    for mode in ("32", "16"):
+        monkeypatch.setenv("V3D_ATTN_MFMA", mode)
+        outs[mode] = ops.attention_bshd(q, k, v, causal=True, q_pos0=Sk - Sq)
+    want = ref_attention(q.cpu(), k.cpu(), v.cpu(), True, 1 / math.sqrt(D), q_pos0=Sk - Sq)
+    close(outs["16"], want, kind, ulps=4.0, floor=0.3)
+    close(outs["16"], outs["32"].float().cpu(), kind, ulps=2.0, floor=0.3)
+    if Sq >= 64:       # rows [a, b) alone (other wave / lane positions, other neighbours): the same bits
+        a, b = Sq // 3 + 5, Sq - 7
+        part = ops.attention_bshd(q[:, a:b].contiguous(), k, v, causal=True, q_pos0=Sk - Sq + a)
+        assert torch.equal(part, outs["16"][:, a:b])
+    # non-causal (the training forward of the padded tower heads takes this kernel at head dim 128)
+    nc = ops.attention_bshd(q, k, v, causal=False)
+    close(nc, ref_attention(q.cpu(), k.cpu(), v.cpu(), False, 1 / math.sqrt(D)), kind, ulps=4.0, floor=0.3)
+
+
 def test_attention_online_softmax_rescale_branch(ops):
     """Force the running max to jump at a late KV tile (rule: rare branches need their own test)."""
     dt = torch.bfloat16

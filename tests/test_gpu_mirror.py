@@ -169,8 +169,12 @@ def test_video_processor_on_scene_files(golden, tmp_path):
     from v3d.pipeline import AsyncSceneLoader
     raw = vp.load_raw(vid, files)
     vp.sample_frame_files = lambda video_id, force_sample=False, frames_upbound=0: files
+    from v3d import frame_io
     for workers in (2, 0):
-        loader = AsyncSceneLoader([vid, vid, vid], lambda v: vp.describe_scene(v, True, V), workers=workers, ahead=1, keep=2)
+        # (a library caller hands in a pool made before the GPU was touched; this test process has long initialised it, and forks
+        # its two PIL-only workers anyway - what AsyncSceneLoader itself no longer does on its own, see the warning test below)
+        pool = frame_io.make_pool(workers) if workers else None
+        loader = AsyncSceneLoader([vid, vid, vid], lambda v: vp.describe_scene(v, True, V), workers=workers, ahead=1, keep=2, pool=pool)
         try:
             for j in range(3):
                 got, _ = loader.get(j)
@@ -183,5 +187,76 @@ def test_video_processor_on_scene_files(golden, tmp_path):
             assert set(loader.stage_seconds) == {"depth_png", "pose_txt", "rgb_decode"}
         finally:
             loader.close()
+            if pool is not None:
+                pool.shutdown(wait=True, cancel_futures=True)
+    with pytest.warns(UserWarning, match="already initialised"):          # no pool + live GPU: decode inline rather than fork
+        loader = AsyncSceneLoader([vid], lambda v: vp.describe_scene(v, True, V), workers=2)
+    assert loader.pool is None
+    got, _ = loader.get(0)
+    assert torch.equal(raw["frames"], got["frames"])
+    got["_done"](None)
+    loader.close()
     want_pose = np.stack([g["axis_align"].astype(np.float64) @ np.loadtxt(f.replace("jpg", "txt")) for f in files]).astype(np.float32)
     assert np.array_equal(raw["pose"].numpy(), want_pose)
+
+
+def test_pipeline_device_inputs_follow_the_depth_maps_aspect(tmp_path):
+    """ScanNet's colour frames (1296 x 968) and depth maps (640 x 480) differ in aspect; the reference sizes BOTH
+    resizes from world_coords, i.e. from the depth map (video_utils.py:264, 298-299): colour -> 512 x 384, crop at column 64 - not the
+    514 / 65 the colour frame's own aspect gives.  v3d.pipeline.ScenePipeline.device_inputs (the default path of every eval runner and
+    of bench.py) must equal VideoProcessor.preprocess + the image processor, which in turn equals the reference's PIL calls; and a
+    'norm' frame-sampling strategy's clamp (video_utils.py:232-236) must reach the pipelined path too."""
+    import llava.video_utils as vu
+    from PIL import Image
+    from llava.model.multimodal_encoder.siglip_encoder import SigLipImageProcessor
+    from scene_files import write_frames
+    from v3d.pipeline import AsyncSceneLoader, ScenePipeline, SceneSample
+    rng = np.random.default_rng(5)
+    V, Hd, Wd, Hc, Wc, crop = 3, 48, 64, 120, 166, 96          # by the colour aspect 166 * 96 / 120 -> 132 (left 18); by the depth's 128 (left 16)
+    assert int(Wc * (crop / Hc)) != int(Wd * (crop / Hd))
+    depth = rng.integers(500, 4000, size=(V, Hd, Wd)).astype(np.uint16)
+    poses = np.tile(np.eye(4), (V, 1, 1))
+    poses[:, :3, 3] = rng.normal(size=(V, 3))
+    folder = str(tmp_path / "posed_images" / "scene0000_00")
+    files = write_frames(folder, depth, poses, rgb=None, ext=".jpg")
+    yy, xx = np.mgrid[0:Hc, 0:Wc]
+    for v, f in enumerate(files):                               # the colour stream at ITS size
+        rgb = np.stack([(xx * (3 + c) + yy * (5 - c) + 40 * v) % 256 for c in range(3)], -1).astype(np.uint8)
+        Image.fromarray(rgb).save(f, quality=95)
+    vid = "scannet/scene0000_00"
+    vp = object.__new__(vu.VideoProcessor)
+    vp.video_folder, vp.frame_sampling_strategy = str(tmp_path), "uniform"
+    vp.scene = {vid: {"axis_align_matrix": np.eye(4).tolist(), "depth_cam2img": [[57.8, 0, 31.5, 0], [0, 57.8, 23.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                      "images": [{"img_path": "posed_images/scene0000_00/" + f.split("/")[-1]} for f in files]}}
+    vp.scan2obj = {vid: [[0.0, 0.1, 0.2, 1.0, 1.0, 1.0]]}
+    vp.sample_frame_files = lambda video_id, force_sample=False, frames_upbound=0: files
+    proc = SigLipImageProcessor(size=(crop, crop), crop_size={"height": crop, "width": crop})
+    eng = types.SimpleNamespace(dtype=torch.float16, device="cuda", ctx=None, ws=None, new_context=lambda: None, new_group=lambda g: None,
+                                new_prefill_workspace=lambda: None)
+    pipe = ScenePipeline(eng, 1, crop=crop, image_mean=proc.image_mean, image_std=proc.image_std, rescale=proc.rescale_factor)
+    for strategy, lo, hi in (("uniform", None, None), ("uniform-norm", [-0.5, -1.0, 0.2], [1.5, 0.75, 1.0])):
+        vp.frame_sampling_strategy = strategy
+        if lo is not None:
+            vp.pc_min, vp.pc_max = {"scene0000_00": torch.tensor(lo)}, {"scene0000_00": torch.tensor(hi)}
+        ref = vp.process_3d_video(vid, proc, force_sample=True, frames_upbound=V)
+        # (the mirror's own preprocess against the reference's PIL calls at the depth-derived width)
+        new_w = int(Wd * (crop / Hd))
+        left = (new_w - crop) // 2
+        pre = vp.preprocess(vid, proc, force_sample=True, frames_upbound=V)
+        for v in range(V):
+            with Image.open(files[v]) as im:
+                want = np.asarray(im.convert("RGB").resize((new_w, crop)).crop((left, 0, left + crop, crop)))
+            assert np.array_equal(pre["images"][v].cpu().numpy(), want)
+        loader = AsyncSceneLoader([vid], lambda v: vp.describe_scene(v, True, V), workers=0)
+        try:
+            raw, _ = loader.get(0)
+            images, coords = pipe.device_inputs(SceneSample(input_ids=torch.tensor([-200]), raw=raw, key=None))
+            torch.cuda.synchronize()
+        finally:
+            loader.close()
+        assert torch.equal(images, ref["images"].to(torch.float16)), strategy          # model_scanqa.py:163: .half() of the f32 pixel_values
+        assert torch.equal(coords, ref["world_coords"].to(torch.float16)), strategy
+        if lo is not None:
+            c = coords.float().cpu()
+            assert bool((c >= torch.tensor(lo).half().float()).all()) and bool((c <= torch.tensor(hi).half().float()).all())
+            assert bool((c == torch.tensor(lo).half().float()).any())                  # (the clamp bit somewhere)

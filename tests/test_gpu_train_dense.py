@@ -774,6 +774,15 @@ def test_trainer_surface_loss_backward_and_checkpoint_round_trip(ops, train):
     sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = mk(I, H, s=H ** -0.5), mk(I, H, s=H ** -0.5), mk(H, I, s=I ** -0.5)
     sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = ln(H), ln(H)
     sd["model.norm.weight"], sd["lm_head.weight"] = ln(H), mk(V, H, s=H ** -0.5)
+    # tensors a real LlavaQwen checkpoint holds and the training step does not model: the tower's post_layernorm (kept after
+    # siglip_encoder.py:570-571 deletes the last layer; :416), the infonce grounding head (llava_qwen.py:98-111: Sequential indices 0, 2, 3)
+    g2 = torch.Generator().manual_seed(92)               # (a generator of their own: the modelled tensors and inputs stay those of r03)
+    mk2 = lambda *shape, s=1.0: (torch.randn(*shape, generator=g2) * s).to(torch.bfloat16)      # noqa: E731
+    unmodelled = {VIT + "post_layernorm.weight": 1 + mk2(Hv, s=0.1), VIT + "post_layernorm.bias": mk2(Hv, s=0.1), "ground_head_zero_target": mk2(H)}
+    for head in ("ground_head_obj", "ground_head_query"):
+        unmodelled.update({f"{head}.0.weight": mk2(H, H, s=H ** -0.5), f"{head}.0.bias": mk2(H, s=0.1), f"{head}.2.weight": 1 + mk2(H, s=0.1),
+                           f"{head}.2.bias": mk2(H, s=0.1), f"{head}.3.weight": mk2(H, H, s=H ** -0.5), f"{head}.3.bias": mk2(H, s=0.1)})
+    sd.update(unmodelled)
 
     model = LlavaQwenTrainable.from_reference_state_dict(sd, n_q, n_kv, max_pos=1024)
     back = model.reference_state_dict()
@@ -813,5 +822,6 @@ def test_trainer_surface_loss_backward_and_checkpoint_round_trip(ops, train):
     torch.optim.SGD(model.parameters(), lr=0.5).step()
     after = model.reference_state_dict()
     changed = [k for k in sd if not torch.equal(before[k], after[k])]
+    assert not set(changed) & set(unmodelled) and all(torch.equal(after[k].cpu(), sd[k]) for k in unmodelled)      # carried, frozen
     # (the tower's k_proj bias has no gradient - softmax shift invariance - and a 16-bit weight near 1 does not move by a small step)
-    assert len(changed) >= len(sd) - 6 and VIT + "encoder.layers.0.self_attn.k_proj.bias" not in changed, sorted(set(sd) - set(changed))
+    assert len(changed) >= len(sd) - len(unmodelled) - 6 and VIT + "encoder.layers.0.self_attn.k_proj.bias" not in changed, sorted(set(sd) - set(changed))

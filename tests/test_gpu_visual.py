@@ -353,7 +353,7 @@ def test_resize_crop_rgb_equals_reference_loop_golden_and_live_pil(ops, golden):
     assert np.array_equal(got_s, g["small_out"])
 
 
-@pytest.mark.parametrize("shape", [(48, 64, 38, 51), (30, 40, 45, 60), (97, 33, 20, 31), (16, 16, 16, 24), (480, 640, 384, 384), (968, 1296, 384, 514)])
+@pytest.mark.parametrize("shape", [(48, 64, 38, 51), (30, 40, 45, 60), (97, 33, 20, 31), (16, 16, 16, 24), (480, 640, 384, 384), (968, 1296, 384, 512), (968, 1296, 384, 514)])
 def test_resize_rgb_other_sizes_equal_live_pil(ops, shape):
     """up- and down-scaling, odd sizes, the ScanNet colour-stream size (1296 x 968): whole resized image vs PIL."""
     from PIL import Image

@@ -81,7 +81,7 @@ def test_attention_and_decode_kernels_do_not_spill_in_their_loops(reports):
     att = reports["attention.hip"]
     # r03: the prefill kernel's rarely taken raise-of-the-maximum block (and code outside the tile loop) may spill; its steady-state
     # tile loop must not - checked on the generated code below.  The totals stay bounded so that a regression is noticed.
-    prefill = {k: v for k, v in att.items() if "attn_prefill_kernel" in k}
+    prefill = {k: v for k, v in att.items() if "attn_prefill_kernel" in k or "attn_prefill16_kernel" in k}      # (r04: + the 16x16x32 form)
     assert prefill and all(v <= 24 for v in prefill.values()), prefill
     att = {k: v for k, v in att.items() if k not in prefill}
     assert all(v == 0 for v in reports["attention_bwd.hip"].values()), reports["attention_bwd.hip"]
@@ -93,3 +93,5 @@ def test_attention_and_decode_kernels_do_not_spill_in_their_loops(reports):
     assert out.returncode == 0, out.stderr[-2000:]
     n, bad = _inner_loop_spills(out.stdout, "attn_prefill_kernel")
     assert n >= 14 and not bad, bad[:10]
+    n, bad = _inner_loop_spills(out.stdout, "attn_prefill16_kernel")
+    assert n >= 8 and not bad, bad[:10]

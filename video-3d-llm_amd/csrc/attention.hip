@@ -552,6 +552,381 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// r04: attn_prefill_kernel<128> on v_mfma_f32_16x16x32 - the A/B MI355X_MICROARCH.md asks for ('DVFS give-back' item 7, rule 28: the
+// chip may hold a higher clock on one bf16 MFMA shape than on the other, so build both at the same per-wave tile and keep the faster
+// by wall on random data).  Same workgroup (4 waves x 32 queries), same 64-key tiles, same LDS image / staging / swizzle, same
+// pipeline step (S' of tile t+1, then O^T += V^T.P^T of tile t with tile t+1's softmax between the MFMAs), same max-deferred exp2
+// softmax with the raise detected from the row-sum share.  What the 16 x 16 tile changes:
+//   * a wave's 32 queries are two blocks of 16 (qb); a K fragment (16 keys x 32 dims, one ds_read_b128) feeds both blocks' MFMAs and a
+//     V^T fragment (16 dims x 32 keys, two ds_read_b64_tr_b16) likewise, so LDS bytes per MFMA FLOP are those of the 32 x 32 form;
+//   * S^T[key][q] tile: lane (g = lane >> 4, n = lane & 15) owns query n of the block and the 4 keys of MFMA rows 4g .. 4g+3 of each
+//     16-key block - a query's 64 keys sit in 4 lanes (row sums per lane, reduced once after the loop; the rare maximum raise reduces
+//     over the 4 lanes);
+//   * the score accumulators are 4 registers per tile, so -m (the start value of a score chain) lives in a 4-register block per query
+//     block that the chain's FIRST MFMA takes as its C operand: no per-step re-initialisation of the score registers (32 v_mov per
+//     lane and step in the 32 x 32 form);
+//   * MFMA row m of a key block is LDS row rho(m) = 4 pi(m >> 2) + (m & 3), pi = (0, 2, 3, 1): with the image's swizzle this keeps both
+//     the K row reads (ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) and V's transposed
+//     reads (lane groups of 32) free of bank conflicts; P^T comes straight out of the S^T registers in the matching k order.
+// Outputs differ from the 32 x 32 kernel's by summation order only (k runs in chunks of 32, row sums over 4 lanes).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int at16_rho(int m) {      // MFMA row within a 16-key block -> LDS row within the block
+  const int a = m >> 2;
+  const int pi = a == 0 ? 0 : (a == 1 ? 2 : (a == 2 ? 3 : 1));
+  return 4 * pi + (m & 3);
+}
+
+template <typename T, bool CAUSAL, bool LSE = false>
+__global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma16<T>;
+  constexpr int D = 128, KS = 4, DB = 8;          // 32-wide k-steps of QK^T; 16-wide d blocks of O^T
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  int qt, head, b;                                  // grid mapping: as attn_prefill_kernel
+  if (p.xcd_p > 0) {
+    const int n_kv = p.Hq / p.group, per_b = ((p.Hq * p.n_qt + 7) >> 3) << 3;
+    b = (int)blockIdx.x / per_b;
+    const int l = (int)blockIdx.x - b * per_b;
+    const int xcd = l & 7, kvh = xcd % n_kv, slot = xcd / n_kv;
+    const int jj = (l >> 3) * p.xcd_p + slot;
+    if (jj >= p.group * p.n_qt) return;
+    head = kvh * p.group + jj % p.group;
+    qt = p.n_qt - 1 - jj / p.group;
+  } else {
+    qt = (int)gridDim.y - 1 - (int)blockIdx.y;
+    head = blockIdx.x; b = blockIdx.z;
+  }
+  const int hk = head / p.group;
+  const int q0 = qt * AT_BQ;
+
+  const uint16_t* Q = (const uint16_t*)p.q + b * p.bsq + (int64_t)head * p.hsq;
+  const uint16_t* K = (const uint16_t*)p.k + b * p.bsk + (int64_t)hk * p.hsk;
+  const uint16_t* V = (const uint16_t*)p.v + b * p.bsk + (int64_t)hk * p.hsk;
+
+  // ---- Q fragments: B operand, lane (g, n) holds c * Q[16qb + n][32ks + 8g .. +8) ----
+  int qi[2];
+  Frag16 qf[2][KS];
+  qi[0] = q0 + wave * 32 + n;
+  qi[1] = qi[0] + 16;
+
+  const int n_tiles_all = (p.Sk + AT_BKV - 1) / AT_BKV;
+  int n_tiles = n_tiles_all;
+  int n_wave = n_tiles_all;
+  if (CAUSAL) {
+    const int last_q = q0 + AT_BQ - 1 < p.Sq ? q0 + AT_BQ - 1 : p.Sq - 1;
+    const int t = (p.q_pos0 + last_q) / AT_BKV + 1;
+    n_tiles = t < n_tiles_all ? t : n_tiles_all;
+    const int tw = (p.q_pos0 + q0 + wave * 32 + 31) / AT_BKV + 1;
+    n_wave = tw < n_tiles ? tw : n_tiles;
+  }
+
+  // ---- KV staging by LDS-DMA: exactly attn_prefill_kernel's ----
+  const int srow = lane >> 4;
+  const int st_row0 = wave * 16 + srow;
+  const int st_chunk0 = (lane & 15) ^ (srow << 2);
+  const unsigned ldk_b = (unsigned)p.ldk * 2u, ldv_b = (unsigned)p.ldv * 2u;
+  auto stage = [&](const uint16_t* src, unsigned ld_b, char* dst, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = t * AT_BKV + st_row0 + 4 * i;
+      key = key < p.Sk ? key : p.Sk - 1;
+      const int chunk = st_chunk0 ^ i;
+      glds16a((const char*)src + ((unsigned)key * ld_b + (unsigned)chunk * 16u), dst + i * 4 * AT_ROW);
+    }
+  };
+  auto stage_k = [&](int buf, int t) { stage(K, ldk_b, smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW, t); };
+  auto stage_v = [&](int buf, int t) { stage(V, ldv_b, smem + buf * 2 * AT_TILE + AT_TILE + (wave * 16) * AT_ROW, t); };
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int chunk = st_chunk0 ^ i;
+    koff[i] = (unsigned)(st_row0 + 4 * i) * ldk_b + (unsigned)chunk * 16u;
+    voff[i] = (unsigned)(st_row0 + 4 * i) * ldv_b + (unsigned)chunk * 16u;
+  }
+  const unsigned lds_wave0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(wave * 16) * AT_ROW;
+  auto stage_fast = [&](const uint16_t* src, unsigned ld_b, const unsigned (&off)[4], unsigned lds_dst, int t) {
+    const char* base = (const char*)src + (size_t)t * (size_t)(AT_BKV * ld_b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   : : "v"(off[i]), "s"(base), "s"(lds_dst + (unsigned)(i * 4 * AT_ROW)) : "memory", "m0");
+  };
+  auto stage_k_fast = [&](int buf, int t) { stage_fast(K, ldk_b, koff, lds_wave0 + buf * 2 * AT_TILE, t); };
+  auto stage_v_fast = [&](int buf, int t) { stage_fast(V, ldv_b, voff, lds_wave0 + buf * 2 * AT_TILE + AT_TILE, t); };
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // K row read (A operand): MFMA row n of key block kb is LDS row 16kb + rho(n); logical chunk 4ks + g
+  const int krow = at16_rho(n);
+  const unsigned kaddr0_ = lds_base + krow * AT_ROW + ((g ^ kv_swz(krow)) << 4);
+  // V transposed read (A operand of O^T += V^T.P^T): lane 16g + 4i + jj supplies LDS row 16kb + 4pi(g) + i, 4 columns at
+  // d = 16db + 4jj; the hardware transpose hands lane 16g + (4a + b) the column d = 16db + 4a + b of those four rows
+  const int vi = (lane >> 2) & 3, vjj = lane & 3;
+  const int vrow = at16_rho(4 * g) + vi;
+  const unsigned vaddr0_ = lds_base + AT_TILE + vrow * AT_ROW + 8 * (vjj & 1) + (((vjj >> 1) ^ kv_swz(vrow)) << 4);
+  const int key_g = at16_rho(4 * g);             // tile-local key of score register r of key block kb: 16kb + key_g + r
+
+  f32x4 o[2][DB];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+  f32x4 negm[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // -m_run splat: the C operand of a score chain's first MFMA
+  const int q_pos[2] = {p.q_pos0 + qi[0], p.q_pos0 + qi[1]};
+  const int wave_first_pos = p.q_pos0 + q0 + wave * 32;
+
+#define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(kaddr0 ^ ((ks) << 6)), "i"(imm))
+#define V3D_KW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+  // both query blocks' MFMAs of one K fragment; the chain's first k-step starts from -m
+#define V3D_KM0(f, kb) { s[0][kb] = M::run(__builtin_bit_cast(typename M::frag, f[0]), as_frag16<T>(qf[0][0]), negm[0]); \
+                         s[1][kb] = M::run(__builtin_bit_cast(typename M::frag, f[0]), as_frag16<T>(qf[1][0]), negm[1]); }
+#define V3D_KM(f, ks, kb) { s[0][kb] = M::run(__builtin_bit_cast(typename M::frag, f[ks]), as_frag16<T>(qf[0][ks]), s[0][kb]); \
+                            s[1][kb] = M::run(__builtin_bit_cast(typename M::frag, f[ks]), as_frag16<T>(qf[1][ks]), s[1][kb]); }
+#define V3D_KM4(f, kb) { V3D_KM0(f, kb) V3D_KM(f, 1, kb) V3D_KM(f, 2, kb) V3D_KM(f, 3, kb) }
+  v4i ka_[4], kc_[4];                // K fragments of two key blocks: [ks]
+  auto qk_fill = [&](auto kb_c) {
+    constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+    auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+    V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
+    V3D_KR(kc[0], 0, KB + 4096); V3D_KR(kc[1], 1, KB + 4096); V3D_KR(kc[2], 2, KB + 4096); V3D_KR(kc[3], 3, KB + 4096);
+  };
+  auto qk_run = [&](auto kb_c, f32x4 (&s)[2][4]) {
+    constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+    auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+    V3D_KW(4, ka); V3D_KM4(ka, 0)
+    V3D_KR(ka[0], 0, KB + 8192); V3D_KR(ka[1], 1, KB + 8192); V3D_KR(ka[2], 2, KB + 8192); V3D_KR(ka[3], 3, KB + 8192);
+    V3D_KW(4, kc); V3D_KM4(kc, 1)
+    V3D_KR(kc[0], 0, KB + 12288); V3D_KR(kc[1], 1, KB + 12288); V3D_KR(kc[2], 2, KB + 12288); V3D_KR(kc[3], 3, KB + 12288);
+    V3D_KW(4, ka); V3D_KM4(ka, 2)
+    V3D_KW(0, kc); V3D_KM4(kc, 3)
+  };
+
+  auto mask_scores = [&](f32x4 (&s)[2][4], int t) {
+    const int kv0 = t * AT_BKV;
+    const bool need_mask = (CAUSAL && kv0 + AT_BKV - 1 > wave_first_pos) || (kv0 + AT_BKV > p.Sk);
+    if (need_mask) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        int last = p.Sk - 1;
+        if (CAUSAL) last = q_pos[qb] < last ? q_pos[qb] : last;
+        const int limit = last - kv0 - key_g;            // visible iff 16kb + r <= limit
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[qb][kb][r] = (16 * kb + r) > limit ? -INFINITY : s[qb][kb][r];
+      }
+    }
+  };
+  // the raise of the running maximum of query block qb (tile 0 fixes it; later only the rare tile whose row-sum share crossed the
+  // limit gets here): per QUERY decision, as attn_prefill_kernel's - the query's 64 scores of the tile sit in 4 lanes
+  auto raise_max = [&](f32x4 (&s)[2][4], int qb, int t) -> float {
+    float mx = s[qb][0][0];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    const float mp = fmaxf(mx, __shfl_xor(mx, 32));
+    float d = t == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);
+    d = mp == -INFINITY ? 0.f : d;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[qb][kb][r] -= d;
+    m_run[qb] += d;
+    const float nm = -m_run[qb];
+    negm[qb] = f32x4{nm, nm, nm, nm};
+    return t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+  };
+  // quarter (qb, j): the 8 scores of key blocks 2j, 2j+1 -> exp2 -> the P^T fragment of 32-key step j (k index 8g + i <-> key
+  // 16(2j + (i >> 2)) + key_g + (i & 3): the order V^T's fragments are read in) + the lane's row-sum share
+  auto softmax_quarter = [&](const f32x4 (&s)[2][4], int qb, int j, Frag16& pf, float& ls) {
+    float e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(s[qb][2 * j + (i >> 2)][i & 3]);
+    ls += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+    pf.u = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
+  };
+
+  // V^T fragments of one d-block pair (2dp, 2dp+1): f[4dbl + kb] = rows of key block kb, d block 2dp + dbl
+#define V3D_VR(f, dp, VB) { \
+  const unsigned a0 = vaddr0 ^ ((2 * (dp)) << 5), a1 = vaddr0 ^ ((2 * (dp) + 1) << 5); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[0]) : "v"(a0), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[1]) : "v"(a0), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[2]) : "v"(a0), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[3]) : "v"(a0), "i"(VB + 12288)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[4]) : "v"(a1), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[5]) : "v"(a1), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[6]) : "v"(a1), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[7]) : "v"(a1), "i"(VB + 12288)); }
+#define V3D_VW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory")
+
+  // One pipeline step (attn_prefill_kernel's): S' of tile t+1, then O^T += V^T . P^T of tile t with the softmax of tile t+1 slotted
+  // between its MFMAs.  pc / pn: P^T fragments [2qb + j] of tile t / t+1.
+  auto step = [&](auto par_c, auto full_c, int t, Frag16 (&pc)[4], Frag16 (&pn)[4]) {
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr bool FULL = decltype(full_c)::value != 0;
+    constexpr int VB = PAR * 2 * AT_TILE;
+    const unsigned vaddr0 = vaddr0_;
+    const bool do_qk = FULL || t + 1 < n_wave, do_pv = FULL || t < n_wave;          // wave-uniform
+    f32x4 s[2][4];
+    if (do_qk) qk_fill(IntC<1 - PAR>{});
+    if constexpr (FULL) {
+      stage_k_fast(PAR, t + 2);
+      stage_v_fast(1 - PAR, t + 1);
+    } else {
+      if (t + 2 < n_tiles) stage_k(PAR, t + 2);
+      if (t + 1 < n_tiles) stage_v(1 - PAR, t + 1);
+    }
+    if (do_qk) qk_run(IntC<1 - PAR>{}, s);
+    v2i va[8], vc[8];
+    if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    float ls[2] = {0.f, 0.f};
+    if (do_qk) mask_scores(s, t + 1);
+    auto mmav = [&](const v2i* f, int dp, int quarter) {
+#pragma unroll
+      for (int dbl = 0; dbl < 2; ++dbl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const v4i vf = {f[4 * dbl + 2 * j][0], f[4 * dbl + 2 * j][1], f[4 * dbl + 2 * j + 1][0], f[4 * dbl + 2 * j + 1][1]};
+          o[0][2 * dp + dbl] = M::run(__builtin_bit_cast(typename M::frag, vf), as_frag16<T>(pc[j]), o[0][2 * dp + dbl]);
+          o[1][2 * dp + dbl] = M::run(__builtin_bit_cast(typename M::frag, vf), as_frag16<T>(pc[2 + j]), o[1][2 * dp + dbl]);
+        }
+      if (do_qk) {
+        softmax_quarter(s, quarter >> 1, quarter & 1, pn[quarter], ls[quarter >> 1]);
+        asm volatile("" : "+v"(pn[quarter].i4), "+v"(ls[0]), "+v"(ls[1]));      // keep the quarter's VALU here, between the MFMAs
+      }
+    };
+    if (do_pv) {
+      V3D_VW(8, va); mmav(va, 0, 0); V3D_VR(va, 2, VB)
+      V3D_VW(8, vc); mmav(vc, 1, 1); V3D_VR(vc, 3, VB)
+      V3D_VW(8, va); mmav(va, 2, 2);
+      V3D_VW(0, vc); mmav(vc, 3, 3);
+    }
+    if (do_qk) {
+      if (__any(ls[0] > AT_LS_LIMIT || ls[1] > AT_LS_LIMIT)) {     // wave-uniform, rare (a lane holds 16 of a query's probabilities)
+        asm volatile("; V3D_RARE_BEGIN (tests/test_kernel_resources.py: register spills are tolerated only between these markers)");
+        f32x4 s2[2][4];
+        qk_fill(IntC<1 - PAR>{});
+        qk_run(IntC<1 - PAR>{}, s2);
+        mask_scores(s2, t + 1);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const float alpha = raise_max(s2, qb, t + 1);
+          if (__any(alpha != 1.0f)) {
+            ls[qb] = 0.f;
+            softmax_quarter(s2, qb, 0, pn[2 * qb], ls[qb]);
+            softmax_quarter(s2, qb, 1, pn[2 * qb + 1], ls[qb]);
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[qb][i][r] *= alpha;
+            l_run[qb] *= alpha;
+          }
+        }
+        asm volatile("; V3D_RARE_END");
+      }
+      l_run[0] += ls[0];
+      l_run[1] += ls[1];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue ----
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (n_tiles > 1) stage_k(1, 1);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi_ld = qi[qb] < p.Sq ? qi[qb] : p.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(Q + (int64_t)qi_ld * p.ldq + ks * 32 + g * 8);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = vec_get<T>(raw, j) * p.scale_log2;
+      qf[qb][ks].u = vec_pack<T>(f);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Frag16 pa[4], pb[4];
+  {
+    f32x4 s[2][4];
+    qk_fill(IntC<0>{});
+    qk_run(IntC<0>{}, s);
+    __builtin_amdgcn_s_barrier();      // every wave has read K of tile 0 before step 0 restages its buffer (tile 2)
+    mask_scores(s, 0);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      raise_max(s, qb, 0);
+      float ls = 0.f;
+      softmax_quarter(s, qb, 0, pa[2 * qb], ls);
+      softmax_quarter(s, qb, 1, pa[2 * qb + 1], ls);
+      l_run[qb] = ls;
+    }
+  }
+  {
+    int n_full = n_tiles - 2 < n_wave - 1 ? n_tiles - 2 : n_wave - 1;
+    n_full = (n_full < p.Sk / AT_BKV - 2 ? n_full : p.Sk / AT_BKV - 2) & ~1;
+    n_full = __builtin_amdgcn_readfirstlane(n_full);
+    int t = 0;
+    for (; t < n_full; t += 2) {
+      step(IntC<0>{}, IntC<1>{}, t, pa, pb);
+      step(IntC<1>{}, IntC<1>{}, t + 1, pb, pa);
+    }
+    for (; t < n_tiles; t += 2) {
+      step(IntC<0>{}, IntC<0>{}, t, pa, pb);
+      if (t + 1 < n_tiles) step(IntC<1>{}, IntC<0>{}, t + 1, pb, pa);
+    }
+  }
+  __syncthreads();
+#undef V3D_KR
+#undef V3D_KW
+#undef V3D_KM0
+#undef V3D_KM
+#undef V3D_KM4
+#undef V3D_VR
+#undef V3D_VW
+
+  // ---- normalise, transpose through LDS, store whole rows ----
+  constexpr int OROW = D * 2 + 16;
+  char* so = smem + wave * 32 * OROW;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 16);
+    l_tot = l_tot + __shfl_xor(l_tot, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if constexpr (LSE) {
+      if (g == 0 && qi[qb] < p.Sq) p.lse[((int64_t)b * p.Hq + head) * p.Sq + qi[qb]] = l_tot > 0.f ? m_run[qb] + __log2f(l_tot) : -INFINITY;
+    }
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int d = 16 * db + 4 * g;
+      uint2 pk;
+      pk.x = pack2<T>(o[qb][db][0] * inv, o[qb][db][1] * inv);
+      pk.y = pack2<T>(o[qb][db][2] * inv, o[qb][db][3] * inv);
+      *reinterpret_cast<uint2*>(so + (16 * qb + n) * OROW + d * 2) = pk;
+    }
+  }
+  __syncthreads();
+  uint16_t* O = (uint16_t*)p.o + b * p.bso + (int64_t)head * p.hso;
+  constexpr int OCH = D / 8;
+#pragma unroll
+  for (int i = 0; i < (32 * OCH + 63) / 64; ++i) {
+    const int idx = i * 64 + lane;
+    const int row = idx / OCH, ch = idx - row * OCH;
+    const int q = q0 + wave * 32 + row;
+    if (row < 32 && q < p.Sq && ch * 8 < p.d_out)
+      *reinterpret_cast<uint4*>(O + (int64_t)q * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(so + row * OROW + ch * 16);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Prefill, head dim 128, 64 queries per wave (r02): workgroup = 4 waves = 256 queries of one (batch, head), ONE workgroup per CU,
 // each wave alone on its SIMD with the whole 512-entry register file (O^T of its two 32-query blocks: 128 accumulator
 // registers).  The same LDS image, staging, swizzle, S^T = K.Q^T / O^T += V^T.P^T operand trick and max-deferred softmax as
@@ -1616,6 +1991,13 @@ static int attn64_mode() {
   return e ? atoi(e) : 0;
 }
 
+// V3D_ATTN_MFMA=16 selects attn_prefill16_kernel (v_mfma_f32_16x16x32) for head dim 128; default 32 = attn_prefill_kernel
+// (v_mfma_f32_32x32x16).  A/B: profiles/r04_attn_mfma_shape.txt.
+static int attn_mfma_shape() {
+  const char* e = getenv("V3D_ATTN_MFMA");
+  return e ? atoi(e) : 32;
+}
+
 template <typename T>
 static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t st) {
   if (D == 128 && p.Sq >= 64 && attn64_mode() != 0 && !p.lse) {
@@ -1639,6 +2021,25 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
   AttnArgs pm = p;
   pm.n_qt = (p.Sq + AT_BQ - 1) / AT_BQ;
   pm.xcd_p = 0;
+  if (D == 128 && attn_mfma_shape() == 16) {      // r04 A/B: the same kernel on v_mfma_f32_16x16x32 (V3D_ATTN_MFMA=16)
+#define V3D_ATTN16(CC, LL)                                                                                        \
+    {                                                                                                             \
+      auto k = attn_prefill16_kernel<T, CC, LL>;                                                                  \
+      static bool done = false;                                                                                   \
+      if (!done) {                                                                                                \
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);   \
+        if (e != hipSuccess) { set_error("v3d_attention: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; } \
+        done = true;                                                                                              \
+      }                                                                                                           \
+      hipLaunchKernelGGL(k, grid, block, AT_LDS, st, pm);                                                         \
+    }
+    if (causal && p.lse) V3D_ATTN16(true, true)
+    else if (p.lse) V3D_ATTN16(false, true)
+    else if (causal) V3D_ATTN16(true, false)
+    else V3D_ATTN16(false, false)
+#undef V3D_ATTN16
+    return check_launch("v3d_attention (16x16x32)");
+  }
   {   // XCD-aware mapping (attn_prefill_kernel): causal prefill at head dim 128 with the kv heads dividing the 8 XCDs
     const int n_kv = p.Hq / p.group;
     static const int xcd_env = getenv("V3D_ATTN_XCD") ? atoi(getenv("V3D_ATTN_XCD")) : 1;

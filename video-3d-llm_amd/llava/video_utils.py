@@ -105,8 +105,12 @@ class VideoProcessor:
 
     def describe_scene(self, video_id, force_sample=False, frames_upbound=0):
         """What v3d.pipeline.AsyncSceneLoader needs to decode a scene's sampled frames off the main thread."""
-        return {"files": self.frame_files(video_id, force_sample, frames_upbound), "axis_align": self._align(video_id).tolist(),
-                "K": torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()}
+        d = {"files": self.frame_files(video_id, force_sample, frames_upbound), "axis_align": self._align(video_id).tolist(),
+             "K": torch.from_numpy(np.array(self.scene[video_id]["depth_cam2img"])).float()}
+        if "norm" in self.frame_sampling_strategy:      # calculate_world_coords(do_normalize=True), :232-236: the pipeline clamps on the device
+            scene_id = video_id.split("/")[-1]
+            d["clamp"] = (self.pc_min[scene_id].tolist(), self.pc_max[scene_id].tolist())
+        return d
 
     def load_raw(self, video_id, frame_files):
         """The sampled frames' files -> host arrays: depth [F,Hd,Wd] int16 view of the 16-bit PNG values, frames [F,Hc,Wc,3] uint8,

@@ -740,6 +740,10 @@ def _resize_tables(in_size, out_size, device):
     if t is None:
         b, k, ks = pil_resample_tables(in_size, out_size)
         t = _RESIZE_TABLES[key] = (b.to(device).contiguous(), k.to(device).contiguous(), ks)
+        # the tables outlive this call and are read from OTHER streams later (two prefill streams): the one-off upload must have
+        # landed before any of them can see the cached tensors
+        if torch.device(device).type == "cuda":
+            torch.cuda.current_stream(torch.device(device)).synchronize()
     return t
 
 

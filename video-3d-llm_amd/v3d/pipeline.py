@@ -82,7 +82,8 @@ class _HostBlock:
 class AsyncSceneLoader:
     """Decodes the frames of the scenes of `keys` (one key per question, in question order) `ahead` scenes in front of the consumer,
     in worker PROCESSES (v3d.frame_io) that write straight into pinned shared-memory blocks.
-    describe(key) -> dict(files=[colour file of each frame], axis_align=4x4, K=[4,4] f32 tensor) - called on the consumer's thread.
+    describe(key) -> dict(files=[colour file of each frame], axis_align=4x4, K=[4,4] f32 tensor[, clamp=(lo, hi)]) - called on the
+    consumer's thread.
     get(j) -> (payload, seconds waited): payload = dict(depth int16-view [F,Hd,Wd], frames u8 [F,Hc,Wc,3], pose f32 [F,4,4], K [F,4,4],
     _done=callback(event)) - the consumer calls payload["_done"](event recorded after its uploads, or None) when it no longer needs
     the host arrays; the block is then recycled.  Equal keys within `keep` scenes of each other are decoded once.
@@ -92,6 +93,13 @@ class AsyncSceneLoader:
         from . import frame_io
         self.io = frame_io
         self.keys, self.describe = list(keys), describe
+        if pool is None and workers > 0 and torch.cuda.is_available() and torch.cuda.is_initialized():
+            # forking a process whose HIP runtime threads and pinned mappings are live is fragile (frame_io.make_pool: make the pool
+            # BEFORE the GPU is touched and pass it in); without one the frames are decoded on the calling thread
+            import warnings
+            warnings.warn("AsyncSceneLoader: no decoding pool was passed and the GPU is already initialised - decoding on the calling "
+                          "thread (make the pool with v3d.frame_io.make_pool before the first GPU call and pass pool=...)", stacklevel=2)
+            workers = 0
         self.own_pool = pool is None and workers > 0
         self.pool = pool if pool is not None else (frame_io.make_pool(workers) if workers > 0 else None)
         self.ahead, self.keep = ahead, keep
@@ -135,6 +143,7 @@ class AsyncSceneLoader:
         blk = self._block(nbytes)
         payload = blk.tensors(layout)
         payload["K"] = d["K"].float().unsqueeze(0).repeat(len(files), 1, 1)
+        payload["clamp"] = d.get("clamp")           # ([lo x, y, z], [hi x, y, z]) under a 'norm' frame-sampling strategy, else None
         align = [list(map(float, r)) for r in d["axis_align"]]
         job = {"payload": payload, "block": blk, "refs": 2, "layout": layout, "files": files, "align": align, "futures": None}     # this position + the key table
         if self.pool is not None:
@@ -230,11 +239,16 @@ class ScenePipeline:
                 raw["_done"](up)
             self.upload_seconds += time.perf_counter() - t0
             coords = ops.unproject_sampled(depth, K, pose, self.crop, dt)                                     # K1 + K2
-            H, W = frames.shape[1:3]
-            if (H, W) == (self.crop, self.crop):
+            bounds = raw.get("clamp")                            # 'norm' strategies: calculate_world_coords(do_normalize=True), :232-236
+            if bounds is not None:                               # (clamping commutes with the nearest-neighbour gather)
+                ops.clamp_xyz(coords, bounds[0], bounds[1])
+            if tuple(frames.shape[1:3]) == (self.crop, self.crop):
                 images = ops.preprocess_rgb(frames, dt, self.mean, self.std, self.rescale)
             else:                                                # video_utils.py:297-306 + siglip_encoder.py:47-67 in one kernel
-                new_w = int(W * (self.crop / H))
+                # the DEPTH map's size steers the colour resize too: V, H, W come from world_coords (video_utils.py:264, 298-299), so
+                # ScanNet's 1296 x 968 colour frames go to 512 x 384 (640 x 480 depth), not to the 514 their own aspect would give
+                Hd, Wd = depth.shape[1:3]
+                new_w = int(Wd * (self.crop / Hd))
                 images = ops.resize_crop_rgb(frames, (self.crop, new_w), crop=(0, (new_w - self.crop) // 2, self.crop, self.crop),
                                              dtype=dt, mean=self.mean, std=self.std, rescale=self.rescale)
         if sample.key is not None and self.scene_cache_size > 0:
@@ -323,5 +337,6 @@ class ScenePipeline:
                     cur.wait_stream(st)
                 cur.wait_stream(sB)
         finally:
+            eng.use_workspace(self.workspaces[0])      # (a prefill that raised part-way may have left the second one selected)
             eng.use(keep)
         return out

@@ -137,7 +137,28 @@ class LlavaQwenTrainable(nn.Module):
         hd = tree["llm"]["layers"][0]["qkv"].shape[0] // (n_q + 2 * n_kv)
         m = cls(tree, n_q, n_kv, head_dim=hd, vit_heads=vit_heads, vit_inter=sd[VIT + "encoder.layers.0.mlp.fc1.weight"].shape[0], **kw)
         m._patch_shape = tuple(pw.shape)
+        # tensors a real LlavaQwen checkpoint holds and this module does not train - vision_model.post_layernorm (stays in the tower after
+        # siglip_encoder.py:570-571), the vision_model.head.* pooling head, the ground_head* tensors, rotary inv_freq buffers, ...: kept
+        # as they came (frozen, on the host) and emitted unchanged by reference_state_dict(), so that a checkpoint saved through this
+        # surface loads strictly on the reference's side
+        m._passthrough = {k: v.detach().clone().cpu() for k, v in sd.items() if k not in m._modelled_keys(n_vit, n_llm)}
         return m
+
+    @staticmethod
+    def _modelled_keys(n_vit, n_llm):
+        keys = {VIT + "embeddings.patch_embedding.weight", VIT + "embeddings.patch_embedding.bias", VIT + "embeddings.position_embedding.weight",
+                "model.mm_projector.0.weight", "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias",
+                "model.image_newline", "model.embed_tokens.weight", "model.norm.weight", "lm_head.weight"}
+        for i in range(n_vit):
+            p = VIT + f"encoder.layers.{i}."
+            for n in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "mlp.fc1", "mlp.fc2", "layer_norm1", "layer_norm2"):
+                keys |= {p + n + ".weight", p + n + ".bias"}
+        for i in range(n_llm):
+            p = f"model.layers.{i}."
+            keys |= {p + f"self_attn.{n}_proj.{w}" for n in ("q", "k", "v") for w in ("weight", "bias")}
+            keys |= {p + "self_attn.o_proj.weight", p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", p + "mlp.down_proj.weight",
+                     p + "input_layernorm.weight", p + "post_attention_layernorm.weight"}
+        return keys
 
     def reference_state_dict(self):
         """Back to the reference's keys and shapes (fused / stacked / padded layouts undone; the padding holds zeros)."""
@@ -173,6 +194,8 @@ class LlavaQwenTrainable(nn.Module):
             out[p + "mlp.down_proj.weight"] = L["down"].clone()
             out[p + "input_layernorm.weight"], out[p + "post_attention_layernorm.weight"] = L["ln1"].clone(), L["ln2"].clone()
         out["model.norm.weight"], out["lm_head.weight"] = tr["llm"]["norm"].clone(), tr["llm"]["lm_head"].clone()
+        for k, v in getattr(self, "_passthrough", {}).items():      # unmodelled tensors of the source checkpoint, unchanged
+            out[k] = v.clone()
         return out
 
     # ------------------------------------------------------------------ forward (llava_qwen.py:121-205 for one video sample with labels)
