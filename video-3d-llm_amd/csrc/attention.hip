@@ -82,6 +82,9 @@ struct AttnArgs {
   int n_qt;                          // query tiles per head (the mapped form needs it; the 3-D grid reads gridDim.y)
 };
 
+#ifndef V3D_ATTN_VPF
+#define V3D_ATTN_VPF 1   // r04: first V^T fragment reads of a steady-state step issued inside the score phase (0: behind it, the r03 order; bit-identical)
+#endif
 #ifdef V3D_ATTN_PROF   // tools/probes/attn_prof.hip only: per-wave cycle split of the tile loop (never in the product build)
 __device__ unsigned long long g_attn_prof[4 * 4096];
 __device__ unsigned long long g_attn_blocks[4 * 4096];   // per workgroup: realtime start, end, shader-clock delta, HW_ID
@@ -267,8 +270,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       V3D_KR(kc[2], 0, KB + 8192); V3D_KR(kc[3], 1, KB + 8192);
     }
   };
-  auto qk_run = [&](auto kb_c, f32x16 (&s)[2]) {
+  // `mid` (r04): called where the first half of the fragment ring has had its last use - the steady-state step issues the first V^T
+  // fragment reads of the P.V phase there, into the registers that half frees, one MFMA group (and its LDS latency: 300-450 cycles
+  // under this load, profiles/r03_attn_probe.txt "vreads") earlier than behind the score MFMAs.  VPF = LDS reads `mid` issued: the
+  // last K wait leaves exactly those in flight (LDS data returns in order).
+  auto qk_run = [&](auto kb_c, f32x16 (&s)[2], auto vpf_c, auto&& mid) {
     constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+    constexpr int VPF = decltype(vpf_c)::value;
+    static_assert(VPF == 0 || VPF == 8, "the mid hook issues none or eight reads");
     auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
     const float init = -m_run;
 #pragma unroll
@@ -281,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       V3D_KW(4, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 1, 0, 5); V3D_KM(kc, 2, 0, 6); V3D_KM(kc, 3, 0, 7);
       V3D_KR(kc[0], 4, KB + 8192); V3D_KR(kc[1], 5, KB + 8192); V3D_KR(kc[2], 6, KB + 8192); V3D_KR(kc[3], 7, KB + 8192);
       V3D_KW(4, ka); V3D_KM(ka, 0, 1, 0); V3D_KM(ka, 1, 1, 1); V3D_KM(ka, 2, 1, 2); V3D_KM(ka, 3, 1, 3);
-      V3D_KW(0, kc); V3D_KM(kc, 0, 1, 4); V3D_KM(kc, 1, 1, 5); V3D_KM(kc, 2, 1, 6); V3D_KM(kc, 3, 1, 7);
+      mid();
+      if constexpr (VPF == 8) { V3D_KW(8, kc); } else { V3D_KW(0, kc); }
+      V3D_KM(kc, 0, 1, 4); V3D_KM(kc, 1, 1, 5); V3D_KM(kc, 2, 1, 6); V3D_KM(kc, 3, 1, 7);
     } else if constexpr (KSV == 6) {   // KS == 6 (head dim 96): 4 + 2 k-steps per key half
       V3D_KW(4, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
       V3D_KR(ka[0], 2, KB + 8192); V3D_KR(ka[1], 3, KB + 8192); V3D_KR(ka[2], 4, KB + 8192); V3D_KR(ka[3], 5, KB + 8192);
@@ -375,10 +386,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       if (t + 2 < n_tiles) stage_k(PAR, t + 2);
       if (t + 1 < n_tiles) stage_v(1 - PAR, t + 1);
     }
-    if (do_qk) qk_run(IntC<1 - PAR>{}, s);
-    V3D_STAMP(ts1);
     v2i va[8], vc[8];          // V^T fragments [2*s4 + half], ring of two d-tiles
-    if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    if constexpr (FULL && KS == 8 && V3D_ATTN_VPF) {
+      qk_run(IntC<1 - PAR>{}, s, IntC<8>{}, [&] { V3D_VR(va, 0, VB) });
+      V3D_VR(vc, 1, VB)
+    } else {
+      if (do_qk) qk_run(IntC<1 - PAR>{}, s, IntC<0>{}, [] {});
+      if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    }
+    V3D_STAMP(ts1);
     float ls0 = 0.f, ls1 = 0.f;
     if (do_qk) mask_scores(s, t + 1);
     V3D_STAMP(ts2);
@@ -414,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
         asm volatile("; V3D_RARE_BEGIN (tests/test_kernel_resources.py: register spills are tolerated only between these markers)");
         f32x16 s2[2];
         qk_fill(IntC<1 - PAR>{});
-        qk_run(IntC<1 - PAR>{}, s2);
+        qk_run(IntC<1 - PAR>{}, s2, IntC<0>{}, [] {});
         mask_scores(s2, t + 1);
         const float alpha = raise_max(s2, t + 1);
         if (__any(alpha != 1.0f)) {   // the maximum moved: P of tile t+1 again at the new reference, O and l brought to it
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     f32x16 s[2];
     float ls0 = 0.f, ls1 = 0.f;
     qk_fill(IntC<0>{});
-    qk_run(IntC<0>{}, s);
+    qk_run(IntC<0>{}, s, IntC<0>{}, [] {});
     __builtin_amdgcn_s_barrier();      // every wave has read K of tile 0 before step 0 restages its buffer (tile 2)
     mask_scores(s, 0);
     raise_max(s, 0);
@@ -693,15 +709,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
     V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
     V3D_KR(kc[0], 0, KB + 4096); V3D_KR(kc[1], 1, KB + 4096); V3D_KR(kc[2], 2, KB + 4096); V3D_KR(kc[3], 3, KB + 4096);
   };
-  auto qk_run = [&](auto kb_c, f32x4 (&s)[2][4]) {
+  auto qk_run = [&](auto kb_c, f32x4 (&s)[2][4], auto vpf_c, auto&& mid) {      // (mid / VPF: see attn_prefill_kernel)
     constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+    constexpr int VPF = decltype(vpf_c)::value;
     auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
     V3D_KW(4, ka); V3D_KM4(ka, 0)
     V3D_KR(ka[0], 0, KB + 8192); V3D_KR(ka[1], 1, KB + 8192); V3D_KR(ka[2], 2, KB + 8192); V3D_KR(ka[3], 3, KB + 8192);
     V3D_KW(4, kc); V3D_KM4(kc, 1)
     V3D_KR(kc[0], 0, KB + 12288); V3D_KR(kc[1], 1, KB + 12288); V3D_KR(kc[2], 2, KB + 12288); V3D_KR(kc[3], 3, KB + 12288);
     V3D_KW(4, ka); V3D_KM4(ka, 2)
-    V3D_KW(0, kc); V3D_KM4(kc, 3)
+    mid();
+    if constexpr (VPF == 8) { V3D_KW(8, kc); } else { V3D_KW(0, kc); }
+    V3D_KM4(kc, 3)
   };
 
   auto mask_scores = [&](f32x4 (&s)[2][4], int t) {
@@ -781,9 +800,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
       if (t + 2 < n_tiles) stage_k(PAR, t + 2);
       if (t + 1 < n_tiles) stage_v(1 - PAR, t + 1);
     }
-    if (do_qk) qk_run(IntC<1 - PAR>{}, s);
     v2i va[8], vc[8];
-    if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    if constexpr (FULL && V3D_ATTN_VPF) {
+      qk_run(IntC<1 - PAR>{}, s, IntC<8>{}, [&] { V3D_VR(va, 0, VB) });
+      V3D_VR(vc, 1, VB)
+    } else {
+      if (do_qk) qk_run(IntC<1 - PAR>{}, s, IntC<0>{}, [] {});
+      if (do_pv) { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+    }
     float ls[2] = {0.f, 0.f};
     if (do_qk) mask_scores(s, t + 1);
     auto mmav = [&](const v2i* f, int dp, int quarter) {
@@ -811,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
         asm volatile("; V3D_RARE_BEGIN (tests/test_kernel_resources.py: register spills are tolerated only between these markers)");
         f32x4 s2[2][4];
         qk_fill(IntC<1 - PAR>{});
-        qk_run(IntC<1 - PAR>{}, s2);
+        qk_run(IntC<1 - PAR>{}, s2, IntC<0>{}, [] {});
         mask_scores(s2, t + 1);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -858,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
   {
     f32x4 s[2][4];
     qk_fill(IntC<0>{});
-    qk_run(IntC<0>{}, s);
+    qk_run(IntC<0>{}, s, IntC<0>{}, [] {});
     __builtin_amdgcn_s_barrier();      // every wave has read K of tile 0 before step 0 restages its buffer (tile 2)
     mask_scores(s, 0);
 #pragma unroll
