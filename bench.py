@@ -283,10 +283,13 @@ def bench_tokenizer():
                                    additional_special_tokens=["<|im_start|>", "<|im_end|>"])
 
 
-def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8):
+def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reuse_questions_per_scene=32):
     """The PRODUCT's eval loop end to end on files: v3d.eval_scanqa.model_answer_fn (pipelined: asynchronous loader -> upload -> device
     geometry / Pillow-exact resize -> ViT -> ... -> grouped decode with the device-side stop test) over a synthetic on-disk scene set at the
-    dataset's true sizes.  Every question asks about ANOTHER scene than the previous eight (no scene reuse: the loader's worst case)."""
+    dataset's true sizes.  Two runs over the same files -> (eval_runner, reuse_runner):
+      eval_runner   every question asks about ANOTHER scene than the previous eight (no scene reuse: the loader's worst case);
+      reuse_runner  --reuse-scenes on the pipeline (r04): `reuse_questions_per_scene` consecutive questions per scene share ONE scene prefill
+                    and are answered in batches of 16, the next scene's load / ViT / prefix prefill running beside them."""
     import contextlib
     import shutil
     import tempfile
@@ -302,15 +305,17 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8):
         tok = bench_tokenizer()
         with contextlib.redirect_stdout(sys.stderr):
             vp = VideoProcessor(video_folder=root, annotation_dir=os.path.join(root, "embodiedscan"), metadata_dir=os.path.join(root, "metadata"))
-        words = " ".join(f"t{(7 * k) % 290 + 1}" for k in range(64))
-        def question(i, n_words):
-            return {"id": f"q{i}", "video": sids[i % n_scenes],
-                    "conversations": [{"from": "human", "value": "<image>\n" + " ".join(words.split()[:n_words])}, {"from": "gpt", "value": "t42"}],
+        words = [f"t{(7 * k) % 290 + 1}" for k in range(64)]
+
+        def question(i, n_words, scene, salt=0):
+            text = " ".join(words[(salt + j) % 64] for j in range(n_words))
+            return {"id": f"q{i}", "video": sids[scene % n_scenes],
+                    "conversations": [{"from": "human", "value": "<image>\n" + text}, {"from": "gpt", "value": "t42"}],
                     "metadata": {"dataset": "scanqa", "question_type": "what", "answers": ["t42"]}}
         n_words = 40
-        while len(E.build_prompt_ids(question(0, n_words), tok)[0]) - 1 < TEXT_PRE + TEXT_POST and n_words < 64:
+        while len(E.build_prompt_ids(question(0, n_words, 0), tok)[0]) - 1 < TEXT_PRE + TEXT_POST and n_words < 64:
             n_words += 1
-        qs = [question(i, n_words) for i in range(n_questions)]
+        qs = [question(i, n_words, i) for i in range(n_questions)]
         S = len(E.build_prompt_ids(qs[0], tok)[0]) - 1 + FRAMES * 210
         model = types.SimpleNamespace(engine=eng, device=dev, dtype=eng.dtype, _eos=lambda: None)
         stats = {}
@@ -324,15 +329,39 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8):
         dt_s = time.perf_counter() - t0
         assert len(recs) == n_questions and all(r["sample_id"] == q["id"] for r, q in zip(recs, qs))
         per_q = {k: v / n_questions * 1e3 for k, v in stats["host_thread_seconds"].items()}
-        return {"what": "the product's eval loop (v3d.eval_scanqa.model_answer_fn, pipelined) end to end on a synthetic ON-DISK scene set: per question "
-                        "32 x (1296x968 JPEG + 640x480 16-bit PNG + pose txt) decoded by the asynchronous host loader, uploaded, back-projected, resized "
-                        "(Pillow-exact, on the device), then the same ViT -> projector -> fusion -> Qwen2 prefill S=%d -> %d greedy tokens as the headline; "
-                        "every question about another scene than the eight before it (no reuse), files in the page cache" % (S, NEW_TOKENS),
-                "value": n_questions / dt_s, "unit": "scenes/s", "ms_per_step": dt_s / n_questions * 1e3, "questions": n_questions, "seq_len": S,
-                "loader_processes": n_workers, "host_cores": os.cpu_count(),
-                "loader_core_ms_per_question": per_q, "gpu_waited_for_loader_ms_per_question": stats["loader_wait_seconds"] / n_questions * 1e3,
-                "upload_enqueue_ms_per_question": stats["upload_enqueue_seconds"] / n_questions * 1e3,
-                "upload_mb_per_question": (FRAMES * (1296 * 968 * 3 + 640 * 480 * 2)) / 1e6, "dataset_write_s": t_write}
+        plain = {"what": "the product's eval loop (v3d.eval_scanqa.model_answer_fn, pipelined) end to end on a synthetic ON-DISK scene set: per question "
+                         "32 x (1296x968 JPEG + 640x480 16-bit PNG + pose txt) decoded by the asynchronous host loader, uploaded, back-projected, resized "
+                         "(Pillow-exact, on the device; colour to 512 x 384 as the depth map's aspect dictates), then the same ViT -> projector -> fusion -> "
+                         "Qwen2 prefill S=%d -> %d greedy tokens as the headline; every question about another scene than the eight before it (no reuse), "
+                         "files in the page cache" % (S, NEW_TOKENS),
+                 "value": n_questions / dt_s, "unit": "scenes/s", "ms_per_step": dt_s / n_questions * 1e3, "questions": n_questions, "seq_len": S,
+                 "loader_processes": n_workers, "host_cores": os.cpu_count(),
+                 "loader_core_ms_per_question": per_q, "gpu_waited_for_loader_ms_per_question": stats["loader_wait_seconds"] / n_questions * 1e3,
+                 "upload_enqueue_ms_per_question": stats["upload_enqueue_seconds"] / n_questions * 1e3,
+                 "upload_mb_per_question": (FRAMES * (1296 * 968 * 3 + 640 * 480 * 2)) / 1e6, "dataset_write_s": t_write}
+        # ---- scene reuse on the pipeline, from the same files: consecutive questions per scene
+        QPS = reuse_questions_per_scene
+        n_sc = min(n_scenes, 4)
+        rq = [question(1000 + sc * QPS + j, n_words, sc, salt=3 * j + sc) for sc in range(n_sc) for j in range(QPS)]
+        rstats = {}
+        rfn = E.model_answer_fn(model, tok, SigLipImageProcessor(), vp, "bench", FRAMES, NEW_TOKENS, reuse_scenes=True, pipeline=True, stats=rstats,
+                                pool=pool, workers=n_workers)
+        rfn(rq[:16])                                      # warm-up (the answer batches' buffers: 16 per-question caches)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rrecs = rfn(rq)
+        torch.cuda.synchronize()
+        rdt = time.perf_counter() - t0
+        assert len(rrecs) == len(rq) and all(r["sample_id"] == q["id"] for r, q in zip(rrecs, rq))
+        ids0 = E.build_prompt_ids(rq[0], tok)[0]
+        at = int((ids0 == IMAGE_TOKEN_INDEX).nonzero()[0])
+        reuse = {"what": "--reuse-scenes ON the pipeline, end to end from the same files (v3d.pipeline.SceneReusePipeline): %d scenes x %d consecutive "
+                         "questions; per scene ONE load + upload + ViT + prefix prefill (%d rows), its questions (%d rows + %d new tokens each) answered in "
+                         "batches of 16 on another stream while the NEXT scene is loaded and prefilled; compare `cached_questions` (the answering alone, "
+                         "scene already prefilled, inputs resident)" % (n_sc, QPS, at + FRAMES * 210, len(ids0) - 1 - at, NEW_TOKENS),
+                 "value": len(rq) / rdt, "unit": "questions/s", "ms_per_question": rdt / len(rq) * 1e3, "questions": len(rq), "scenes": n_sc,
+                 "questions_per_scene": QPS, "gpu_waited_for_loader_ms_per_scene": rstats["loader_wait_seconds"] / n_sc * 1e3}
+        return plain, reuse
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
@@ -499,7 +528,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one scene at a time: no decode groups, no prefill/decode overlap")
-    ap.add_argument("--decode-group", type=int, default=16, help="scenes decoded together per pass over the weights (1..16)")
+    ap.add_argument("--decode-group", type=int, default=16, help="scenes decoded together per pass over the weights (1..32)")
+    ap.add_argument("--answer-batch", type=int, default=16, help="cached_questions / reuse_runner: questions answered together (1..32)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[3]: e4m3 linears in the Qwen2 prefill; the headline line becomes that run")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements appended to the default N=1 line (fp8, cached questions, grounding)")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip only the configs[3] extra")
@@ -564,7 +594,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    G_ALL = 1 if a.no_overlap else max(1, min(16, a.decode_group))
+    G_ALL = 1 if a.no_overlap else max(1, min(32, a.decode_group))
 
     def measure(eng, stamps):
         """W untimed warm-up scenes, then EXACTLY `steps` scenes between barrier + synchronize; max over ranks.  The timed region IS the
@@ -613,7 +643,7 @@ def main():
             "attention_us_per_layer": a_us, "attention_frac_of_2.5PF": 2.0 * 4096 * 4096 * 128 * 28 / a_us / 1e6 / 2500.0,
             "gate_up_gemm_us": st4["gemm"].mean_us(), "gate_up_gemm_frac_of_2.5PF": 2.0 * 4096 * 37888 * 3584 / st4["gemm"].mean_us() / 1e6 / 2500.0}
     if world == 1 and a.eval_runner_only:
-        extras["eval_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
+        extras["eval_runner"], extras["reuse_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
     elif world == 1 and not a.no_extras:
         nq, scene_ms = measure_cached_questions(eng, ops, scenes[0], dev, n_groups=max(1, a.steps // 4))
         extras["cached_questions"] = {
@@ -622,7 +652,8 @@ def main():
                     "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, NEW_TOKENS),
             "value": nq, "unit": "questions/s", "scene_prefill_ms": scene_ms}
         try:
-            extras["eval_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
+            extras["eval_runner"], extras["reuse_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
+            extras["reuse_runner"]["vs_cached_questions"] = extras["reuse_runner"]["value"] / nq
         except Exception as e:                          # an extra must never take the headline line down with it
             extras["eval_runner"] = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["ground_config2"] = {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 5   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds */
+#define V3D_ABI_VERSION 6   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds; 6: sumsq, *_rows entries take 1..32 rows */
 
 enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
 enum { V3D_U8_HWC = 16 };   /* v3d_resize_bicubic_u8 only: 8-bit interleaved output, no normalisation */
@@ -246,7 +246,7 @@ int64_t v3d_attention_decode_workspace_bytes(int Hq, int max_splits);
 int v3d_attention_decode(const void* q, const void* k_cache, const void* v_cache, void* o, int dtype, int Sk,
                          int Hq, int Hkv, int64_t ldk, int64_t ldv, int hsq, int hsk, int hso, float scale,
                          void* workspace, int64_t workspace_bytes, void* stream);
-/* The same for M = 1..16 scenes decoding together in ONE launch pair (the single-scene kernels are latency-bound, not
+/* The same for M = 1..32 (r04; was 16) scenes decoding together in ONE launch pair (the single-scene kernels are latency-bound, not
  * bandwidth-bound): query rows q + m*q_stride, outputs o + m*o_stride (elements), per-scene cache pointers and lengths
  * in HOST arrays of M entries; workspace >= M * v3d_attention_decode_workspace_bytes(Hq, 1024/Hkv).  Scene m's output
  * is bit-identical to v3d_attention_decode on it alone, whatever the other scenes' lengths: every scene partitions its keys
@@ -276,7 +276,7 @@ int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const v
                       void* stream);
 /* The same linear for M activation rows at once (M scenes decoding together share one pass over the weights; the
  * step is HBM-bound on them).  x [M, K] row stride ldx, res [M, N] row stride ldr, out [M, N'] row stride ldo.
- * M = 1 is v3d_linear_decode.  M = 2..16 (no fused norm, K % 128 == 0, N % 16 == 0): the weights feed the matrix cores
+ * M = 1 is v3d_linear_decode.  M = 2..32 (r04; two 16-row blocks per weight fragment above 16; no fused norm, K % 128 == 0, N % 16 == 0): the weights feed the matrix cores
  * (v_mfma_f32_16x16x32, activation rows as the B operand), so the cost does not grow with M and a row's result does not
  * depend on the other rows or on M; against the one-row form it differs by the f32 summation order only.  Other shapes
  * (fused norm, odd sizes): VALU form, M = 1..4, each row bit-identical to v3d_linear_decode on it. */
@@ -285,7 +285,7 @@ int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_w
                            int K, int dtype, int epilogue, void* stream);
 /* The decode linear over OCP e4m3 weights (BASELINE configs[3]; W8A16): W8 [N,K] bytes (row stride ldw) with one
  * f32 scale per output row as v3d_quantize_fp8_rows writes them; y[m,n] = scale_w[n] * sum_k W8[n,k] x[m,k], then
- * the epilogue of v3d_linear_decode.  K % 16 == 0.  M = 1: VALU form; M = 2..16 with K % 256 == 0, N % 16 == 0: matrix-core
+ * the epilogue of v3d_linear_decode.  K % 16 == 0.  M = 1: VALU form; M = 2..32 with K % 256 == 0, N % 16 == 0: matrix-core
  * form (weights widened to the activation type in registers; a row's result depends neither on the other rows nor on
  * M); other shapes: VALU form, M <= 4.  Not a reference code path (tolerance: tests/test_gpu_fp8.py). */
 int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8, int64_t ldw, const float* scale_w,
@@ -296,7 +296,7 @@ int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, const void* W8
  * of the QKV row (in place), rotated k and v copied to cache_row = [k heads | v heads]. */
 int v3d_rope_kv_append(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
                        const void* sin_table, int n_pos, int pos, void* cache_row, int dtype, void* stream);
-/* M = 1..16 scenes in one launch: QKV rows qkv + m*qkv_stride, positions pos[m] and cache rows cache_rows[m] (HOST arrays). */
+/* M = 1..32 scenes in one launch: QKV rows qkv + m*qkv_stride, positions pos[m] and cache rows cache_rows[m] (HOST arrays). */
 int v3d_rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_heads, int n_kv_heads, int head_dim,
                             const void* cos_table, const void* sin_table, int n_pos, const int* pos,
                             void* const* cache_rows, int dtype, void* stream);
@@ -480,6 +480,13 @@ int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight, const voi
 /* y[i] = T(y[i] + alpha * x[i]) for flat 16-bit tensors: gradient accumulation over micro-batches (train_multi.sh:31-32, 60:
  * gradient_accumulation_steps = 2), in the arithmetic torch uses when it adds a new gradient to .grad (f32 add, one rounding). */
 int v3d_axpy(void* y, const void* x, float alpha, int64_t n, int dtype, void* stream);
+
+/* Sum of squares of a flat tensor x [n] (f32 / f16 / bf16; 16-byte aligned) in f32 -> out[0] (device; accumulate != 0: added to it),
+ * deterministic (fixed partials folded in a fixed order).  The global gradient norm of gradient clipping - the HF Trainer's
+ * max_grad_norm = 1.0 behind scripts/zero2.json:36 "gradient_clipping": "auto" and torch.nn.utils.clip_grad_norm_ - is the square root
+ * of the sum of these over the gradient tensors.  workspace: v3d_sumsq_workspace_bytes() bytes of device scratch. */
+int64_t v3d_sumsq_workspace_bytes(void);
+int v3d_sumsq(const void* x, int64_t n, int dtype, float* out, int accumulate, float* workspace, void* stream);
 
 /* The grounding loss (ScanRefer / Multi3DRefer samples of the joint training), predict_box 'infonce', llava_qwen.py:296-310: with
  * s_i = <normalize(obj[i]), normalize(query)> (v3d_ground_scores) over the n head outputs obj [n, C] (the zero-target row included),

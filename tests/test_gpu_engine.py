@@ -311,7 +311,7 @@ def _group_decode(eng, scenes, steps):
     return toks
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 6])
+@pytest.mark.parametrize("M", [2, 3, 4, 6, 18])
 def test_decode_group_tokens_do_not_depend_on_the_group(M):
     """Scenes decoding together share each pass over the weights (bench.py's decode groups).  A scene's tokens must be
     bit-identical whatever group it is in (matrix-core decode linears: columns are independent; attention: the split
@@ -330,14 +330,14 @@ def test_decode_group_tokens_do_not_depend_on_the_group(M):
     pair = _group_decode(eng, [scenes[M - 1], scenes[M + 1]], steps)   # ... and inside another, smaller one
     assert torch.equal(pair[0], toks[M - 1])
     same = 0
-    for m in range(M):
+    for m in range(min(M, 6)):
         alone, margins = _single_decode_with_margins(eng, scenes[m], steps)
         for st in range(steps):
             if int(toks[m, st]) != alone[st]:
                 assert margins[st] < 0.02, (m, st, toks[m].tolist(), alone, margins[st])
                 break
             same += 1
-    assert same >= M * steps // 2
+    assert same >= min(M, 6) * steps // 2
 
 
 def test_decode_group_ragged_lengths_close_to_single_scene():

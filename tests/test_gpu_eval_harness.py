@@ -66,10 +66,14 @@ def test_eval_runner_end_to_end(tmp_path):
             "--max_frame_num", "4", "--max-new-tokens", "5"]
     assert E.main(argv + ["--answer-file", os.path.join(root, "out", "plain.jsonl"), "--no-pipeline"]) == 0
     assert E.main(argv + ["--answer-file", os.path.join(root, "out", "pipe.jsonl"), "--decode-group", "3", "--loader-workers", "3"]) == 0
-    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "reuse.jsonl"), "--reuse-scenes"]) == 0
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "reuse.jsonl"), "--reuse-scenes", "--no-pipeline"]) == 0
+    assert E.main(argv + ["--answer-file", os.path.join(root, "out", "reuse_pipe.jsonl"), "--reuse-scenes", "--loader-workers", "2"]) == 0
     plain = [json.loads(l) for l in open(os.path.join(root, "out", "plain.jsonl"))]
     pipe = [json.loads(l) for l in open(os.path.join(root, "out", "pipe.jsonl"))]
     reuse = [json.loads(l) for l in open(os.path.join(root, "out", "reuse.jsonl"))]
+    # r04: scene reuse ON the pipeline (asynchronous loader per scene, the next scene's prefill on another stream and scratch beside this
+    # scene's answer batches) = the synchronous scene-reuse records, exactly: same kernels on the same operands
+    assert [json.loads(l) for l in open(os.path.join(root, "out", "reuse_pipe.jsonl"))] == reuse
     for recs in (plain, pipe, reuse):
         assert [r["sample_id"] for r in recs] == [q["id"] for q in qs]
         assert all(list(r) == ["dataset", "sample_id", "prompt", "pred_response", "gt_response", "model_id", "question_type"] for r in recs)

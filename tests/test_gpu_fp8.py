@@ -140,7 +140,7 @@ def test_engine_prefill_fp8_close_to_bf16():
     assert torch.isfinite(lb2).all()
 
 
-@pytest.mark.parametrize("M", [1, 2, 4, 9, 16])
+@pytest.mark.parametrize("M", [1, 2, 4, 9, 16, 23, 32])
 @pytest.mark.parametrize("K,N", [(3584, 512), (18944, 256), (256, 384), (400, 64)])
 def test_linear_decode_fp8_rows(M, K, N):
     """W8A16 decode linear: e4m3 weights (per-row scales) x 16-bit activations, against an f64 product of the SAME

@@ -336,15 +336,22 @@ def test_attention_decode_rows_ragged(ops, lens):
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
-@pytest.mark.parametrize("P,tails", [(6734, [60, 61, 77, 3, 64]), (500, [1] * 16), (256, [0, 5, 300]), (37, [19, 40])])
-def test_attention_decode_rows_shared_prefix_is_bit_identical(ops, kind, P, tails, monkeypatch):
-    """Questions about one scene: the caches start with the same P rows.  With prefix=P the split-KV kernels read
-    those keys from the first cache for every question (the chip streams them once); the outputs must equal the launch in which
-    every question reads its own copy, bit for bit - prefix ends inside a 16-key group / a 64-key chunk / a split, tails of 0 rows,
-    both kernels (V3D_DEC_ATTN is read once per process, so the VALU form is covered by its equality with the MFMA form elsewhere)."""
+@pytest.mark.parametrize("mm", [0, 1])
+@pytest.mark.parametrize("P,tails", [(6734, [60, 61, 77, 3, 64]), (500, [1] * 16), (256, [0, 5, 300]), (37, [19, 40]), (1500, list(range(1, 28)))])
+def test_attention_decode_rows_shared_prefix(ops, kind, P, tails, mm, monkeypatch):
+    """Questions about one scene: the caches start with the same P rows, and with prefix=P nobody reads the other copies
+    (poisoned with NaN here).
+    mm = 0 (V3D_DEC_PREFIX_MM=0, the r03 form): the split-KV kernels read those keys from the first cache for every question - the
+    outputs equal the launch in which every question reads its own copy bit for bit (prefix ends inside a 16-key group / a 64-key chunk /
+    a split, tails of 0 rows).
+    mm = 1 (r04, default): the prefix keys are ONE matrix-core launch for all rows (attn_prefill16_kernel<PART>: a chunk of the prefix
+    through LDS once for all M x 7 query heads of a kv head), the rows' own keys stay with the split kernels, the merge folds both:
+    within 2 ulp16 of |v| of the own-copy launch (other f32 summation order), equal to the f32 reference at the decode bound, and a row's
+    bits depend neither on M nor on the other rows (up to 27 rows = two query tiles; 1500 = a short last chunk)."""
     dt = DT[kind]
     H, KV, D = 28, 4, 128
     M = len(tails)
+    monkeypatch.setenv("V3D_DEC_PREFIX_MM", str(mm))
     g = torch.Generator().manual_seed(P + sum(tails))
     q = torch.randn(M, H * D, generator=g).to(dt).cuda()
     shared = torch.randn(P, 2 * KV * D, generator=g).to(dt)
@@ -363,7 +370,25 @@ def test_attention_decode_rows_shared_prefix_is_bit_identical(ops, kind, P, tail
         c[:P] = float("nan")
     got = torch.empty(M, H * D, dtype=dt, device="cuda")
     ops.attention_decode_rows(q, caches, [c[:, KV * D:] for c in caches], got, lens, H, KV, 1 / math.sqrt(D), ws, prefix=P)
-    assert torch.equal(got, own)
+    if mm == 0:
+        assert torch.equal(got, own)
+    else:
+        assert bool(torch.isfinite(got.float()).all())
+        close(got, own.float().cpu(), kind, ulps=2.0, floor=0.3)
+        for m in (0, M - 1):                                   # against the f32 reference over the row's own keys
+            cm = caches[m].clone()
+            cm[:P] = shared.cuda()
+            k = cm[:lens[m], :KV * D].view(1, lens[m], KV, D).cpu()
+            v = cm[:lens[m], KV * D:].view(1, lens[m], KV, D).cpu()
+            want = ref_attention(q[m].cpu().view(1, 1, H, D), k, v, True, 1 / math.sqrt(D), q_pos0=lens[m] - 1)
+            close(got[m].view(1, 1, H, D), want, kind, ulps=2.0, floor=0.3)
+        if M >= 3:                                             # group independence: the last two rows as their own launch
+            sub = torch.empty(2, H * D, dtype=dt, device="cuda")
+            c2 = caches[M - 2].clone()
+            c2[:P] = shared.cuda()                             # (the shared prefix is read from the FIRST cache handed in)
+            ops.attention_decode_rows(q[M - 2:].contiguous(), [c2, caches[M - 1]], [c2[:, KV * D:], caches[M - 1][:, KV * D:]], sub, lens[M - 2:],
+                                      H, KV, 1 / math.sqrt(D), ws, prefix=P)
+            assert torch.equal(sub, got[M - 2:])
     with pytest.raises(Exception):
         ops.attention_decode_rows(q, caches, [c[:, KV * D:] for c in caches], got, [P - 1] + lens[1:], H, KV, 1 / math.sqrt(D), ws, prefix=P)
 
@@ -460,7 +485,7 @@ def test_linear_decode_fused_variants(ops, kind):
     close(act, want, kind, ulps=3.0, floor=0.3)
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 16])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 16, 17, 32])
 @pytest.mark.parametrize("K,N", [(512, 384), (3584, 512), (4736, 256), (18944, 128), (520, 36)])
 def test_linear_decode_rows(ops, M, K, N):
     """Scenes decoding together share one pass over the weights.  Matrix-core shapes (K % 128 == 0, N % 16 == 0), M >= 2:
@@ -505,6 +530,17 @@ def test_linear_decode_rows(ops, M, K, N):
                 kw2["res"] = r[M - 2:]
             ops.linear_decode_rows(x[M - 2:], w, sub, **kw2)
             assert torch.equal(sub, got[M - 2:])
+            if M > 16:      # r04, two 16-row blocks per pass: the first rows as a group of 16 (the one-block kernel): the same bits
+                sub16 = torch.empty((16, n_out), dtype=dt, device="cuda")
+                kw3 = dict(kw)
+                if "res" in kw3:
+                    kw3["res"] = r[:16]
+                ops.linear_decode_rows(x[:16], w, sub16, **kw3)
+                assert torch.equal(sub16, got[:16])
+            want = x.double() @ w.double().t()                   # f64 reference of the plain product (the epilogues are checked above / below)
+            if not kw:
+                err = (got.double() - want).abs()
+                assert bool((err <= 2.0 ** -7 * want.abs() + 2.0 ** -8 * want.pow(2).mean().sqrt()).all())
         if "norm_weight" not in kw and not swiglu:       # and the values are right (f64 reference)
             ref = x.double() @ w.double().t()
             if "bias" in kw:

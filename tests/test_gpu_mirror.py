@@ -231,7 +231,7 @@ def test_pipeline_device_inputs_follow_the_depth_maps_aspect(tmp_path):
     vp.scan2obj = {vid: [[0.0, 0.1, 0.2, 1.0, 1.0, 1.0]]}
     vp.sample_frame_files = lambda video_id, force_sample=False, frames_upbound=0: files
     proc = SigLipImageProcessor(size=(crop, crop), crop_size={"height": crop, "width": crop})
-    eng = types.SimpleNamespace(dtype=torch.float16, device="cuda", ctx=None, ws=None, new_context=lambda: None, new_group=lambda g: None,
+    eng = types.SimpleNamespace(dtype=torch.float16, device="cuda", ctx=None, ws=None, MAX_GROUP=32, new_context=lambda: None, new_group=lambda g: None,
                                 new_prefill_workspace=lambda: None)
     pipe = ScenePipeline(eng, 1, crop=crop, image_mean=proc.image_mean, image_std=proc.image_std, rescale=proc.rescale_factor)
     for strategy, lo, hi in (("uniform", None, None), ("uniform-norm", [-0.5, -1.0, 0.2], [1.5, 0.75, 1.0])):

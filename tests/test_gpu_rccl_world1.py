@@ -83,6 +83,21 @@ def test_zero_adamw_over_rccl_equals_adamw_bitwise_and_flattens_by_key(nccl_worl
     bad["llm"]["norm"] = bad["llm"]["norm"][:8]
     with pytest.raises(train.V3DError):
         zero.step(bad)
+    # r04: per-module learning rates, no-decay groups, clipping and a schedule: the flat partition is updated in runs of constant
+    # (lr, weight decay) and the clip norm is the all-reduced norm of the averaged gradient - the plain AdamW's update
+    pa2, pb2 = _tree(dev, 20), _tree(dev, 20)
+    kw = dict(lr=1e-2, weight_decay=0.05, lr_by_module={"ground": 3e-3, "newline": 5e-3}, max_grad_norm=0.5, schedule=train.cosine_warmup_schedule(10, 0.2))
+    zero2, plain2 = train.ZeroAdamW(pa2, bucket_elems=200, **kw), train.AdamW(pb2, **kw)
+    assert len(zero2.segments) > 3
+    for seed in (21, 22, 23):
+        gsd = _tree(dev, seed)
+        out2 = zero2.step(gsd, grad_scale=0.5)
+        plain2.step(pb2, gsd, grad_scale=0.5)
+        assert abs(zero2.last_grad_norm - plain2.last_grad_norm) <= 1e-6 * plain2.last_grad_norm
+    # (the two norms sum the same squares in another order - flat partition against leaf by leaf - so the clip coefficients agree to
+    #  f32 rounding and a 16-bit parameter may land one rounding apart here and there)
+    for x, y in zip(train._leaves(out2), train._leaves(pb2)):
+        assert (x == y).float().mean().item() > 0.98 and torch.allclose(x.float(), y.float(), rtol=1e-2, atol=1e-4)
     # a leaf written through grad_views() is taken in place
     gv = zero.grad_views()
     gv["newline"].copy_(g1["newline"])

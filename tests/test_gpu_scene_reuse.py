@@ -115,16 +115,22 @@ def test_answer_group_equals_answering_alone(dtype):
     same = sum(int(torch.equal(a, b)) for a, b in zip(alone, together))
     assert same >= len(questions) - 2, (alone, together)                  # near-ties may flip a token of a question or two
     assert all(t.shape == (steps,) for t in together)
-    # the decode attention reads the shared prefix rows from ONE copy for every question (default): same tokens as with every
-    # question reading its own copy of them
+    # the decode attention reads the shared prefix rows from ONE copy for every question (default; r04: one matrix-core launch over the
+    # prefix for all questions): the tokens of every question reading its own copy of them, up to near-ties (the r03 form, which walks
+    # the prefix per question out of one copy, gives them bit for bit)
     import os
     os.environ["V3D_SHARED_PREFIX"] = "0"
     try:
         own = eng.answer_group(questions, max_new_tokens=steps)
+        os.environ["V3D_SHARED_PREFIX"] = "1"
+        os.environ["V3D_DEC_PREFIX_MM"] = "0"
+        r03 = eng.answer_group(questions, max_new_tokens=steps)
     finally:
         del os.environ["V3D_SHARED_PREFIX"]
-    for a, b in zip(own, together):
+        os.environ.pop("V3D_DEC_PREFIX_MM", None)
+    for a, b in zip(own, r03):
         assert torch.equal(a, b)
+    assert sum(int(torch.equal(a, b)) for a, b in zip(own, together)) >= len(questions) - 1, (own, together)
     eos = int(together[2][1])
     cut = eng.answer_group(questions, max_new_tokens=steps, eos_token_id=eos)
     for a, b in zip(cut, together):

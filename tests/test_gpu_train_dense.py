@@ -280,6 +280,64 @@ def test_adamw_step_matches_torch_adamw(ops):
     assert torch.allclose(v.cpu(), opt.state[ref_p]["exp_avg_sq"], rtol=2e-6, atol=1e-9)
 
 
+def test_sumsq_is_deterministic_and_matches_f64(ops):
+    """v3d_sumsq (the global gradient norm's building block): f32 / bf16 / f16, odd lengths, chained accumulation; run-to-run identical."""
+    g = torch.Generator().manual_seed(21)
+    for dt, n in ((torch.float32, 100003), (torch.bfloat16, 3 * 4096 + 5), (torch.float16, 8), (torch.bfloat16, 37_000_000)):
+        x = torch.randn(n, generator=g).to(dt).cuda()
+        a, b = ops.sumsq(x).clone(), ops.sumsq(x).clone()
+        assert torch.equal(a, b)
+        want = x.double().pow(2).sum().item()
+        assert abs(a.item() - want) <= 2e-6 * want
+    parts = [torch.randn(k, generator=g).to(torch.bfloat16).cuda() for k in (16, 4096, 999)]
+    acc = None
+    for t in parts:
+        acc = ops.sumsq(t, out=acc, accumulate=acc is not None)
+    want = sum(t.double().pow(2).sum().item() for t in parts)
+    assert abs(acc.item() - want) <= 2e-6 * want
+
+
+def test_optimizer_groups_clipping_and_schedule_match_torch(ops, train):
+    """r04, the trainer-side fidelity of f4 (VERDICT r03 missing #4): per-module learning rates (llava_trainer.py:446-523; train_multi.sh:45
+    --mm_vision_tower_lr 2e-6 beside :65 --learning_rate 1e-5), no weight decay on biases / LayerNorm parameters (:459-460), global
+    gradient-norm clipping (HF max_grad_norm 1.0 = zero2.json:36 "gradient_clipping": "auto"), the cosine schedule with 3 % warm-up
+    (train_multi.sh:67-68) - train.AdamW against torch.optim.AdamW with the reference's parameter groups + torch.nn.utils.clip_grad_norm_
+    + transformers' get_cosine_schedule_with_warmup on f32 copies of the same parameters and the same 16-bit gradients."""
+    from transformers import get_cosine_schedule_with_warmup
+    g = torch.Generator().manual_seed(31)
+    mk = lambda *s_, sc=0.1: (torch.randn(*s_, generator=g) * sc).to(torch.bfloat16).cuda()      # noqa: E731
+    tree = {"vision": {"patch_w": mk(32, 64), "patch_b": mk(32), "layers": [{"ln1_w": mk(32), "ln1_b": mk(32), "qkv": mk(96, 32), "qkv_b": mk(96)}]},
+            "projector": {"w1": mk(48, 32), "b1": mk(48)}, "newline": mk(48),
+            "llm": {"layers": [{"ln1": mk(48), "qkv": mk(144, 48), "qkv_bias": mk(144)}], "norm": mk(48), "lm_head": mk(64, 48)}}
+    total, lr, wd = 40, 1e-3, 0.05
+    by = {"vision_tower": 2e-4, "mm_projector": 5e-4}                       # the reference's module keywords
+    opt = train.AdamW(tree, lr=lr, weight_decay=wd, lr_by_module=by, max_grad_norm=1.0, schedule=train.cosine_warmup_schedule(total, 0.03))
+    paths = train._paths(tree)
+    leaves = train._leaves(tree)
+    assert [p_ for p_ in paths if train._no_decay(p_)] == ["vision.patch_b", "vision.layers.0.ln1_w", "vision.layers.0.ln1_b", "vision.layers.0.qkv_b",
+                                                           "projector.b1", "llm.layers.0.qkv_bias"]       # (Qwen2's RMSNorm weights ARE decayed)
+    ref = [t.detach().float().clone().requires_grad_() for t in leaves]
+    groups = []
+    for path, t in zip(paths, ref):
+        top = path.split(".")[0]
+        groups.append({"params": [t], "lr": {"vision": 2e-4, "projector": 5e-4}.get(top, lr), "weight_decay": 0.0 if train._no_decay(path) else wd})
+    topt = torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    sched = get_cosine_schedule_with_warmup(topt, num_warmup_steps=2, num_training_steps=total)      # ceil(0.03 * 40) = 2
+    for step in range(1, 7):
+        grads = train._tree_map(lambda t: (torch.randn(t.shape, generator=g) * (3.0 if step % 2 else 0.01)).to(torch.bfloat16).cuda(), tree)
+        for t, gr in zip(ref, train._leaves(grads)):
+            t.grad = gr.float() * 0.5                                                     # grad_scale 0.5: two accumulated micro-batches
+        norm = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        topt.step()
+        sched.step()
+        opt.step(tree, grads, grad_scale=0.5)
+        assert abs(opt.last_grad_norm - norm.item()) <= 1e-5 * norm.item()
+        for path, (p32, _, _), t in zip(paths, train._leaves_of_state(opt.state), ref):
+            assert torch.allclose(p32.cpu(), t.detach().cpu(), rtol=3e-6, atol=3e-7), (step, path)
+    lam = train.cosine_warmup_schedule(total, 0.03)
+    assert lam(1) == 0.0 and lam(2) == 0.5 and lam(3) == 1.0 and abs(lam(total + 1)) < 1e-12
+
+
 def test_adamw_eight_wide_form_equals_the_scalar_form_bitwise(ops):
     """r03: 16-bit gradients with n % 8 == 0 take the kernel with 16-byte loads / stores; every element goes through the same
     arithmetic, so three steps leave p32 / m / v / p16 bit-identical to the scalar kernel's (taken by an odd-length prefix view)."""

@@ -80,6 +80,12 @@ struct AttnArgs {
   float* lse;                        // training only (v3d_attention_train): [B, Hq, Sq] row log-sum-exp in scaled log2 units, or null
   int xcd_p;                         // > 0: 1-D grid, XCD-aware (head, query tile) mapping with xcd_p XCDs per kv head (see attn_prefill_kernel)
   int n_qt;                          // query tiles per head (the mapped form needs it; the 3-D grid reads gridDim.y)
+  // attn_prefill16_kernel<PART> only (r04, shared-prefix decode attention): the "queries" of kernel head hk are the q_rpg query heads of
+  // kv head hk of each of the M decode rows (query i = row i / q_rpg, head hk q_rpg + i % q_rpg: address q + (i / q_rpg) ldq + hsq hk +
+  // 128 (i % q_rpg)); blockIdx.z = key chunk c: keys [c Sk, min((c + 1) Sk, sk_total)); the result is the decode kernels' f32 partial
+  // (o[128], m, l) in split slot part_split0 + c of row i / q_rpg's workspace slice (part_ws_stride floats apart), head hk q_rpg + i % q_rpg
+  int q_rpg, sk_total, part_split0, part_hq;
+  int64_t part_ws_stride;
 };
 
 #ifndef V3D_ATTN_VPF
@@ -592,8 +598,10 @@ __device__ __forceinline__ int at16_rho(int m) {      // MFMA row within a 16-ke
   return 4 * pi + (m & 3);
 }
 
-template <typename T, bool CAUSAL, bool LSE = false>
+// PART (r04): the shared-prefix segment of the decode attention of M rows (questions about one scene) - see AttnArgs; non-causal.
+template <typename T, bool CAUSAL, bool LSE = false, bool PART = false>
 __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
+  static_assert(!PART || (!CAUSAL && !LSE), "the partial form is non-causal and writes no log-sum-exp");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   using M = Mfma16<T>;
   constexpr int D = 128, KS = 4, DB = 8;          // 32-wide k-steps of QK^T; 16-wide d blocks of O^T
@@ -617,6 +625,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
   }
   const int hk = head / p.group;
   const int q0 = qt * AT_BQ;
+  if (PART) {                                      // this workgroup's key chunk (the last one may be short)
+    const int left = p.sk_total - b * p.Sk;
+    p.Sk = left < p.Sk ? left : p.Sk;
+  }
 
   const uint16_t* Q = (const uint16_t*)p.q + b * p.bsq + (int64_t)head * p.hsq;
   const uint16_t* K = (const uint16_t*)p.k + b * p.bsk + (int64_t)hk * p.hsk;
@@ -869,7 +881,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
     const int qi_ld = qi[qb] < p.Sq ? qi[qb] : p.Sq - 1;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(Q + (int64_t)qi_ld * p.ldq + ks * 32 + g * 8);
+      const int64_t qoff = PART ? (int64_t)(qi_ld / p.q_rpg) * p.ldq + (qi_ld % p.q_rpg) * D : (int64_t)qi_ld * p.ldq;
+      const uint4 raw = *reinterpret_cast<const uint4*>(Q + qoff + ks * 32 + g * 8);
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = vec_get<T>(raw, j) * p.scale_log2;
@@ -917,6 +930,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill16_kernel(AttnArgs p) {
 #undef V3D_VR
 #undef V3D_VW
 
+  if constexpr (PART) {     // the decode kernels' partial: unnormalised O (f32) + the reference maximum m (scaled log2 units) + row sum l
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 16);
+      l_tot = l_tot + __shfl_xor(l_tot, 32);
+      if (qi[qb] < p.Sq) {
+        const int row = qi[qb] / p.q_rpg, hd_ = head * p.q_rpg + qi[qb] % p.q_rpg;
+        float* w = (float*)p.o + (int64_t)row * p.part_ws_stride + ((int64_t)(p.part_split0 + b) * p.part_hq + hd_) * (D + 2);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+          *reinterpret_cast<float4*>(w + 16 * db + 4 * g) = make_float4(o[qb][db][0], o[qb][db][1], o[qb][db][2], o[qb][db][3]);
+        if (g == 0) { w[D] = m_run[qb]; w[D + 1] = l_tot; }
+      }
+    }
+    return;
+  }
   // ---- normalise, transpose through LDS, store whole rows ----
   constexpr int OROW = D * 2 + 16;
   char* so = smem + wave * 32 * OROW;
@@ -1685,7 +1714,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs p) {
 // the workspace; a second tiny kernel merges the splits.  HBM-bound: cache bytes read once.
 // ------------------------------------------------------------------------------------------
 constexpr int DEC_MAXG = 8;
-constexpr int DEC_MAXROWS = 16;
+constexpr int DEC_MAXROWS = 32;
 
 // Scenes decoding together (blockIdx.z = scene): each has its own cache, length, query row and workspace slice.
 struct DecRows {
@@ -1696,6 +1725,8 @@ struct DecRows {
   int64_t ws_stride;                // floats between the scenes' workspace slices
   int kps, cap;                     // keys per split / most splits per scene: a scene's OWN split count min(cap, ceil(n_keys / kps))
                                     // decides its key partition, so its output does not depend on the other scenes of the launch
+  int skip;                         // r04: keys < skip are NOT this launch's (the shared-prefix segment went to attn_prefill16_kernel<PART>,
+                                    // its partials sit in the split slots behind this launch's): a scene partitions keys [skip, n_keys)
   const void* kp;                   // shared prefix (scene-level reuse): keys < prefix are read HERE for every scene of the launch -
   const void* vp;                   // the scenes' own copies of those rows hold the same bytes, so outputs do not change, but the
   int prefix;                       // chip reads the prefix once (L2 / Infinity Cache hits for the other scenes) instead of M times
@@ -1716,9 +1747,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(AttnArgs p, DecR
   const int slot = tid >> 4, cl = tid & 15;       // 16 key slots, 16 lanes per key row
   const int hk = blockIdx.x, split = blockIdx.y;
   const int n_keys = p.q_pos0 + 1 < p.Sk ? p.q_pos0 + 1 : p.Sk;
-  const int ns_own = min(rw.cap, (n_keys + rw.kps - 1) / rw.kps);      // splits >= ns_own are empty: (m, l, o) = (-inf, 0, 0)
-  const int per = (n_keys + ns_own - 1) / ns_own;
-  const int k_begin = split * per;
+  const int n_own = n_keys - rw.skip;                                    // (rw.skip = 0 unless the shared prefix has its own launch)
+  const int ns_own = min(rw.cap, (n_own + rw.kps - 1) / rw.kps);         // splits >= ns_own are empty: (m, l, o) = (-inf, 0, 0)
+  const int per = ns_own > 0 ? (n_own + ns_own - 1) / ns_own : 1;
+  const int k_begin = rw.skip + (split < ns_own ? split * per : n_own);
   int k_end = k_begin + per;
   k_end = k_end < n_keys ? k_end : n_keys;
   const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * p.hsk;
@@ -1835,9 +1867,10 @@ __global__ __launch_bounds__(256) void attn_decode_split_mm_kernel(AttnArgs p, D
   const int hr = lane & 15, g4 = lane >> 4;        // score tile: column (key) hr, heads 4 g4 + i;  V layout: slot g4, dims 8 hr..
   const int hk = blockIdx.x, split = blockIdx.y;
   const int n_keys = p.q_pos0 + 1 < p.Sk ? p.q_pos0 + 1 : p.Sk;
-  const int ns_own = min(rw.cap, (n_keys + rw.kps - 1) / rw.kps);      // splits >= ns_own are empty: (m, l, o) = (-inf, 0, 0)
-  const int per = (n_keys + ns_own - 1) / ns_own;
-  const int k_begin = split * per;
+  const int n_own = n_keys - rw.skip;                                    // (rw.skip = 0 unless the shared prefix has its own launch)
+  const int ns_own = min(rw.cap, (n_own + rw.kps - 1) / rw.kps);         // splits >= ns_own are empty: (m, l, o) = (-inf, 0, 0)
+  const int per = ns_own > 0 ? (n_own + ns_own - 1) / ns_own : 1;
+  const int k_begin = rw.skip + (split < ns_own ? split * per : n_own);
   int k_end = k_begin + per;
   k_end = k_end < n_keys ? k_end : n_keys;
   const uint16_t* K = (const uint16_t*)p.k + (int64_t)hk * p.hsk;
@@ -2177,16 +2210,32 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
   // with them every bit of its output - depend neither on M nor on the other scenes' lengths (measured at
   // S = 6.8k: 128 is 10 % faster for a single scene, 256 is 20-25 % faster from four scenes on)
   const int kps = kps_env > 0 ? kps_env : 256;
-  int n_split = (sk_max + kps - 1) / kps;
   const int cap = 1024 / Hkv;                        // ~4 workgroups per CU and scene
+  for (int m = 0; m < M && prefix > 0; ++m) V3D_REQUIRE(Sk[m] >= prefix, "%s: scene %d is shorter than the shared prefix", who, m);
+  // r04, shared prefix on the matrix cores (V3D_DEC_PREFIX_MM=0: the r03 form, every row walks the prefix keys itself out of one copy):
+  // the prefix keys are ONE launch of attn_prefill16_kernel<PART> for all rows - per kv head the M x G query heads are the "queries", a
+  // workgroup takes a chunk of the prefix through LDS once for all of them, scores and P.V on v_mfma_f32_16x16x32 - and the rows' own
+  // keys (question + generated tokens) stay with the split kernels (rw.skip); the merge folds both sets of partials.  A row's chunks are
+  // fixed by the prefix length and its own key count, so its bits depend neither on M nor on the other rows.
+  int pmm_env = 1, pmm_chunk = 256;                  // (read per call: the tests and the A/B switch it inside one process)
+  if (prefix > 0) {
+    const char* e = getenv("V3D_DEC_PREFIX_MM"); if (e) pmm_env = atoi(e);
+    const char* c = getenv("V3D_DEC_PREFIX_CHUNK"); if (c && atoi(c) >= 64) pmm_chunk = (atoi(c) + 63) / 64 * 64;
+  }
+  const int G = Hq / Hkv;
+  const bool pmm = prefix > 0 && pmm_env != 0 && ldk == ldv;
+  const int n_chunks = pmm ? (prefix + pmm_chunk - 1) / pmm_chunk : 0;
+  const int own_max = pmm ? sk_max - prefix : sk_max;
+  int n_split = (own_max + kps - 1) / kps;
   if (n_split > cap) n_split = cap;
   if (n_split < 1) n_split = 1;
-  const int64_t ws_one = v3d_attention_decode_workspace_bytes(Hq, n_split);
-  V3D_REQUIRE(workspace_bytes >= ws_one * M, "%s: workspace too small for %d scenes x %d splits", who, M, n_split);
+  const int n_slots = n_split + n_chunks;
+  const int64_t ws_one = v3d_attention_decode_workspace_bytes(Hq, n_slots);
+  V3D_REQUIRE(workspace_bytes >= ws_one * M, "%s: workspace too small for %d scenes x %d splits", who, M, n_slots);
   rw.q_stride = q_stride; rw.o_stride = o_stride; rw.ws_stride = ws_one / (int64_t)sizeof(float);
   rw.kps = kps; rw.cap = cap;
   rw.kp = k_prefix; rw.vp = v_prefix; rw.prefix = prefix;
-  for (int m = 0; m < M && prefix > 0; ++m) V3D_REQUIRE(Sk[m] >= prefix, "%s: scene %d is shorter than the shared prefix", who, m);
+  rw.skip = pmm ? prefix : 0;
   AttnArgs p{};
   p.q = q; p.o = o;
   p.ldk = ldk; p.ldv = ldv; p.hsq = hsq; p.hsk = hsk; p.hso = hso;
@@ -2194,7 +2243,31 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
   p.scale_log2 = scale * 1.44269504088896340736f;
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
-  const int G = Hq / Hkv;
+  if (pmm) {
+    AttnArgs pp{};
+    pp.q = q; pp.k = k_prefix; pp.v = v_prefix; pp.o = ws;
+    pp.ldq = q_stride; pp.ldk = ldk; pp.ldv = ldv; pp.hsq = G * 128; pp.hsk = hsk;
+    pp.bsq = 0; pp.bsk = (int64_t)pmm_chunk * ldk;
+    pp.Sq = G * M; pp.Sk = pmm_chunk; pp.sk_total = prefix; pp.Hq = Hkv; pp.group = 1; pp.d_out = 128;
+    pp.scale_log2 = p.scale_log2;
+    pp.q_rpg = G; pp.part_split0 = n_split; pp.part_hq = Hq; pp.part_ws_stride = rw.ws_stride;
+    pp.n_qt = (pp.Sq + AT_BQ - 1) / AT_BQ;
+    const dim3 pgrid(Hkv, pp.n_qt, n_chunks);
+#define V3D_PART(TT)                                                                                                             \
+    {                                                                                                                            \
+      auto kfn = attn_prefill16_kernel<TT, false, false, true>;                                                                  \
+      static bool done = false;                                                                                                  \
+      if (!done) {                                                                                                               \
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);                \
+        if (e != hipSuccess) { set_error("%s: LDS attribute: %s", who, hipGetErrorString(e)); return V3D_E_LAUNCH; }             \
+        done = true;                                                                                                             \
+      }                                                                                                                          \
+      hipLaunchKernelGGL(kfn, pgrid, dim3(256), AT_LDS, st, pp);                                                                 \
+    }
+    if (dtype == V3D_BF16) V3D_PART(bf16_t) else V3D_PART(f16_t)
+#undef V3D_PART
+    if (int e = check_launch(who)) return e;
+  }
   static int use_mm = -1;
   if (use_mm < 0) { const char* e = getenv("V3D_DEC_ATTN"); use_mm = e && e[0] == 'v' ? 0 : 1; }     // "valu" selects the shuffle-reduction kernel
 #define V3D_DEC(TT, GG)                                                                                                          \
@@ -2210,8 +2283,8 @@ static int attention_decode_rows(const void* q, int64_t q_stride, int M, const v
 #undef V3D_DEC_G
 #undef V3D_DEC
   if (int e = check_launch(who)) return e;
-  if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_merge_kernel<bf16_t>), dim3(Hq, 1, M), dim3(128), 0, st, p, rw, n_split, ws);
-  else hipLaunchKernelGGL((attn_decode_merge_kernel<f16_t>), dim3(Hq, 1, M), dim3(128), 0, st, p, rw, n_split, ws);
+  if (dtype == V3D_BF16) hipLaunchKernelGGL((attn_decode_merge_kernel<bf16_t>), dim3(Hq, 1, M), dim3(128), 0, st, p, rw, n_slots, ws);
+  else hipLaunchKernelGGL((attn_decode_merge_kernel<f16_t>), dim3(Hq, 1, M), dim3(128), 0, st, p, rw, n_slots, ws);
   return check_launch(who);
 }
 

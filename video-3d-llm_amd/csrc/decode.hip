@@ -178,35 +178,56 @@ __device__ __forceinline__ dec_f32x4 dec_mfma(f16_t, const uint4& a, const uint4
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dec_f16x8, a), __builtin_bit_cast(dec_f16x8, b), c, 0, 0, 0);
 }
 
-template <typename T, int EPI>
+// MB (r04): 16-row blocks of activation rows - M <= 16 MB scenes / questions share the pass over the weights (a weight fragment feeds MB
+// MFMAs; the accumulators of the blocks are independent, so a row's bits depend neither on M nor on MB).
+// OG (r04): 16-row groups of OUTPUTS per workgroup.  Every workgroup reads all M activation rows (each wave its K slices), so the
+// activation bytes pulled out of L2 per weight byte are M : 16 OG - at M = 32 and OG = 1 twice the weight stream itself (the gate/up
+// linear then ran at 3.8 TB/s of weights).  More outputs per workgroup divide that; the k order of an output's sum does not change.
+template <typename T, int EPI, int MB, int OG>
 __global__ __launch_bounds__(512) void linear_decode_mfma_kernel(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W,
                                                                  int64_t ldw, const T* __restrict__ bias, const T* __restrict__ res,
                                                                  int64_t ldr, T* __restrict__ out, int64_t ldo, int N, int K) {
-  constexpr int RG = EPI == DEC_EPI_SWIGLU ? 2 : 1;        // 16-row groups per workgroup
-  constexpr int UN = 2;                                     // 128-element K tiles in flight per wave (8 x 16 B of weights per lane and group)
+  constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;         // weight row groups per output group (gate + up)
+  constexpr int RG = SW * OG;                               // 16-row weight groups per workgroup: [og][gate | up]
+  constexpr int UN = RG * MB >= 8 ? 1 : 2;                  // 128-element K tiles in flight per wave (8 x 16 B of weights per lane and group)
   constexpr int PITCH = 272;                                // LDS row pitch in bytes (256 + 16)
-  __shared__ __attribute__((aligned(16))) char tile[8][RG][16 * PITCH];
-  __shared__ float part[8][RG][256];
+  constexpr int TILE_B = 8 * RG * 16 * PITCH, PART_B = 8 * RG * MB * 256 * 4;
+  __shared__ __attribute__((aligned(16))) char smem_[TILE_B > PART_B ? TILE_B : PART_B];
+  auto tile = [&](int w, int q) -> char* { return smem_ + (size_t)(w * RG + q) * 16 * PITCH; };
+  auto part = [&](int w, int q, int b_) -> float* { return reinterpret_cast<float*>(smem_) + (size_t)((w * RG + q) * MB + b_) * 256; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;                   // operand layout: row / scene r, k group g
   const int lr = lane >> 4, lc = lane & 15;                 // load layout: row 4j + lr of the tile, 16-byte chunk lc
-  const int o0 = blockIdx.x * 16;                           // first output of this workgroup
+  const int o0 = blockIdx.x * 16 * OG;                      // first output of this workgroup
   const T* wbase[RG];                                       // row lr of the group, chunk lc
-  if (EPI == DEC_EPI_SWIGLU) {
-    const int gate = (o0 >> 6) * 128 + (o0 & 63);           // tile-interleaved rows: 64 gate rows, then their 64 up rows
-    wbase[0] = W + (int64_t)(gate + lr) * ldw + 8 * lc;
-    wbase[RG - 1] = W + (int64_t)(gate + 64 + lr) * ldw + 8 * lc;
-  } else {
-    wbase[0] = W + (int64_t)(o0 + lr) * ldw + 8 * lc;
-  }
-  const bool col_ok = r < M;
-  const T* xrow = x + (int64_t)(col_ok ? r : 0) * ldx + 8 * g;
-  dec_f32x4 acc[RG];
 #pragma unroll
-  for (int q = 0; q < RG; ++q) acc[q] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int og = 0; og < OG; ++og) {
+    const int o = o0 + 16 * og;
+    if (EPI == DEC_EPI_SWIGLU) {
+      const int gate = (o >> 6) * 128 + (o & 63);           // tile-interleaved rows: 64 gate rows, then their 64 up rows
+      wbase[SW * og] = W + (int64_t)(gate + lr) * ldw + 8 * lc;
+      wbase[SW * og + SW - 1] = W + (int64_t)(gate + 64 + lr) * ldw + 8 * lc;
+    } else {
+      wbase[SW * og] = W + (int64_t)(o + lr) * ldw + 8 * lc;
+    }
+  }
+  bool col_ok[MB];
+  const T* xrow[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    col_ok[b] = r + 16 * b < M;
+    xrow[b] = x + (int64_t)(col_ok[b] ? r + 16 * b : 0) * ldx + 8 * g;
+  }
+  dec_f32x4 acc[RG][MB];
+#pragma unroll
+  for (int q = 0; q < RG; ++q)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[q][b] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
   const int tiles = K / 128;
+  // (the tile -> wave assignment does not depend on UN / MB / OG: tile s goes to wave s % 8 and a wave sums its tiles in ascending
+  //  order, so an output's f32 summation order - and with it every bit - is the same in a group of 2 and in a group of 32)
   for (int s0 = wave; s0 < tiles; s0 += 8 * UN) {
-    uint4 wreg[UN][RG][4], xb[UN][4];
+    uint4 wreg[UN][RG][4], xb[UN][MB][4];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int s = s0 + 8 * u;
@@ -217,10 +238,12 @@ __global__ __launch_bounds__(512) void linear_decode_mfma_kernel(const T* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) wreg[u][q][j] = ldg_nt(reinterpret_cast<const uint4*>(wbase[q] + (int64_t)(4 * j) * ldw + k0));
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xb[u][t] = make_uint4(0u, 0u, 0u, 0u);
-        if (col_ok && ok) xb[u][t] = *reinterpret_cast<const uint4*>(xrow + k0 + 32 * t);     // lanes of absent scenes load nothing
-      }
+      for (int b = 0; b < MB; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          xb[u][b][t] = make_uint4(0u, 0u, 0u, 0u);
+          if (col_ok[b] && ok) xb[u][b][t] = *reinterpret_cast<const uint4*>(xrow[b] + k0 + 32 * t);     // lanes of absent scenes load nothing
+        }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -228,34 +251,40 @@ __global__ __launch_bounds__(512) void linear_decode_mfma_kernel(const T* __rest
       for (int q = 0; q < RG; ++q)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<uint4*>(&tile[wave][q][(4 * j + lr) * PITCH + lc * 16]) = wreg[u][q][j];
+          *reinterpret_cast<uint4*>(tile(wave, q) + (4 * j + lr) * PITCH + lc * 16) = wreg[u][q][j];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int q = 0; q < RG; ++q) {
-          const uint4 a = *reinterpret_cast<const uint4*>(&tile[wave][q][r * PITCH + (4 * t + g) * 16]);
-          acc[q] = dec_mfma(T{}, a, xb[u][t], acc[q]);
+          const uint4 a = *reinterpret_cast<const uint4*>(tile(wave, q) + r * PITCH + (4 * t + g) * 16);
+#pragma unroll
+          for (int b = 0; b < MB; ++b) acc[q][b] = dec_mfma(T{}, a, xb[u][b][t], acc[q][b]);
         }
     }
   }
+  __syncthreads();                                          // the partial sums reuse the tiles' LDS
 #pragma unroll
   for (int q = 0; q < RG; ++q)
-    *reinterpret_cast<float4*>(&part[wave][q][lane * 4]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
-  __syncthreads();
-  if (tid < 256) {                                          // element (row 4 (l >> 4) + i, column l & 15), l = tid >> 2, i = tid & 3
-    const int l = tid >> 2, i = tid & 3;
-    const int row = 4 * (l >> 4) + i, m = l & 15;
-    float v[RG];
 #pragma unroll
-    for (int q = 0; q < RG; ++q) {
+    for (int b = 0; b < MB; ++b)
+      *reinterpret_cast<float4*>(part(wave, q, b) + lane * 4) = make_float4(acc[q][b][0], acc[q][b][1], acc[q][b][2], acc[q][b][3]);
+  __syncthreads();
+  for (int e = tid; e < 256 * MB * OG; e += 512) {          // element (row 4 (l >> 4) + i, column l & 15) of block b, group og
+    const int og = e / (256 * MB), e2 = e - og * 256 * MB;
+    const int b = e2 >> 8, t8 = e2 & 255;
+    const int l = t8 >> 2, i = t8 & 3;
+    const int row = 4 * (l >> 4) + i, m = (l & 15) + 16 * b;
+    float v[SW];
+#pragma unroll
+    for (int q = 0; q < SW; ++q) {
       v[q] = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v[q] += part[w][q][tid];
+      for (int w = 0; w < 8; ++w) v[q] += part(w, SW * og + q, b)[t8];
     }
     if (m < M) {
-      const int n = o0 + row;
+      const int n = o0 + 16 * og + row;
       if (EPI == DEC_EPI_SWIGLU) {
-        const float gt = round_to<T>(v[0]), up = round_to<T>(v[RG - 1]);
+        const float gt = round_to<T>(v[0]), up = round_to<T>(v[SW - 1]);
         out[m * ldo + n] = from_f32<T>(round_to<T>(silu_f(gt)) * up);
       } else {
         float y = v[0];
@@ -362,9 +391,10 @@ __global__ __launch_bounds__(256, 4) void linear_decode_fp8_kernel(
 
 // rotary (apply_rotary_pos_emb, modeling_qwen2.py:141-173) on the new token's q and k heads, in place in the
 // QKV row, and append of k (rotated) and v to cache row `pos`:  cache_row = [k heads | v heads].
+constexpr int DEC_MAX_ROWS = 32;     // scenes / questions decoding together (r04: 32; the attention side: DEC_MAXROWS in attention.hip)
 struct RopeRows {        // scenes decoding together (blockIdx.y = scene): own position and cache row
-  int pos[16];
-  void* cache_row[16];
+  int pos[DEC_MAX_ROWS];
+  void* cache_row[DEC_MAX_ROWS];
   int64_t qkv_stride;
 };
 
@@ -464,7 +494,7 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
   // fall back to the VALU form with up to 4 rows.
   const bool mfma_ok = !norm_weight && K % 128 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
   const bool mfma = mfma_ok && M >= 2;
-  V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? 16 : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? 16 : 4, M);
+  V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? DEC_MAX_ROWS : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? DEC_MAX_ROWS : 4, M);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
   V3D_REQUIRE(aligned16(x) && aligned16(W) && (!norm_weight || aligned16(norm_weight)), "%s: alignment", who);
   V3D_REQUIRE(M == 1 || (ldx % 8 == 0 && ldx >= K), "%s: activation row stride %lld", who, (long long)ldx);
@@ -474,9 +504,22 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
   hipStream_t st = (hipStream_t)stream;
   if (mfma) {
     V3D_REQUIRE(aligned16(W) && (M == 1 || ldx % 8 == 0), "%s: alignment", who);
-    const int mblocks = (epilogue == DEC_EPI_SWIGLU ? N / 2 : N) / 16;
-#define V3D_LDM(TT, EE) hipLaunchKernelGGL((linear_decode_mfma_kernel<TT, EE>), dim3(mblocks), dim3(512), 0, st, (const TT*)x, ldx, M, \
-                                           (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+    const int n_out = epilogue == DEC_EPI_SWIGLU ? N / 2 : N;
+    // outputs per workgroup: 16 (r03) or 32.  32 halves the activation bytes every workgroup pulls out of L2 per weight byte, but also the
+    // number of workgroups that stream.  Measured (tools/time_decode_rows.py, M = 16 / 32 rows, us; profiles/r04_decode_rows.txt):
+    //   LM head  152064 x 3584: 228 -> 188 / 330 -> 260      gate/up 37888 x 3584: 56 -> 60 / 70.5 -> 62      qkv 4608 x 3584: 14.0 -> 11.4 / 20.3 -> 15.4
+    //   o_proj 3584 x 3584: 9.3 -> 11.2 / 11.7 -> 14.3      down 3584 x 18944: 32.6 -> 42.1 / 45.5 -> 57.1   (112 workgroups are too few)
+    // hence: 32 outputs where at least 128 workgroups remain, except in the 256..1023-workgroup range at M <= 16.  V3D_DEC_OG=1 / 3: never / always.
+    static int og_env = -1;
+    if (og_env < 0) { const char* e = getenv("V3D_DEC_OG"); og_env = e ? atoi(e) : 2; }
+    const int wg32 = n_out / 32;
+    const bool og_rule = wg32 >= 128 && !(wg32 >= 256 && wg32 < 1024 && M <= 16);
+    const int og = (og_env >= 2 && n_out % 32 == 0 && (og_env >= 3 || og_rule)) ? 2 : 1;
+    const int mblocks = n_out / (16 * og);
+#define V3D_LDM_B(TT, EE, BB, GG) hipLaunchKernelGGL((linear_decode_mfma_kernel<TT, EE, BB, GG>), dim3(mblocks), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                                     (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LDM(TT, EE) { if (M <= 16) { if (og == 2) V3D_LDM_B(TT, EE, 1, 2); else V3D_LDM_B(TT, EE, 1, 1); }                       \
+                          else { if (og == 2) V3D_LDM_B(TT, EE, 2, 2); else V3D_LDM_B(TT, EE, 2, 1); } }
 #define V3D_LDM_E(TT)                                                                                 \
   switch (epilogue) {                                                                                 \
     case DEC_EPI_NONE: V3D_LDM(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LDM(TT, DEC_EPI_BIAS); break; \
@@ -486,6 +529,7 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
     if (dtype == V3D_BF16) { V3D_LDM_E(bf16_t) } else { V3D_LDM_E(f16_t) }
 #undef V3D_LDM_E
 #undef V3D_LDM
+#undef V3D_LDM_B
     return check_launch(who);
   }
   const int blocks = N / 4;                                   // 4 weight rows per workgroup (SWIGLU: 2 gate/up pairs)
@@ -540,7 +584,7 @@ __device__ __forceinline__ uint4 dec_widen_fp8(f16_t, uint2 w8) {
   return make_uint4(__builtin_bit_cast(uint32_t, p0), __builtin_bit_cast(uint32_t, p1), __builtin_bit_cast(uint32_t, p2), __builtin_bit_cast(uint32_t, p3));
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int MB>
 __global__ __launch_bounds__(512) void linear_decode_fp8_mfma_kernel(const T* __restrict__ x, int64_t ldx, int M, const uint8_t* __restrict__ W,
                                                                      int64_t ldw, const float* __restrict__ sw, const T* __restrict__ bias,
                                                                      const T* __restrict__ res, int64_t ldr, T* __restrict__ out, int64_t ldo,
@@ -548,7 +592,7 @@ __global__ __launch_bounds__(512) void linear_decode_fp8_mfma_kernel(const T* __
   constexpr int RG = EPI == DEC_EPI_SWIGLU ? 2 : 1;
   constexpr int PITCH = 272;
   __shared__ __attribute__((aligned(16))) char tile[8][RG][16 * PITCH];
-  __shared__ float part[8][RG][256];
+  __shared__ float part[8][RG][MB][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int lr = lane >> 4, lc = lane & 15;
@@ -559,24 +603,33 @@ __global__ __launch_bounds__(512) void linear_decode_fp8_mfma_kernel(const T* __
   const uint8_t* wbase[RG];
 #pragma unroll
   for (int q = 0; q < RG; ++q) wbase[q] = W + (int64_t)(row0[q] + lr) * ldw + 16 * lc;
-  const bool col_ok = r < M;
-  const T* xrow = x + (int64_t)(col_ok ? r : 0) * ldx + 8 * g;
-  dec_f32x4 acc[RG];
+  bool col_ok[MB];
+  const T* xrow[MB];
 #pragma unroll
-  for (int q = 0; q < RG; ++q) acc[q] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < MB; ++b) {
+    col_ok[b] = r + 16 * b < M;
+    xrow[b] = x + (int64_t)(col_ok[b] ? r + 16 * b : 0) * ldx + 8 * g;
+  }
+  dec_f32x4 acc[RG][MB];
+#pragma unroll
+  for (int q = 0; q < RG; ++q)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[q][b] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
   const int tiles = K / 256;
   for (int s = wave; s < tiles; s += 8) {
     const int k0 = 256 * s;
-    uint4 wreg[RG][4], xb[8];
+    uint4 wreg[RG][4], xb[MB][8];
 #pragma unroll
     for (int q = 0; q < RG; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j) wreg[q][j] = ldg_nt(reinterpret_cast<const uint4*>(wbase[q] + (int64_t)(4 * j) * ldw + k0));
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      xb[t] = make_uint4(0u, 0u, 0u, 0u);
-      if (col_ok) xb[t] = *reinterpret_cast<const uint4*>(xrow + k0 + 32 * t);
-    }
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        xb[b][t] = make_uint4(0u, 0u, 0u, 0u);
+        if (col_ok[b]) xb[b][t] = *reinterpret_cast<const uint4*>(xrow[b] + k0 + 32 * t);
+      }
 #pragma unroll
     for (int q = 0; q < RG; ++q)
 #pragma unroll
@@ -587,22 +640,27 @@ __global__ __launch_bounds__(512) void linear_decode_fp8_mfma_kernel(const T* __
 #pragma unroll
       for (int q = 0; q < RG; ++q) {
         const uint2 w8 = *reinterpret_cast<const uint2*>(&tile[wave][q][r * PITCH + (4 * t + g) * 8]);
-        acc[q] = dec_mfma(T{}, dec_widen_fp8(T{}, w8), xb[t], acc[q]);
+        const uint4 a = dec_widen_fp8(T{}, w8);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[q][b] = dec_mfma(T{}, a, xb[b][t], acc[q][b]);
       }
   }
 #pragma unroll
   for (int q = 0; q < RG; ++q)
-    *reinterpret_cast<float4*>(&part[wave][q][lane * 4]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      *reinterpret_cast<float4*>(&part[wave][q][b][lane * 4]) = make_float4(acc[q][b][0], acc[q][b][1], acc[q][b][2], acc[q][b][3]);
   __syncthreads();
-  if (tid < 256) {
-    const int l = tid >> 2, i = tid & 3;
-    const int row = 4 * (l >> 4) + i, m = l & 15;
+  for (int e = tid; e < 256 * MB; e += 512) {
+    const int b = e >> 8, t8 = e & 255;
+    const int l = t8 >> 2, i = t8 & 3;
+    const int row = 4 * (l >> 4) + i, m = (l & 15) + 16 * b;
     float v[RG];
 #pragma unroll
     for (int q = 0; q < RG; ++q) {
       v[q] = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v[q] += part[w][q][tid];
+      for (int w = 0; w < 8; ++w) v[q] += part[w][q][b][t8];
       v[q] *= sw[row0[q] + row];
     }
     if (m < M) {
@@ -632,7 +690,7 @@ extern "C" int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, con
   // rows nor on M); other shapes: VALU form with up to 4 rows
   const bool mfma_ok = K % 256 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
   const bool mfma = mfma_ok && M >= 2;
-  V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? 16 : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? 16 : 4, M);
+  V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? DEC_MAX_ROWS : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? DEC_MAX_ROWS : 4, M);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
   V3D_REQUIRE(aligned16(x) && aligned16(W8) && (M == 1 || (ldx % 8 == 0 && ldx >= K)), "%s: alignment", who);
   V3D_REQUIRE(epilogue != DEC_EPI_BIAS || bias, "%s: bias epilogue without bias", who);
@@ -640,8 +698,9 @@ extern "C" int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, con
   hipStream_t st = (hipStream_t)stream;
   if (mfma) {
     const int mblocks = (epilogue == DEC_EPI_SWIGLU ? N / 2 : N) / 16;
-#define V3D_LD8M(TT, EE) hipLaunchKernelGGL((linear_decode_fp8_mfma_kernel<TT, EE>), dim3(mblocks), dim3(512), 0, st, (const TT*)x, ldx, M, \
-                                            (const uint8_t*)W8, ldw, scale_w, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LD8M_B(TT, EE, BB) hipLaunchKernelGGL((linear_decode_fp8_mfma_kernel<TT, EE, BB>), dim3(mblocks), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                                  (const uint8_t*)W8, ldw, scale_w, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, N, K)
+#define V3D_LD8M(TT, EE) { if (M <= 16) V3D_LD8M_B(TT, EE, 1); else V3D_LD8M_B(TT, EE, 2); }
 #define V3D_LD8M_E(TT)                                                                                \
   switch (epilogue) {                                                                                 \
     case DEC_EPI_NONE: V3D_LD8M(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LD8M(TT, DEC_EPI_BIAS); break; \
@@ -651,6 +710,7 @@ extern "C" int v3d_linear_decode_fp8_rows(const void* x, int64_t ldx, int M, con
     if (dtype == V3D_BF16) { V3D_LD8M_E(bf16_t) } else { V3D_LD8M_E(f16_t) }
 #undef V3D_LD8M_E
 #undef V3D_LD8M
+#undef V3D_LD8M_B
     return check_launch(who);
   }
   const int blocks = N / 4;
@@ -677,7 +737,7 @@ static int rope_kv_append_rows(void* qkv, int64_t qkv_stride, int M, int n_q_hea
                                const void* sin_table, int n_pos, const int* pos, void* const* cache_rows, int dtype, void* stream,
                                const char* who) {
   V3D_REQUIRE(qkv && cos_table && sin_table && pos && cache_rows, "%s: null pointer", who);
-  V3D_REQUIRE(M >= 1 && M <= 16 && head_dim % 16 == 0 && aligned16(qkv) && qkv_stride % 8 == 0, "%s: bad arguments", who);
+  V3D_REQUIRE(M >= 1 && M <= DEC_MAX_ROWS && head_dim % 16 == 0 && aligned16(qkv) && qkv_stride % 8 == 0, "%s: bad arguments", who);
   RopeRows rw{};
   for (int m = 0; m < M; ++m) {
     V3D_REQUIRE(pos[m] >= 0 && pos[m] < n_pos, "%s: pos %d outside the table (%d)", who, pos[m], n_pos);

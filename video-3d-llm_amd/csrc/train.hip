@@ -680,6 +680,44 @@ __global__ __launch_bounds__(256) void axpy_kernel(T* __restrict__ y, const T* _
 }
 
 
+// Sum of squares of a flat tensor (f32 / f16 / bf16) in f32, deterministic: SUMSQ_BLOCKS fixed partials (a block walks a fixed strided
+// set of 8-element vectors, lanes then waves reduced in a fixed order), then ONE block folds the partials in index order.  The global
+// gradient norm of torch.nn.utils.clip_grad_norm_ (HF Trainer max_grad_norm = 1.0; scripts/zero2.json:36 "gradient_clipping": "auto")
+// is sqrt of the sum of these over the gradient tensors.  `accumulate`: the result is added to *out (chaining over tensors in a fixed
+// order) instead of overwriting it.
+constexpr int SUMSQ_BLOCKS = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_part_kernel(const T* __restrict__ x, int64_t n, float* __restrict__ part) {
+  constexpr int VEC = sizeof(T) == 4 ? 4 : 8;
+  const int64_t nv = n / VEC;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+    const uint4 a = reinterpret_cast<const uint4*>(x)[i];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { const float v = vec_get<T>(a, j); acc = fmaf(v, v, acc); }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n - nv * VEC)) { const float v = to_f32(x[nv * VEC + threadIdx.x]); acc = fmaf(v, v, acc); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ float sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ part, int n_part, float* __restrict__ out, int accumulate) {
+  __shared__ float sm[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_part; i += 256) acc += part[i];
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if ((int)threadIdx.x < s_) sm[threadIdx.x] += sm[threadIdx.x + s_];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + sm[0];
+}
+
 // The grounding head's loss, predict_box 'infonce' (llava_qwen.py:296-310): s_i = <o_i / |o_i|, q / |q|>, logits e^{s_i / tau},
 // loss = -log(sum over the positives / sum over all rows), and its gradient with respect to the head outputs o [n, C] and q [C]:
 //   dloss / ds_i = (l_i / Z - [i positive] l_i / P) / tau,   do_i = ds_i (q^ - s_i o^_i) / |o_i|,   dq = sum_i ds_i (o^_i - s_i q^) / |q|.
@@ -1044,6 +1082,20 @@ extern "C" int v3d_axpy(void* y, const void* x, float alpha, int64_t n, int dtyp
   if (blocks > 256 * 16) blocks = 256 * 16;
   V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(axpy_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (T*)y, (const T*)x, alpha, n));
   return check_launch("v3d_axpy");
+}
+
+extern "C" int64_t v3d_sumsq_workspace_bytes() { return (int64_t)SUMSQ_BLOCKS * (int64_t)sizeof(float); }
+
+extern "C" int v3d_sumsq(const void* x, int64_t n, int dtype, float* out, int accumulate, float* workspace, void* stream) {
+  V3D_REQUIRE(x && out && workspace && n > 0 && aligned16(x), "v3d_sumsq: bad arguments (16-byte aligned, n > 0)");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
+  V3D_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(sumsq_part_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, n, workspace));
+  if (int e = check_launch("v3d_sumsq")) return e;
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, (int)blocks, out, accumulate);
+  return check_launch("v3d_sumsq");
 }
 
 extern "C" int v3d_ground_infonce(const void* obj, int64_t ldo, int n, const void* query, int C, const uint8_t* positive, float temperature,

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libv3d_hip.so")
 
 _lib = None
-ABI_VERSION = 5      # include/v3d.h V3D_ABI_VERSION
+ABI_VERSION = 6      # include/v3d.h V3D_ABI_VERSION
 
 
 class V3DError(RuntimeError):
@@ -109,6 +109,8 @@ SIGNATURES = {
     "v3d_gelu_grad": (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
     "v3d_layernorm_grad": (c_i, [c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p, c_l, c_p, c_p, c_p, c_i, c_l, c_i, c_f, c_i, c_p]),
     "v3d_axpy": (c_i, [c_p, c_p, c_f, c_l, c_i, c_p]),
+    "v3d_sumsq_workspace_bytes": (c_l, []),
+    "v3d_sumsq": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_p]),
     "v3d_ground_infonce": (c_i, [c_p, c_l, c_i, c_p, c_i, c_p, c_f, c_p, c_p, c_p, c_l, c_p, c_i, c_p]),
     "v3d_masked_mean_grad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "v3d_uniform_frame_indices_host": (c_i, [c_i, c_i, c_p]),

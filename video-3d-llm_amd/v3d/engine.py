@@ -712,15 +712,17 @@ class Engine:
         logits = self.llm_forward(x, P, last_rows=[Q - 1])
         return self.decode_loop(logits, P + Q, max_new_tokens, eos_token_id, stopping)
 
+    MAX_GROUP = 32          # scenes / questions whose decode steps share a pass over the weights (r04: 32; csrc DEC_MAX_ROWS)
+
     def _answer_state(self, n):
-        """Buffers of answer_group, allocated once: per layer ONE K/V allocation [16, max_pos, 2*kv_width] whose slices are the
+        """Buffers of answer_group, allocated once: per layer ONE K/V allocation [MAX_GROUP, max_pos, 2*kv_width] whose slices are the
         caches of the questions answered together (so one batched attention launch can address them by a batch stride), the
         contexts that view them, the residual stream of the batched question rows and the decode group's row buffers."""
         st = self.__dict__.get("_answer_st")
         if st is None:
             l = self.cfg.llm
             st = self._answer_st = SceneContext()
-            st.n = 16
+            st.n = self.MAX_GROUP
             st.kv = [torch.zeros((st.n, l.max_pos, 2 * l.kv_heads * self.hd), dtype=self.dtype, device=self.device) for _ in range(l.layers)]
             st.x = torch.zeros((l.max_pos, l.hidden), dtype=self.dtype, device=self.device)
             st.ctxs = []
@@ -736,7 +738,7 @@ class Engine:
 
     @torch.no_grad()
     def answer_group(self, questions, max_new_tokens=16, eos_token_id=None):
-        """Up to 16 questions about the scene prefilled by prefill_scene, answered together: the cached prefix K/V is handed to
+        """Up to 32 questions about the scene prefilled by prefill_scene, answered together: the cached prefix K/V is handed to
         each question's own cache (one broadcast copy per layer), the questions' rows run through the decoder as ONE batch
         (one pass over the weights; rows padded to the longest question, which causality keeps from affecting the real rows),
         then all answers decode as one group (decode_group).  Returns a list of token-id tensors, each cut after its first EOS.
@@ -749,7 +751,7 @@ class Engine:
         st = self._answer_state(G)
         lens = [int(q.numel()) for q in questions]
         if G < 1 or min(lens) < 1:
-            raise V3DError("answer_group() needs 1 to 16 non-empty questions")
+            raise V3DError(f"answer_group() needs 1 to {self.MAX_GROUP} non-empty questions")
         Sq = max(lens)
         l = self.cfg.llm
         if G * Sq > l.max_pos:
@@ -787,18 +789,18 @@ class Engine:
 
     @torch.no_grad()
     def generate_group(self, samples, max_new_tokens=16, eos_token_id=None):
-        """Throughput form of `generate` for up to 16 (input_ids, images, world_coords) samples: each is prefilled into its
+        """Throughput form of `generate` for up to 32 (input_ids, images, world_coords) samples: each is prefilled into its
         own context, then all decode together (one pass over the weights per step).  Returns a list of token-id tensors,
         each cut after its first EOS like `generate` does.  The contexts and the row buffers are cached on the engine."""
         n = len(samples)
-        if not 1 <= n <= 16:
-            raise V3DError("generate_group takes 1 to 16 samples")
+        if not 1 <= n <= self.MAX_GROUP:
+            raise V3DError(f"generate_group takes 1 to {self.MAX_GROUP} samples")
         pool = self.__dict__.setdefault("_group_ctxs", [])
         while len(pool) < n:
             pool.append(self.new_context())
         grp = self.__dict__.get("_group_rows")
         if grp is None or grp.n < n:
-            grp = self._group_rows = self.new_group(16 if n > 4 else 4)
+            grp = self._group_rows = self.new_group(self.MAX_GROUP if n > 16 else (16 if n > 4 else 4))
         keep = self.ctx
         lens = []
         try:
@@ -817,11 +819,11 @@ class Engine:
 
     # ------------------------------------------------------------------ scenes decoding together
     def new_group(self, n_scenes):
-        """Row buffers for up to 16 scenes whose decode steps run as ONE pass over the weights (the decode step is
+        """Row buffers for up to 32 scenes whose decode steps run as ONE pass over the weights (the decode step is
         HBM-bound on the 15 GB of weights and the weights feed the matrix cores directly, so M scenes cost about
         what one does; a row's arithmetic does not depend on the other rows, so grouping never changes a token)."""
-        if not 1 <= n_scenes <= 16:
-            raise V3DError("a decode group holds 1 to 16 scenes")
+        if not 1 <= n_scenes <= self.MAX_GROUP:
+            raise V3DError(f"a decode group holds 1 to {self.MAX_GROUP} scenes")
         l = self.cfg.llm
         z = lambda *s: torch.zeros(s, dtype=self.dtype, device=self.device)
         g = SceneContext()

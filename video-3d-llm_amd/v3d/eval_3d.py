@@ -185,7 +185,7 @@ def main(argv=None, task=None):
         print(f"The {a.answer_file} already exists!!!")
         return 0
     pool = None
-    if a.loader_workers >= 0 and not (task in GEN_TASKS and (a.no_pipeline or a.reuse_scenes)):
+    if a.loader_workers >= 0 and not (task in GEN_TASKS and a.no_pipeline):
         from . import frame_io
         pool = frame_io.make_pool(a.loader_workers or E.default_workers())          # forked before this process touches the GPU
     torch.cuda.set_device(local)

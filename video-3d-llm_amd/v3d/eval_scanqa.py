@@ -15,7 +15,9 @@ GPU instead of Ray actors + a file lock:
 * collation: ONE variable-length gather of the records to rank 0 (v3d.distributed.gather_records over RCCL), which writes
   the JSONL answer file in the original question order (the reference appends under fasteners.InterProcessLock in arrival order).
 `--reuse-scenes` (not in the reference): consecutive questions of one scene share the scene's prefill
-(Engine.prefill_scene) and are answered in batches of up to 16 (Engine.answer_group); records and order are unchanged.
+(Engine.prefill_scene) and are answered in batches of up to 16 (Engine.answer_group); records and order are unchanged.  It runs on the
+pipeline too (r04, v3d.pipeline.SceneReusePipeline: asynchronous loader, the next scene's prefill beside this scene's answers);
+`--no-pipeline` gives the synchronous form.
 """
 import argparse
 import json
@@ -134,6 +136,7 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
                     reuse_scenes=False, times=None, pipeline=True, group_size=16, workers=None, stats=None, record_fn=None, pool=None,
                     box_input_fn=None, skip_fn=None):
     """The per-rank loop of model_scanqa.py:130-206 around `model` (the loader-produced LlavaQwenForCausalLM).
+    reuse_scenes: one scene prefill per run of consecutive questions about a scene (pipelined or, with pipeline=False, synchronous).
     pipeline (default): v3d.pipeline - asynchronous host loader, prefill / grouped-decode overlap, device-side stop test; the
     records are those of the one-question-at-a-time loop (`pipeline=False`, the reference's own order of operations) up to the
     f32 summation order of the decode linears (tests/test_gpu_eval_harness.py).  stats: dict that receives the host-stage seconds.
@@ -244,8 +247,60 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
                           "upload_enqueue_seconds": pipe.upload_seconds, "questions": len(lines), "wall_seconds": time.time() - t0})
         return [decode(t) for t in toks]
 
+    def scene_pipelined(lines):
+        """--reuse-scenes on the pipeline (v3d.pipeline.SceneReusePipeline; r04): asynchronous loader per SCENE, scene i + 1's upload / ViT /
+        prefix prefill on one stream while scene i's answer batches run on another; records = scene_batches' records."""
+        return with_skipped(lines, _scene_pipelined_texts)
+
+    def _scene_pipelined_texts(lines):
+        from .pipeline import AsyncSceneLoader, SceneReusePipeline, SceneSample
+        if not lines:
+            return []
+        eng = model.engine
+        pipe = model.__dict__.get("_v3d_reuse_pipeline")
+        if pipe is None:
+            pipe = model.__dict__["_v3d_reuse_pipeline"] = SceneReusePipeline(
+                eng, crop=image_processor.crop_size["width"], image_mean=image_processor.image_mean, image_std=image_processor.image_std,
+                rescale=image_processor.rescale_factor)
+        groups, i = [], 0                                  # runs of consecutive questions about one scene
+        while i < len(lines):
+            j = i
+            while j < len(lines) and lines[j]["video"] == lines[i]["video"]:
+                j += 1
+            ids = [build_prompt_ids(l, tokenizer)[0] for l in lines[i:j]]
+            if any(int((x == IMAGE_TOKEN_INDEX).sum()) != 1 for x in ids):
+                raise ValueError("exactly one <image> placeholder per prompt (model_scanqa.py:61)")
+            at = int((ids[0] == IMAGE_TOKEN_INDEX).nonzero()[0])
+            prefix = ids[0][: at + 1]
+            if any(not torch.equal(x[: at + 1], prefix) for x in ids):
+                raise ValueError("questions of one scene must share the prompt prefix up to <image>")
+            groups.append((lines[i]["video"], prefix, [x[at + 1:] for x in ids]))
+            i = j
+        loader = AsyncSceneLoader([g[0] for g in groups], lambda vid: video_processor.describe_scene(vid, True, max_frame_num),
+                                  workers=default_workers() if workers is None else workers, pool=pool, ahead=2, keep=2)
+        waited = [0.0]
+
+        def scenes():
+            for k, (vid, prefix, qs) in enumerate(groups):
+                raw, w = loader.get(k)
+                waited[0] += w
+                yield SceneSample(input_ids=prefix, raw=raw, key=None), qs
+
+        t0 = time.time()
+        try:
+            answers = pipe.run(scenes(), max_new_tokens, eos_token_id=model._eos())
+        finally:
+            loader.close()
+        if times is not None and lines:
+            times.extend([(time.time() - t0) / len(lines)] * len(lines))
+        if stats is not None:
+            stats.update({"host_thread_seconds": dict(loader.stage_seconds), "loader_wait_seconds": waited[0],
+                          "upload_enqueue_seconds": pipe.upload_seconds, "questions": len(lines), "scenes": len(groups),
+                          "wall_seconds": time.time() - t0})
+        return [decode(t) for scene_answers in answers for t in scene_answers]
+
     if reuse_scenes:
-        return scene_batches
+        return scene_pipelined if pipeline else scene_batches
     return pipelined if pipeline else one_by_one
 
 
@@ -291,7 +346,7 @@ def main(argv=None):
         print(f"The {a.answer_file} already exists!!!")
         return 0
     pool = None
-    if not a.no_pipeline and not a.reuse_scenes and a.loader_workers >= 0:
+    if not a.no_pipeline and a.loader_workers >= 0:
         from . import frame_io
         pool = frame_io.make_pool(a.loader_workers or default_workers())        # forked before this process touches the GPU
     torch.cuda.set_device(local)

@@ -955,6 +955,30 @@ def adamw_step(p32, m, v, grad, p16=None, lr=1e-5, betas=(0.9, 0.999), eps=1e-8,
           "v3d_adamw_step")
 
 
+_sumsq_ws = {}
+
+
+def sumsq(x, out=None, accumulate=False):
+    """Sum of squares of a flat device tensor (f32 / f16 / bf16) in f32, deterministic (v3d_sumsq) -> out f32 [1] on the device
+    (accumulate: added to it).  The global gradient norm of clip_grad_norm_ is sqrt of the sum over the gradient tensors."""
+    t = _dev(x, "x")
+    if not t.is_contiguous():
+        raise V3DError("sumsq wants a contiguous tensor")
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=t.device)
+        accumulate = False
+    key = (t.device, torch.cuda.current_stream().cuda_stream)
+    ws = _sumsq_ws.get(key)
+    if ws is None:
+        ws = _sumsq_ws[key] = torch.empty(lib().v3d_sumsq_workspace_bytes() // 4, dtype=torch.float32, device=t.device)
+    if t.numel() == 0:
+        if not accumulate:
+            out.zero_()
+        return out
+    check(lib().v3d_sumsq(_p(t), t.numel(), _DT[t.dtype], _p(out), 1 if accumulate else 0, _p(ws), _stream()), "v3d_sumsq")
+    return out
+
+
 def embed_grad(dh, rows, ids, dE):
     """dE[ids[i]] = sum of dh[rows[j]] over the j with the same id (text rows of a sample); dE [vocab, H] pre-zeroed by the caller.
     ids outside [0, vocab) (e.g. IMAGE_TOKEN_INDEX of a raw prompt) and rows outside dh are skipped."""

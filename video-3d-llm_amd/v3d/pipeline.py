@@ -185,13 +185,15 @@ class AsyncSceneLoader:
 
 class ScenePipeline:
     def __init__(self, eng, group_size=16, crop=384, scene_cache=3, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5),
-                 rescale=1 / 255, prefill_streams=1):
-        if not 1 <= group_size <= 16:
-            raise V3DError("decode groups hold 1 to 16 scenes")
+                 rescale=1 / 255, prefill_streams=1, decode_contexts=True):
+        if not 1 <= group_size <= eng.MAX_GROUP:
+            raise V3DError(f"decode groups hold 1 to {eng.MAX_GROUP} scenes")
         self.eng, self.G, self.crop = eng, group_size, crop
         self.mean, self.std, self.rescale = tuple(image_mean), tuple(image_std), rescale
-        self.sets = [[eng.ctx] + [eng.new_context() for _ in range(group_size - 1)], [eng.new_context() for _ in range(group_size)]]
-        self.groups = [eng.new_group(group_size), eng.new_group(group_size)]
+        # decode_contexts=False (SceneReusePipeline): only the device-input half is wanted - no per-scene decode contexts (0.6 GB each)
+        self.sets = [[eng.ctx] + [eng.new_context() for _ in range(group_size - 1)], [eng.new_context() for _ in range(group_size)]] \
+            if decode_contexts else None
+        self.groups = [eng.new_group(group_size), eng.new_group(group_size)] if decode_contexts else None
         dev = torch.device(eng.device)
         self.streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self.copy_stream = torch.cuda.Stream(device=dev)
@@ -339,4 +341,84 @@ class ScenePipeline:
         finally:
             eng.use_workspace(self.workspaces[0])      # (a prefill that raised part-way may have left the second one selected)
             eng.use(keep)
+        return out
+
+
+class SceneReusePipeline:
+    """Scene-level reuse AND the pipeline (r04; VERDICT r03 missing #2): consecutive questions about one scene share ONE
+    scene prefill (Engine.prefill_scene: geometry, ViT, projector, fusion, the decoder over [system | user | <image>]) and are answered in
+    batches (Engine.answer_group: the questions' rows as one batch over the cached prefix, then one decode group) - with the asynchronous
+    host loader in front and scene i+1's upload / device inputs / ViT / prefix prefill (MFMA-bound, stream A, its own scratch and scene
+    context) queued BEFORE scene i's answer groups (weight streaming, HBM-bound, stream B, the other scratch), so the two run side by side.
+    The reference recomputes the whole prompt for every question, one after the other (model_scanqa.py:130-206).
+    Records are those of the synchronous form (eval_scanqa.scene_batches): same kernels on the same operands; the scratch and the stream
+    a launch goes to do not enter the arithmetic (tests/test_gpu_eval_harness.py)."""
+
+    def __init__(self, eng, crop=384, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5), rescale=1 / 255, batch=16):
+        if not 1 <= batch <= eng.MAX_GROUP:
+            raise V3DError(f"answer batches hold 1 to {eng.MAX_GROUP} questions")
+        self.eng, self.batch = eng, batch
+        self.inputs = ScenePipeline(eng, 1, crop=crop, scene_cache=0, image_mean=image_mean, image_std=image_std, rescale=rescale,
+                                    decode_contexts=False)
+        dev = torch.device(eng.device)
+        self.sA, self.sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.scene_ctx = [eng.ctx, eng.new_context()]            # the prefix K/V of the scene being answered / being prefilled
+        self.ws = [eng.ws, eng.new_prefill_workspace()]          # [0]: scene prefills (stream A); [1]: the question-row batches (stream B)
+        self.wait_seconds = 0.0
+
+    @property
+    def upload_seconds(self):
+        return self.inputs.upload_seconds
+
+    @torch.no_grad()
+    def run(self, scenes, max_new_tokens, eos_token_id=None, overlap=True):
+        """scenes: iterable of (SceneSample whose input_ids are the PREFIX ids up to and including <image>, [question id tensors]) - consumed
+        lazily, one scene ahead.  Returns, per scene, the list of its answers' token-id tensors (host, cut after the first EOS)."""
+        eng = self.eng
+        keep_ctx, keep_ws = eng.ctx, eng.ws
+        it = iter(scenes)
+        cur = torch.cuda.current_stream()
+        sA, sB = (self.sA, self.sB) if overlap else (cur, cur)
+        out = []
+
+        def queue_prefill(k):
+            item = next(it, None)
+            if item is None:
+                return None
+            smp, questions = item
+            with torch.cuda.stream(sA):
+                eng.use_workspace(self.ws[0])
+                eng.use(self.scene_ctx[k % 2])
+                images, coords = self.inputs.device_inputs(smp)
+                P = eng.prefill_scene(smp.input_ids, images, coords)
+                done = sA.record_event()
+            return k, questions, P, done
+
+        try:
+            if overlap:
+                sA.wait_stream(cur)
+                sB.wait_stream(cur)
+            pending = queue_prefill(0)
+            while pending is not None:
+                k, questions, P, done = pending
+                # the NEXT scene's prefill goes to stream A before this scene's answers are queued: the host then sits in the answer
+                # groups' stop-test polling while stream A works.  Its context was last read by scene k - 1's answers, which the host
+                # has already collected.
+                pending = queue_prefill(k + 1)
+                answers = []
+                with torch.cuda.stream(sB):
+                    sB.wait_event(done)
+                    eng.use_workspace(self.ws[1])
+                    eng.use(self.scene_ctx[k % 2])
+                    for b0 in range(0, len(questions), self.batch):
+                        qs = questions[b0: b0 + self.batch]
+                        room = eng.cfg.llm.max_pos - P - max(int(q.numel()) for q in qs) + 1
+                        answers += [a.cpu() for a in eng.answer_group(qs, max_new_tokens=min(max_new_tokens, room), eos_token_id=eos_token_id)]
+                out.append(answers)
+            if overlap:
+                cur.wait_stream(sA)
+                cur.wait_stream(sB)
+        finally:
+            eng.use_workspace(keep_ws)
+            eng.use(keep_ctx)
         return out

@@ -308,18 +308,116 @@ def accumulate_grads(total, grads):
     return total
 
 
+# ---- what the reference's trainer configures around the update (train_multi.sh:45, 65-68; llava_trainer.py:446-523; zero2.json:36)
+LR_KEYWORDS = {"vision_tower": "vision", "mm_projector": "projector"}     # the reference's module keywords -> this tree's top-level keys
+
+
+def _paths(tree, prefix=""):
+    if isinstance(tree, dict):
+        out = []
+        for k in tree:
+            out += _paths(tree[k], f"{prefix}.{k}" if prefix else str(k))
+        return out
+    if isinstance(tree, list):
+        out = []
+        for i, v in enumerate(tree):
+            out += _paths(v, f"{prefix}.{i}")
+        return out
+    return [prefix]
+
+
+def _no_decay(path):
+    """llava_trainer.py:459-460: no weight decay for the parameters of nn.LayerNorm modules (get_parameter_names(model,
+    ALL_LAYERNORM_LAYERS); the vendored Qwen2RMSNorm is NOT in that list, so the decoder's norm weights ARE decayed) and for every
+    parameter whose name contains "bias".  This tree's names: the tower's LayerNorms vision.layers.N.ln{1,2}_{w,b}, the grounding heads'
+    LayerNorm `*.ln_w / ln_b`; biases *_b, b0 .. b3, *_bias."""
+    leaf = path.rsplit(".", 1)[-1]
+    layernorm = leaf in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "ln_w", "ln_b")
+    return layernorm or (leaf[:1] == "b" and leaf[1:].isdigit()) or leaf.endswith(("_b", "_bias")) or "bias" in leaf
+
+
+def param_groups(params, lr, weight_decay=0.0, lr_by_module=None):
+    """Per-leaf (lr, weight_decay) in the order of the tree's leaves: the reference's optimizer groups (llava_trainer.py:446-523) -
+    `--mm_vision_tower_lr 2e-6` / `--mm_projector_lr` give the tower / projector their own learning rate (train_multi.sh:45), every other
+    parameter takes `--learning_rate` (:65); biases and norm weights are not decayed.  lr_by_module: {"vision_tower" | "mm_projector" (the
+    reference's keywords) or a top-level key of this tree: lr}."""
+    by = {LR_KEYWORDS.get(k, k): float(v) for k, v in (lr_by_module or {}).items() if v is not None}
+    out = []
+    for path in _paths(params):
+        top = path.split(".", 1)[0]
+        out.append((by.get(top, float(lr)), 0.0 if _no_decay(path) else float(weight_decay)))
+    return out
+
+
+def cosine_warmup_schedule(total_steps, warmup_ratio=0.03):
+    """`--lr_scheduler_type cosine --warmup_ratio 0.03` (train_multi.sh:67-68) as the HF Trainer builds it (get_cosine_schedule_with_warmup,
+    warm-up steps = ceil(ratio * total)): multiplier of every group's base lr at optimizer step t = 1, 2, ...  The scheduler is stepped
+    AFTER the optimizer, so step t runs with lambda(t - 1): the first step of a run with warm-up has lr 0."""
+    import math
+    warm = int(math.ceil(total_steps * warmup_ratio))
+
+    def lam(t):
+        k = t - 1
+        if k < warm:
+            return k / max(1, warm)
+        prog = (k - warm) / max(1, total_steps - warm)
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    return lam
+
+
+def global_grad_norm(grad_leaves):
+    """Sum of squares over all gradient tensors as one f32 device scalar [1], deterministic (v3d_sumsq chained over the leaves in tree
+    order); its square root is torch.nn.utils.clip_grad_norm_'s total_norm (norm_type 2)."""
+    acc = None
+    for g in grad_leaves:
+        if g is None or g.numel() == 0:
+            continue
+        acc = ops.sumsq(g.contiguous().view(-1), out=acc, accumulate=acc is not None)
+    if acc is None:
+        return torch.zeros(1, dtype=torch.float32, device="cuda")
+    return acc
+
+
+def clip_coefficient(total_norm, max_norm):
+    """clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1."""
+    return min(1.0, float(max_norm) / (float(total_norm) + 1e-6))
+
+
 class AdamW:
     """f32 master weights and moments for a dict / list tree of 16-bit parameter tensors; step(grads) updates the tree in place
-    (one v3d_adamw_step per tensor).  Hyper-parameters as train_multi.sh gives them to the HF Trainer (lr 1e-5, weight decay 0)."""
+    (one v3d_adamw_step per tensor).  Hyper-parameters as train_multi.sh gives them to the HF Trainer (lr 1e-5, weight decay 0).
+    r04 (the trainer-side fidelity of f4): lr_by_module (per-module learning rates, llava_trainer.py:446-523), max_grad_norm (global
+    gradient-norm clipping before the update: HF max_grad_norm = 1.0 / zero2.json:36; None = off), schedule (a multiplier of the
+    learning rates per step, e.g. cosine_warmup_schedule).  `last_grad_norm` holds the norm of the last step's (scaled) gradient."""
 
-    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lr_by_module=None, max_grad_norm=None, schedule=None):
         self.lr, self.betas, self.eps, self.weight_decay, self.t = lr, betas, eps, weight_decay, 0
+        self.groups = param_groups(params, lr, weight_decay, lr_by_module)
+        self.max_grad_norm, self.schedule, self.last_grad_norm = max_grad_norm, schedule, None
         self.state = _tree_map(lambda p: (p.detach().float().contiguous(), torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32)), params)
 
     def step(self, params, grads, grad_scale=1.0):
         self.t += 1
-        _tree_zip(lambda p, g, st: ops.adamw_step(st[0], st[1], st[2], g.contiguous(), p16=p, lr=self.lr, betas=self.betas, eps=self.eps,
-                                                  weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale), params, grads, self.state)
+        if self.max_grad_norm is not None:             # the norm of the gradient the update sees (after grad_scale: the accumulation mean)
+            self.last_grad_norm = float(global_grad_norm(_leaves(grads)).sqrt()) * abs(grad_scale)
+            grad_scale = grad_scale * clip_coefficient(self.last_grad_norm, self.max_grad_norm)
+        mult = self.schedule(self.t) if self.schedule is not None else 1.0
+        groups = iter(self.groups)
+
+        def one(p, g, st):
+            lr, wd = next(groups)
+            ops.adamw_step(st[0], st[1], st[2], g.contiguous(), p16=p, lr=lr * mult, betas=self.betas, eps=self.eps, weight_decay=wd,
+                           step=self.t, grad_scale=grad_scale)
+        _tree_zip(one, params, grads, self.state)
+
+
+def _leaves_of_state(state):
+    """The (p32, m, v) tuples of an AdamW state tree, in leaf order."""
+    if isinstance(state, dict):
+        return [x for k in state for x in _leaves_of_state(state[k])]
+    if isinstance(state, list):
+        return [x for v in state for x in _leaves_of_state(v)]
+    return [state]
 
 
 def _tree_map(fn, tree):
@@ -537,13 +635,16 @@ class ZeroAdamW:
     with "gloo" - the one-GPU rehearsal of tests/test_gpu_zero2.py - the flat buffers are staged through host memory).
     Not yet run on more than one GPU."""
 
-    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_elems=None, algorithm="ring"):
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, bucket_elems=None, algorithm="ring",
+                 lr_by_module=None, max_grad_norm=None, schedule=None):
         import torch.distributed as dist
         from . import distributed as D
         self.D, self.dist = D, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.host_staged = dist.get_backend() == "gloo"
         self.lr, self.betas, self.eps, self.weight_decay, self.t = lr, betas, eps, weight_decay, 0
+        self.max_grad_norm, self.schedule, self.last_grad_norm = max_grad_norm, schedule, None
+        groups = param_groups(params, lr, weight_decay, lr_by_module)
         self.bucket = bucket_elems or D.ZERO2_BUCKET_ELEMS
         self.algorithm = algorithm
         leaves = _leaves(params)
@@ -565,6 +666,19 @@ class ZeroAdamW:
         self.master = self.mine.float()
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
+        # this rank's partition cut into runs of constant (lr, weight decay) - the optimizer groups of llava_trainer.py:446-523 laid over
+        # the flat buffer (a partition boundary may fall inside a tensor, a tensor boundary inside a partition): [(lo, hi, lr, wd)], local
+        self.segments = []
+        off = 0
+        for p, (g_lr, g_wd) in zip(leaves, groups):
+            lo, hi = max(off, b) - b, min(off + p.numel(), b + self.per) - b
+            off += p.numel()
+            if lo >= hi:
+                continue
+            if self.segments and self.segments[-1][1] == lo and self.segments[-1][2:] == (g_lr, g_wd):
+                self.segments[-1] = (self.segments[-1][0], hi, g_lr, g_wd)
+            else:
+                self.segments.append((lo, hi, g_lr, g_wd))
 
     def _flatten_grads(self, grads):
         """grads -> self.flat_g, walking the PARAMETER tree by key: a leaf the sample has no gradient for (the LM head of a
@@ -630,8 +744,20 @@ class ZeroAdamW:
             part = self.D.reduce_scatter_grads(flat_g.cpu(), self.bucket, average=True, algorithm=self.algorithm).to(self.flat.device)
         else:
             part = self.D.reduce_scatter_grads(flat_g, self.bucket, average=True, algorithm=self.algorithm)
-        ops.adamw_step(self.master, self.m, self.v, part.contiguous(), p16=self.mine, lr=self.lr, betas=self.betas, eps=self.eps,
-                       weight_decay=self.weight_decay, step=self.t, grad_scale=grad_scale)
+        part = part.contiguous()
+        if self.max_grad_norm is not None:
+            # the norm of the AVERAGED gradient: each rank holds one partition of it after the reduce-scatter, so the squared norm is the
+            # sum of the partitions' (one all-reduce of a scalar; DeepSpeed's stage-2 clipping does the same)
+            sq = global_grad_norm([part])
+            if self.world > 1:
+                sq = sq.cpu() if self.host_staged else sq
+                self.dist.all_reduce(sq, op=self.dist.ReduceOp.SUM)
+            self.last_grad_norm = float(sq.sqrt()) * abs(grad_scale)
+            grad_scale = grad_scale * clip_coefficient(self.last_grad_norm, self.max_grad_norm)
+        mult = self.schedule(self.t) if self.schedule is not None else 1.0
+        for lo, hi, g_lr, g_wd in self.segments:
+            ops.adamw_step(self.master[lo:hi], self.m[lo:hi], self.v[lo:hi], part[lo:hi], p16=self.mine[lo:hi], lr=g_lr * mult, betas=self.betas,
+                           eps=self.eps, weight_decay=g_wd, step=self.t, grad_scale=grad_scale)
         if self.host_staged:
             full = self.D.all_gather_params(self.mine.cpu(), self.per * self.world, self.bucket).to(self.flat.device)
             self.flat.copy_(full)
