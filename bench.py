@@ -289,7 +289,7 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reus
     dataset's true sizes.  Two runs over the same files -> (eval_runner, reuse_runner):
       eval_runner   every question asks about ANOTHER scene than the previous eight (no scene reuse: the loader's worst case);
       reuse_runner  --reuse-scenes on the pipeline (r04): `reuse_questions_per_scene` consecutive questions per scene share ONE scene prefill
-                    and are answered in batches of 16, the next scene's load / ViT / prefix prefill running beside them."""
+                    and are answered in batches of 32, the next scene's load / ViT / prefix prefill running beside them."""
     import contextlib
     import shutil
     import tempfile
@@ -346,7 +346,7 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reus
         rstats = {}
         rfn = E.model_answer_fn(model, tok, SigLipImageProcessor(), vp, "bench", FRAMES, NEW_TOKENS, reuse_scenes=True, pipeline=True, stats=rstats,
                                 pool=pool, workers=n_workers)
-        rfn(rq[:16])                                      # warm-up (the answer batches' buffers: 16 per-question caches)
+        rfn(rq[:32])                                      # warm-up (the answer batches' buffers: 32 per-question caches)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rrecs = rfn(rq)
@@ -357,7 +357,7 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reus
         at = int((ids0 == IMAGE_TOKEN_INDEX).nonzero()[0])
         reuse = {"what": "--reuse-scenes ON the pipeline, end to end from the same files (v3d.pipeline.SceneReusePipeline): %d scenes x %d consecutive "
                          "questions; per scene ONE load + upload + ViT + prefix prefill (%d rows), its questions (%d rows + %d new tokens each) answered in "
-                         "batches of 16 on another stream while the NEXT scene is loaded and prefilled; compare `cached_questions` (the answering alone, "
+                         "batches of 32 on another stream while the NEXT scene is loaded and prefilled; compare `cached_questions` (the answering alone, "
                          "scene already prefilled, inputs resident)" % (n_sc, QPS, at + FRAMES * 210, len(ids0) - 1 - at, NEW_TOKENS),
                  "value": len(rq) / rdt, "unit": "questions/s", "ms_per_question": rdt / len(rq) * 1e3, "questions": len(rq), "scenes": n_sc,
                  "questions_per_scene": QPS, "gpu_waited_for_loader_ms_per_scene": rstats["loader_wait_seconds"] / n_sc * 1e3}
@@ -529,7 +529,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="one scene at a time: no decode groups, no prefill/decode overlap")
     ap.add_argument("--decode-group", type=int, default=16, help="scenes decoded together per pass over the weights (1..32)")
-    ap.add_argument("--answer-batch", type=int, default=16, help="cached_questions / reuse_runner: questions answered together (1..32)")
+    ap.add_argument("--answer-batch", type=int, default=32, help="cached_questions / reuse_runner: questions answered together (1..32)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[3]: e4m3 linears in the Qwen2 prefill; the headline line becomes that run")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements appended to the default N=1 line (fp8, cached questions, grounding)")
     ap.add_argument("--no-fp8-extra", action="store_true", help="skip only the configs[3] extra")
@@ -645,11 +645,12 @@ def main():
     if world == 1 and a.eval_runner_only:
         extras["eval_runner"], extras["reuse_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
     elif world == 1 and not a.no_extras:
-        nq, scene_ms = measure_cached_questions(eng, ops, scenes[0], dev, n_groups=max(1, a.steps // 4))
+        AB = max(1, min(32, a.answer_batch))
+        nq, scene_ms = measure_cached_questions(eng, ops, scenes[0], dev, n_groups=max(1, a.steps // 4), group=AB)
         extras["cached_questions"] = {
             "what": "scene-level reuse (SURVEY 8 f1; not the headline): further questions about an ALREADY prefilled scene - %d question rows "
-                    "per question run over the cached prefix of %d rows, 16 questions per batch, %d new tokens each; the one-off scene prefill "
-                    "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, NEW_TOKENS),
+                    "per question run over the cached prefix of %d rows, %d questions per batch, %d new tokens each; the one-off scene prefill "
+                    "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, AB, NEW_TOKENS),
             "value": nq, "unit": "questions/s", "scene_prefill_ms": scene_ms}
         try:
             extras["eval_runner"], extras["reuse_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)

@@ -15,7 +15,7 @@ GPU instead of Ray actors + a file lock:
 * collation: ONE variable-length gather of the records to rank 0 (v3d.distributed.gather_records over RCCL), which writes
   the JSONL answer file in the original question order (the reference appends under fasteners.InterProcessLock in arrival order).
 `--reuse-scenes` (not in the reference): consecutive questions of one scene share the scene's prefill
-(Engine.prefill_scene) and are answered in batches of up to 16 (Engine.answer_group); records and order are unchanged.  It runs on the
+(Engine.prefill_scene) and are answered in batches of up to 32 (Engine.answer_group); records and order are unchanged.  It runs on the
 pipeline too (r04, v3d.pipeline.SceneReusePipeline: asynchronous loader, the next scene's prefill beside this scene's answers);
 `--no-pipeline` gives the synchronous form.
 """
@@ -177,8 +177,9 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
         return with_skipped(lines, run)
 
     def scene_batches(lines):
-        """Consecutive questions of one scene: ONE scene prefill, answers in batches of up to 16 (Engine.answer_group)."""
+        """Consecutive questions of one scene: ONE scene prefill, answers in batches of up to 32 (Engine.answer_group)."""
         eng, out, i = model.engine, [], 0
+        nb = eng.MAX_GROUP
         eos = model._eos()
         while i < len(lines):
             j = i
@@ -192,8 +193,8 @@ def model_answer_fn(model, tokenizer, image_processor, video_processor, model_na
             images, vd = _video_inputs(video_processor, image_processor, lines[i]["video"], model, max_frame_num)
             with torch.inference_mode():
                 P = eng.prefill_scene(prefix, images[0], vd["world_coords"][0])
-                for b in range(i, j, 16):
-                    qs = [x[at + 1:] for x in ids[b - i: min(j, b + 16) - i]]
+                for b in range(i, j, nb):
+                    qs = [x[at + 1:] for x in ids[b - i: min(j, b + nb) - i]]
                     room = eng.cfg.llm.max_pos - P - max(len(q) for q in qs) + 1
                     answers = eng.answer_group(qs, max_new_tokens=min(max_new_tokens, room), eos_token_id=eos)
                     out += [record_fn(l, decode(a)) for l, a in zip(lines[b: b + len(qs)], answers)]

@@ -354,7 +354,7 @@ class SceneReusePipeline:
     Records are those of the synchronous form (eval_scanqa.scene_batches): same kernels on the same operands; the scratch and the stream
     a launch goes to do not enter the arithmetic (tests/test_gpu_eval_harness.py)."""
 
-    def __init__(self, eng, crop=384, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5), rescale=1 / 255, batch=16):
+    def __init__(self, eng, crop=384, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5), rescale=1 / 255, batch=32):
         if not 1 <= batch <= eng.MAX_GROUP:
             raise V3DError(f"answer batches hold 1 to {eng.MAX_GROUP} questions")
         self.eng, self.batch = eng, batch
