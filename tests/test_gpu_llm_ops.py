@@ -261,6 +261,36 @@ def test_attention_vit_heads_packed_at_true_stride(ops, kind):
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
+@pytest.mark.parametrize("B,S", [(32, 729), (3, 729), (1, 729), (5, 256), (2, 128), (40, 729), (7, 200)])
+def test_attention_vit_persistent_kernel_equals_one_workgroup_per_item_bitwise(ops, kind, B, S, monkeypatch):
+    """r04: attn_vit_persistent_kernel (workgroups walk their items; the last step of an item stages the next item's first tiles and
+    loads its Q) = attn_prefill_kernel<96, non-causal, 5 k-steps> (V3D_ATTN_VIT_PERSIST=0), bit for bit: the true shape (32 frames: one
+    (frame, head) pair per workgroup), fewer / more pairs than workgroup slots (3, 1, 40 frames), 4 and 2 key tiles, a short last tile
+    (200 keys), the output columns beyond the 16 x 72 head dims untouched; and against the f32 reference."""
+    dt = DT[kind]
+    H, D, DP = 16, 72, 96
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    qkv = torch.randn(B * S, 3584, generator=g).to(dt).cuda()
+    W = H * D
+
+    def run(mode):
+        monkeypatch.setenv("V3D_ATTN_VIT_PERSIST", mode)
+        att = torch.full((B * S, 1280), 3.0, dtype=dt, device="cuda")
+        ld = qkv.stride(0)
+        ops.attention(qkv, qkv[:, W:], qkv[:, 2 * W:], att, B, S, S, H, H, DP, D, ld, ld, ld, att.stride(0), S * ld, S * ld, S * att.stride(0),
+                      D, D, D, False, 0, D ** -0.5)
+        return att
+    a, b = run("0"), run("1")
+    assert torch.equal(a, b)
+    assert bool((b[:, W:] == 3.0).all())
+    q = qkv[:, :W].view(B, S, H, D).cpu()
+    k = qkv[:, W: 2 * W].view(B, S, H, D).cpu()
+    v = qkv[:, 2 * W: 3 * W].view(B, S, H, D).cpu()
+    want = ref_attention(q, k, v, False, D ** -0.5)
+    close(b[:, :W].view(B, S, H, D), want, kind, ulps=3.0, floor=0.3)
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
 @pytest.mark.parametrize("past", [0, 5, 700])
 def test_attention_decode(ops, kind, past):
     dt = DT[kind]

@@ -574,6 +574,365 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// r04: the SigLIP tower's attention as a PERSISTENT kernel.  attn_prefill_kernel<96, non-causal, KSV = 5> spends
+// about 9 k of the 41 k cycles of an item (one 128-query tile of one (frame, head): twelve 64-key steps) at its seam - workgroup launch,
+// the first tiles' DMAs and Q's HBM round trip with nothing else to do, tile 0's scores and softmax outside the pipeline, the
+// normalise / transpose / store tail - and because the 3072 items are all equal, the two workgroups of a CU reach their seams TOGETHER
+// for the whole launch.  Here a workgroup walks its items itself (grid = 2 per CU, items in the old grid's order), and the LAST step of
+// an item - which only has the final P.V product left - already stages the next item's first tiles (K0, V0, K1) into the three ring buffers that step no longer reads and
+// loads the next Q fragments into the registers the finished score phase freed.  The output tile leaves through the fourth buffer
+// (the last V tile's, free after the step-end barrier), 16 query rows per wave at a time, wave-private: no workgroup barrier in the tail.
+// Same arithmetic in the same order as attn_prefill_kernel<96, false, 5>: outputs bit for bit (tests/test_gpu_llm_ops.py).
+// Needs an even number of key tiles (the next item's buffers are free in the last step only then): 729 keys = 12 tiles.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_vit_persistent_kernel(AttnArgs p, int n_items) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  using M = Mfma32<T>;
+  constexpr int D = 96, KS = 6, DT = 3, CH = 12;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, h = lane >> 5;
+  const int n_pairs = n_items / p.n_qt;                     // (batch, head) pairs; item L = pair + n_pairs * query tile
+  const int n_tiles = (p.Sk + AT_BKV - 1) / AT_BKV;         // even (checked by the launcher)
+
+  const int srow = lane >> 4;
+  const int st_row0 = wave * 16 + srow;
+  const int st_chunk0 = (lane & 15) ^ (srow << 2);
+  const unsigned ldk_b = (unsigned)p.ldk * 2u, ldv_b = (unsigned)p.ldv * 2u;
+  // every LDS-DMA of this kernel is an asm statement: with the builtin anywhere in the item loop hipcc orders EVERY compiler-visible LDS
+  // access (the output staging of the tail) behind all outstanding vector-memory operations - vmcnt(0), i.e. behind the next item's
+  // tiles.  `stage`: the clamped form (a tile whose last rows do not exist: tail keys are masked in the scores).
+  auto stage = [&](const uint16_t* src, unsigned ld_b, unsigned lds_dst, int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = t * AT_BKV + st_row0 + 4 * i;
+      key = key < p.Sk ? key : p.Sk - 1;
+      int chunk = st_chunk0 ^ i;
+      chunk = chunk < CH ? chunk : CH - 1;
+      const unsigned off = (unsigned)key * ld_b + (unsigned)chunk * 16u;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   : : "v"(off), "s"(src), "s"(lds_dst + (unsigned)(i * 4 * AT_ROW)) : "memory", "m0");
+    }
+  };
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int chunk = st_chunk0 ^ i;
+    chunk = chunk < CH ? chunk : CH - 1;
+    koff[i] = (unsigned)(st_row0 + 4 * i) * ldk_b + (unsigned)chunk * 16u;
+    voff[i] = (unsigned)(st_row0 + 4 * i) * ldv_b + (unsigned)chunk * 16u;
+  }
+  const unsigned lds_wave0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)(wave * 16) * AT_ROW;
+  auto stage_fast = [&](const uint16_t* src, unsigned ld_b, const unsigned (&off)[4], unsigned lds_dst, int t) {
+    const char* base = (const char*)src + (size_t)t * (size_t)(AT_BKV * ld_b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   : : "v"(off[i]), "s"(base), "s"(lds_dst + (unsigned)(i * 4 * AT_ROW)) : "memory", "m0");
+  };
+
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int k_sw = kv_swz(ql);
+  const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int v_chunk_lo = 2 * (g & 1) + (pp >> 1);
+  const int v_byte = 8 * (pp & 1);
+  const int v_row0 = 4 * h + qq;
+  const int v_sw0 = kv_swz(v_row0), v_sw1 = kv_swz(v_row0 + 8);
+  const unsigned kaddr0_ = lds_base + ql * AT_ROW + ((h ^ k_sw) << 4);
+  const unsigned vaddr0_ = lds_base + AT_TILE + v_row0 * AT_ROW + v_byte + ((v_chunk_lo ^ v_sw0) << 4);
+  const unsigned vaddr1_ = lds_base + AT_TILE + (v_row0 + 8) * AT_ROW + v_byte + ((v_chunk_lo ^ v_sw1) << 4);
+
+  Frag16 qf[KS];
+  // item -> pointers
+  auto item_ptrs = [&](int L, const uint16_t*& Q, const uint16_t*& K, const uint16_t*& V, int& q0, int& head, int& b) {
+    // item order = the one-workgroup-per-item grid's (head fastest, then query tile, then frame): the six query tiles of a (frame,
+    // head) pair are in flight TOGETHER on workgroups of one XCD (ids equal mod 8), so the pair's K / V come out of that XCD's L2.
+    // (Giving a workgroup the six tiles of ONE pair, one after the other, was measured first: 240 us against 130 - every tile then
+    // pulls the pair's 210 KB of K / V through an L2 that 64 other pairs have flushed in the meantime.)
+    head = L % p.Hq;
+    const int r_ = L / p.Hq, qt = r_ % p.n_qt;
+    b = r_ / p.n_qt;
+    (void)n_pairs;
+    const int hk = head / p.group;
+    q0 = qt * AT_BQ;
+    Q = (const uint16_t*)p.q + b * p.bsq + (int64_t)head * p.hsq;
+    K = (const uint16_t*)p.k + b * p.bsk + (int64_t)hk * p.hsk;
+    V = (const uint16_t*)p.v + b * p.bsk + (int64_t)hk * p.hsk;
+  };
+  // Q in two parts: the loads (issued in the previous item's last step, beside its P.V product - their round trip is not waited for
+  // there) and the scaling / packing into the B-operand fragments (in the prologue, after the loads have landed)
+  uint4 qraw[KS];
+  auto load_q = [&](const uint16_t* Q, int q0) {
+    const int qi = q0 + wave * 32 + ql;
+    const int qi_ld = qi < p.Sq ? qi : p.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qraw[ks] = *reinterpret_cast<const uint4*>(Q + (int64_t)qi_ld * p.ldq + ks * 16 + h * 8);
+  };
+  auto pack_q = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 raw = qraw[ks];
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = vec_get<T>(raw, j) * p.scale_log2;
+      if (ks * 16 + 8 >= 72) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (ks * 16 + h * 8 + j) < p.d_out ? f[j] : 0.f;
+      }
+      qf[ks].u = vec_pack<T>(f);
+    }
+  };
+
+#define V3D_KR(dst, ks, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(kaddr0 ^ ((ks) << 5)), "i"(imm))
+#define V3D_KW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : : "memory")
+#define V3D_KM(f, i, kt, ks) s[kt] = M::run(__builtin_bit_cast(typename M::frag, f[i]), as_frag<T>(qf[ks]), s[kt])
+#define V3D_VR(f, dt, VB) { \
+  const unsigned a0 = vaddr0 ^ ((dt) << 6), a1 = vaddr1 ^ ((dt) << 6); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[0]) : "v"(a0), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[1]) : "v"(a1), "i"(VB)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[2]) : "v"(a0), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[3]) : "v"(a1), "i"(VB + 4096)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[4]) : "v"(a0), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[5]) : "v"(a1), "i"(VB + 8192)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[6]) : "v"(a0), "i"(VB + 12288)); \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[7]) : "v"(a1), "i"(VB + 12288)); }
+#define V3D_VW(cnt, f) asm volatile("s_waitcnt lgkmcnt(" #cnt ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory")
+
+  bool prefetched = false;
+  for (int L = blockIdx.x; L < n_items; L += gridDim.x) {
+    const uint16_t *Q, *K, *V;
+    int q0, head, b;
+    item_ptrs(L, Q, K, V, q0, head, b);
+    const int Ln = L + (int)gridDim.x;
+    const bool has_next = Ln < n_items;                       // workgroup-uniform
+
+    auto stage_k = [&](int buf, int t) { stage(K, ldk_b, lds_wave0 + buf * 2 * AT_TILE, t); };
+    auto stage_v = [&](int buf, int t) { stage(V, ldv_b, lds_wave0 + buf * 2 * AT_TILE + AT_TILE, t); };
+    auto stage_k_fast = [&](int buf, int t) { stage_fast(K, ldk_b, koff, lds_wave0 + buf * 2 * AT_TILE, t); };
+    auto stage_v_fast = [&](int buf, int t) { stage_fast(V, ldv_b, voff, lds_wave0 + buf * 2 * AT_TILE + AT_TILE, t); };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+
+    v4i ka_[4], kc_[4];
+    auto qk_fill = [&](auto kb_c) {
+      constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+      auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+      V3D_KR(ka[0], 0, KB); V3D_KR(ka[1], 1, KB); V3D_KR(ka[2], 2, KB); V3D_KR(ka[3], 3, KB);
+      V3D_KR(kc[0], 4, KB);
+      V3D_KR(kc[2], 0, KB + 8192); V3D_KR(kc[3], 1, KB + 8192);
+    };
+    auto qk_run = [&](auto kb_c, f32x16 (&s)[2]) {
+      constexpr int KB = decltype(kb_c)::value * 2 * AT_TILE;
+      auto& ka = ka_; auto& kc = kc_; const unsigned kaddr0 = kaddr0_;
+      const float init = -m_run;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = init;
+      V3D_KW(3, ka); V3D_KM(ka, 0, 0, 0); V3D_KM(ka, 1, 0, 1); V3D_KM(ka, 2, 0, 2); V3D_KM(ka, 3, 0, 3);
+      V3D_KR(ka[0], 2, KB + 8192); V3D_KR(ka[1], 3, KB + 8192); V3D_KR(ka[2], 4, KB + 8192);
+      V3D_KW(3, kc); V3D_KM(kc, 0, 0, 4); V3D_KM(kc, 2, 1, 0); V3D_KM(kc, 3, 1, 1);
+      V3D_KW(0, ka); V3D_KM(ka, 0, 1, 2); V3D_KM(ka, 1, 1, 3); V3D_KM(ka, 2, 1, 4);
+    };
+    auto mask_scores = [&](f32x16 (&s)[2], int t) {
+      const int kv0 = t * AT_BKV;
+      if (kv0 + AT_BKV > p.Sk) {
+        const int limit = p.Sk - 1 - kv0 - 4 * h;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            s[kt][r] = (kt * 32 + (r & 3) + 8 * (r >> 2)) > limit ? -INFINITY : s[kt][r];
+      }
+    };
+    auto raise_max = [&](f32x16 (&s)[2], int t) -> float {
+      float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+      const float mp = fmaxf(mx, __shfl_xor(mx, 32));
+      float d = t == 0 ? mp : (mp > AT_RAISE ? mp : 0.f);
+      d = mp == -INFINITY ? 0.f : d;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] -= d;
+      m_run += d;
+      return t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+    };
+    auto softmax_quarter = [&](const f32x16 (&s)[2], int i, Frag16& pf, float& ls0, float& ls1) {
+      float e[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(s[i >> 1][8 * (i & 1) + j]);
+      ls0 += (e[0] + e[1]) + (e[2] + e[3]);
+      ls1 += (e[4] + e[5]) + (e[6] + e[7]);
+      pf.u = make_uint4(pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3]), pack2<T>(e[4], e[5]), pack2<T>(e[6], e[7]));
+    };
+
+    // one pipeline step of attn_prefill_kernel (non-causal: every wave computes every tile); LAST = the item's final step, which
+    // stages the next item's first tiles and loads its Q instead of this item's (there are none left)
+    auto step = [&](auto par_c, auto full_c, auto last_c, int t, Frag16 (&pc)[4], Frag16 (&pn)[4]) {
+      constexpr int PAR = decltype(par_c)::value;
+      constexpr bool FULL = decltype(full_c)::value != 0;
+      constexpr bool LAST = decltype(last_c)::value != 0;
+      constexpr int VB = PAR * 2 * AT_TILE;
+      const unsigned vaddr0 = vaddr0_, vaddr1 = vaddr1_;
+      const bool do_qk = FULL || t + 1 < n_tiles;
+      f32x16 s[2];
+      if (do_qk) qk_fill(IntC<1 - PAR>{});
+      if constexpr (FULL) {
+        stage_k_fast(PAR, t + 2);
+        stage_v_fast(1 - PAR, t + 1);
+      } else if constexpr (LAST) {
+        if (has_next) {          // PAR = 1 here (even tile count): K[0], K[1] and V[0] are free; V[1] is this step's
+          const uint16_t *Qn, *Kn, *Vn;      // (formed here, not carried through the item: they would live in 6 scalar pairs for 12 steps)
+          int q0n, headn, bn;
+          item_ptrs(Ln, Qn, Kn, Vn, q0n, headn, bn);
+          // (tiles 0 and 1 are whole: the launcher asks for two full key tiles)
+          stage_fast(Kn, ldk_b, koff, lds_wave0, 0);
+          stage_fast(Vn, ldv_b, voff, lds_wave0 + AT_TILE, 0);
+          stage_fast(Kn, ldk_b, koff, lds_wave0 + 2 * AT_TILE, 1);
+          load_q(Qn, q0n);       // the score phase of this item is over: its Q registers are free
+        }
+      } else {
+        if (t + 2 < n_tiles) stage_k(PAR, t + 2);
+        if (t + 1 < n_tiles) stage_v(1 - PAR, t + 1);
+      }
+      if (do_qk) qk_run(IntC<1 - PAR>{}, s);
+      v2i va[8], vc[8];
+      { V3D_VR(va, 0, VB) V3D_VR(vc, 1, VB) }
+      float ls0 = 0.f, ls1 = 0.f;
+      if (do_qk) mask_scores(s, t + 1);
+      auto mmav = [&](const v2i* f, int dt, int quarter) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const v4i vf = {f[2 * s4][0], f[2 * s4][1], f[2 * s4 + 1][0], f[2 * s4 + 1][1]};
+          o[dt] = M::run(__builtin_bit_cast(typename M::frag, vf), as_frag<T>(pc[s4]), o[dt]);
+        }
+        if (quarter >= 0 && do_qk) {
+          softmax_quarter(s, quarter, pn[quarter], ls0, ls1);
+          asm volatile("" : "+v"(pn[quarter].i4), "+v"(ls0), "+v"(ls1));
+        }
+      };
+      V3D_VW(8, va); mmav(va, 0, 0); V3D_VR(va, 2, VB)
+      V3D_VW(8, vc); mmav(vc, 1, 1);
+      V3D_VW(0, va); mmav(va, 2, 2);
+      if (do_qk) softmax_quarter(s, 3, pn[3], ls0, ls1);
+      if (do_qk) {
+        if (__any(ls0 + ls1 > AT_LS_LIMIT)) {
+          asm volatile("; V3D_RARE_BEGIN (tests/test_kernel_resources.py: register spills are tolerated only between these markers)");
+          f32x16 s2[2];
+          qk_fill(IntC<1 - PAR>{});
+          qk_run(IntC<1 - PAR>{}, s2);
+          mask_scores(s2, t + 1);
+          const float alpha = raise_max(s2, t + 1);
+          if (__any(alpha != 1.0f)) {
+            ls0 = 0.f; ls1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) softmax_quarter(s2, i, pn[i], ls0, ls1);
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            l_run *= alpha;
+          }
+          asm volatile("; V3D_RARE_END");
+        }
+        l_run += ls0 + ls1;
+      }
+      if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the last step's DMAs are the NEXT item's: waited for in its prologue)
+      __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue: tiles 0 (K, V) and 1 (K) staged (by the previous item's last step, or here), S' and P of tile 0 ----
+    if (!prefetched) {
+      stage_k(0, 0);
+      stage_v(0, 0);
+      if (n_tiles > 1) stage_k(1, 1);
+      load_q(Q, q0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    pack_q();
+    Frag16 pa[4], pb[4];
+    {
+      f32x16 s[2];
+      float ls0 = 0.f, ls1 = 0.f;
+      qk_fill(IntC<0>{});
+      qk_run(IntC<0>{}, s);
+      __builtin_amdgcn_s_barrier();      // every wave has read K of tile 0 before step 0 restages its buffer (tile 2)
+      mask_scores(s, 0);
+      raise_max(s, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) softmax_quarter(s, i, pa[i], ls0, ls1);
+      l_run = ls0 + ls1;
+    }
+    {
+      int n_full = n_tiles - 2;
+      n_full = (n_full < p.Sk / AT_BKV - 2 ? n_full : p.Sk / AT_BKV - 2) & ~1;
+      n_full = __builtin_amdgcn_readfirstlane(n_full < 0 ? 0 : n_full);
+      int t = 0;
+      for (; t < n_full; t += 2) {
+        step(IntC<0>{}, IntC<1>{}, IntC<0>{}, t, pa, pb);
+        step(IntC<1>{}, IntC<1>{}, IntC<0>{}, t + 1, pb, pa);
+      }
+      for (; t + 2 < n_tiles; t += 2) {
+        step(IntC<0>{}, IntC<0>{}, IntC<0>{}, t, pa, pb);
+        step(IntC<1>{}, IntC<0>{}, IntC<0>{}, t + 1, pb, pa);
+      }
+      step(IntC<0>{}, IntC<0>{}, IntC<0>{}, t, pa, pb);               // t = n_tiles - 2
+      step(IntC<1>{}, IntC<0>{}, IntC<1>{}, t + 1, pb, pa);           // the item's last step: P.V only + the next item's staging
+    }
+    prefetched = has_next;
+
+    // ---- normalise, transpose through the (now free) V[1] buffer 16 query rows per wave at a time, store whole rows ----
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    constexpr int OROW = D * 2 + 16;                                  // 208 B
+    char* so = smem + 3 * AT_TILE + wave * 16 * 256;                  // 4 KiB per wave (16 rows x 208 B = 3.3 KiB)
+    uint16_t* O = (uint16_t*)p.o + b * p.bso + (int64_t)head * p.hso;
+    constexpr int OCH = D / 8;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if ((ql >> 4) == half) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = 32 * dt + 8 * r4 + 4 * h;
+            uint2 pk;
+            pk.x = pack2<T>(o[dt][4 * r4 + 0] * inv, o[dt][4 * r4 + 1] * inv);
+            pk.y = pack2<T>(o[dt][4 * r4 + 2] * inv, o[dt][4 * r4 + 3] * inv);
+            *reinterpret_cast<uint2*>(so + (ql & 15) * OROW + d * 2) = pk;
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < (16 * OCH + 63) / 64; ++i) {
+        const int idx = i * 64 + lane;
+        const int row = idx / OCH, ch = idx - row * OCH;
+        const int q = q0 + wave * 32 + 16 * half + row;
+        if (row < 16 && q < p.Sq && ch * 8 < p.d_out)
+          *reinterpret_cast<uint4*>(O + (int64_t)q * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(so + row * OROW + ch * 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the reads are done before the second half overwrites the rows
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#undef V3D_KR
+#undef V3D_KW
+#undef V3D_KM
+#undef V3D_VR
+#undef V3D_VW
+}
+
+// ------------------------------------------------------------------------------------------
 // r04: attn_prefill_kernel<128> on v_mfma_f32_16x16x32 - the A/B MI355X_MICROARCH.md asks for ('DVFS give-back' item 7, rule 28: the
 // chip may hold a higher clock on one bf16 MFMA shape than on the other, so build both at the same per-wave tile and keep the faster
 // by wall on random data).  Same workgroup (4 waves x 32 queries), same 64-key tiles, same LDS image / staging / swizzle, same
@@ -2115,6 +2474,28 @@ static int launch_attn(const AttnArgs& p, int D, int causal, int B, hipStream_t 
       done = true;                                                                                                \
     }                                                                                                             \
     hipLaunchKernelGGL(k, grid, block, AT_LDS, st, pm);                                                           \
+  }
+  if (D == 96 && !causal && p.d_out <= 80 && !p.lse && !getenv("V3D_ATTN_KS6")) {
+    // SigLIP: V3D_ATTN_VIT_PERSIST=1 opts in to the persistent form (bit-identical).  Default: one workgroup per item, the r03 kernel -
+    // measured equal within the boxes' spread (136 vs 131-140 us per layer, profiles/r04_vit_attention.txt): the seam was not the cost.
+    const char* e = getenv("V3D_ATTN_VIT_PERSIST");
+    const int n_tiles = (p.Sk + AT_BKV - 1) / AT_BKV;
+    if (e && atoi(e) != 0 && n_tiles >= 2 && n_tiles % 2 == 0 && p.Sk / AT_BKV >= 2) {
+      const int n_items = p.Hq * B * pm.n_qt;
+      int cus = 256;
+      { static int cached = 0; if (!cached) { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cached = prop.multiProcessorCount; if (cached <= 0) cached = 256; } cus = cached; }
+      int nwg = 2 * cus;
+      if (nwg > n_items) nwg = n_items;
+      auto k = attn_vit_persistent_kernel<T>;
+      static bool done = false;
+      if (!done) {
+        hipError_t e2 = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);
+        if (e2 != hipSuccess) { set_error("v3d_attention: LDS attribute: %s", hipGetErrorString(e2)); return V3D_E_LAUNCH; }
+        done = true;
+      }
+      hipLaunchKernelGGL(k, dim3(nwg), dim3(256), AT_LDS, st, pm, n_items);
+      return check_launch("v3d_attention (SigLIP, persistent)");
+    }
   }
   if (p.lse && D != 128) { set_error("v3d_attention_train: head dim 128 only (zero-pad narrower heads)"); return V3D_E_UNSUPPORTED; }
   if (D == 128 && causal && p.lse) V3D_ATTN(128, true, 8, true)
