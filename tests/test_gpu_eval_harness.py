@@ -146,6 +146,11 @@ def test_runners_for_the_other_3d_drivers(tmp_path):
     assert E3.main(_argv(root, ckpt, "questions.json", "sqa.jsonl", "--task", "sqa3d", "--loader-workers", "-1")) == 0
     sqa = [json.loads(l) for l in open(os.path.join(root, "out", "sqa.jsonl"))]
     assert [r["sample_id"] for r in sqa] == [q["id"] for q in qs] and all(len(r) == 7 for r in sqa)
+    # (r04) ... and with scene reuse on the pipeline, through eval_3d's own entry point: the synchronous scene-reuse records
+    assert E3.main(_argv(root, ckpt, "questions.json", "sqa_reuse.jsonl", "--task", "sqa3d", "--reuse-scenes", "--loader-workers", "2")) == 0
+    assert E3.main(_argv(root, ckpt, "questions.json", "sqa_reuse_sync.jsonl", "--task", "sqa3d", "--reuse-scenes", "--no-pipeline")) == 0
+    assert [json.loads(l) for l in open(os.path.join(root, "out", "sqa_reuse.jsonl"))] == \
+        [json.loads(l) for l in open(os.path.join(root, "out", "sqa_reuse_sync.jsonl"))]
     # ---- ScanRefer / Multi3DRefer
     refs = [dict(q, id=f"r{i}", box=[0.1 * i, 0.2, 0.3, 1, 1, 1],
                  conversations=[q["conversations"][0], {"from": "gpt", "value": "t318"}]) for i, q in enumerate(qs[:4])]

@@ -26,11 +26,12 @@ wgu = torch.randn(37888, 3584, device="cuda", dtype=dt) * 0.02
 qkv_out = torch.empty(S, 4608, device="cuda", dtype=dt)
 o_out = torch.empty(S, 3584, device="cuda", dtype=dt)
 act = torch.empty(S, 18944, device="cuda", dtype=dt)
-flops = 2.0 * S * S * D * H
+CAUSAL = os.environ.get("V3D_AB_CAUSAL", "1") != "0"          # 0: every key for every query (the kernels' steady state alone)
+flops = (2.0 if CAUSAL else 4.0) * S * S * D * H
 
 
 def attn():
-    return ops.attention_bshd(q, k, v, causal=True)
+    return ops.attention_bshd(q, k, v, causal=CAUSAL)
 
 
 def back_to_back(n=40):
@@ -63,18 +64,20 @@ def in_layer(n=28):
     return sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs)
 
 
+MODES = {"32": {"V3D_ATTN_MFMA": "32"}, "16": {"V3D_ATTN_MFMA": "16"}}
+SEL = os.environ.get("V3D_AB_MODES", "32,16").split(",")
 outs = {}
-for mode in ("32", "16"):
-    os.environ["V3D_ATTN_MFMA"] = mode
+for mode in SEL:
+    os.environ.update(MODES[mode])
     outs[mode] = attn().float()
 torch.cuda.synchronize()
-d = (outs["16"] - outs["32"]).abs()
-print(f"S={S}: max |out16 - out32| = {d.max().item():.3e} (mean {d.mean().item():.3e}; |v| ~ 1, bf16 ulp at 1 = 7.8e-3)", flush=True)
+d = (outs[SEL[-1]] - outs[SEL[0]]).abs()
+print(f"S={S}: max |out_{SEL[-1]} - out_{SEL[0]}| = {d.max().item():.3e} (mean {d.mean().item():.3e}; |v| ~ 1, bf16 ulp at 1 = 7.8e-3)", flush=True)
 for rep in range(3):
     row = []
-    for mode in ("32", "16"):
-        os.environ["V3D_ATTN_MFMA"] = mode
+    for mode in SEL:
+        os.environ.update(MODES[mode])
         a, b = back_to_back(), in_layer()
-        row.append(f"mfma{mode}: back-to-back {a:.1f} us = {flops / a / 1e6:.0f} TF/s = {flops / a / 1e6 / 2500:.3f} | in layer {b:.1f} us = "
+        row.append(f"{mode}: back-to-back {a:.1f} us = {flops / a / 1e6:.0f} TF/s = {flops / a / 1e6 / 2500:.3f} | in layer {b:.1f} us = "
                    f"{flops / b / 1e6:.0f} TF/s = {flops / b / 1e6 / 2500:.3f}")
     print(f"rep {rep}:  " + "   ||   ".join(row), flush=True)
