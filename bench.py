@@ -455,32 +455,9 @@ def measure_train_step(dev, steps=2, answer_tokens=64):
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start `torch.distributed.run` with N ranks of this very file as a
     CHILD process (never an exec, and before this process has made any GPU call), let rank 0's JSON line through and return the child's
-    exit code.  No retry: a failed child is a failed run."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")
-    print("bench.py: --gpus %d without RANK / WORLD_SIZE: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = []
-    for ln in proc.stdout:                                  # rank 0's one JSON line (anything else a rank printed goes to stderr)
-        if ln.lstrip().startswith("{"):
-            lines.append(ln.rstrip("\n"))
-        else:
-            sys.stderr.write(ln)
-    rc = proc.wait()
-    for ln in lines[-1:]:
-        print(ln, flush=True)
-    if rc == 0 and not lines:
-        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
-        return 1
-    return rc
+    exit code.  No retry: a failed child is a failed run.  (v3d.distributed.launch_ranks: the eval runners' --n_gpu uses the same.)"""
+    from v3d import distributed as v3dist
+    return v3dist.launch_ranks(n, argv, script=__file__, json_only=True)
 
 
 def dry_run(a, rank, world):

@@ -132,3 +132,48 @@ def test_bench_relays_a_failed_childs_exit_code():
     r = _run_bench("--gpus", "2", "--steps", "3", env_extra={"V3D_BENCH_DRY_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_launch_ranks_starts_a_script_and_a_module_and_returns_the_exit_code(tmp_path, capfd):
+    """v3d.distributed.launch_ranks - what `bench.py --gpus N` and the eval runners' `--n_gpu N` (the reference's flag, model_scanqa.py:222,
+    242-247) start their ranks with: N children under torch.distributed.run on 127.0.0.1, the package importable in them, stdout passed
+    through, the exit code returned, no retry."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-3d-llm_amd"))
+    from v3d import distributed as D
+    script = tmp_path / "rank_prog.py"
+    script.write_text(
+        "import os, sys\n"
+        "import v3d.distributed\n"                                           # the package root is on the ranks' PYTHONPATH
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "open(os.path.join(sys.argv[1], f'rank{r}of{w}'), 'w').write(os.environ['MASTER_ADDR'])\n"
+        "print('hello from', r, flush=True)\n"
+        "sys.exit(int(sys.argv[2]) if r == 1 else 0)\n")
+    env_before = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        assert D.launch_ranks(2, [str(tmp_path), "0"], script=str(script)) == 0
+        out = capfd.readouterr()
+        assert sorted(os.listdir(tmp_path)) == ["rank0of2", "rank1of2", "rank_prog.py"]
+        assert (tmp_path / "rank0of2").read_text() == "127.0.0.1" and "hello from 0" in out.out and "hello from 1" in out.out
+        assert D.launch_ranks(2, [str(tmp_path), "5"], script=str(script)) != 0          # rank 1 exits with 5: the run fails
+        # json_only (the bench): only result lines reach stdout
+        capfd.readouterr()
+        assert D.launch_ranks(2, [str(tmp_path), "0"], script=str(script), json_only=True) == 1      # clean exit but no result line
+        assert "hello" not in capfd.readouterr().out
+    finally:
+        for k, v in env_before.items():
+            if v is not None:
+                os.environ[k] = v
+
+
+def test_eval_runners_take_the_references_n_gpu_flag():
+    """`--n_gpu` parses in both runners, and a process that already is a rank never launches again."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-3d-llm_amd"))
+    from v3d import eval_scanqa as E
+    os.environ["RANK"] = "0"
+    try:
+        assert E.self_launch(4, "v3d.eval_scanqa", ["--x"]) is None
+    finally:
+        del os.environ["RANK"]
+    assert E.self_launch(1, "v3d.eval_scanqa", ["--x"]) is None and E.self_launch(None, "v3d.eval_scanqa", []) is None

@@ -173,3 +173,28 @@ def test_runners_for_the_other_3d_drivers(tmp_path):
         if best == 3:
             best = int(torch.argmax(scores[:-1]))
         assert r["pred_response"] == vd["objects"][0][best].tolist() and r["gt_response"] == line["box"]
+
+
+def test_eval_runner_with_n_gpu_2_on_one_card(tmp_path):
+    """`python -m v3d.eval_scanqa ... --n_gpu 2` started plainly, as the reference's driver is (model_scanqa.py:222, 242-247): the runner starts two
+    ranks itself; V3D_EVAL_REHEARSAL=1 puts both on cuda:0 over gloo.  Stride sharding (`questions[rank::2]`, :245) and, with --reuse-scenes, scene
+    sharding; ONE gather of the records to rank 0, which writes them in question order - the records of the one-process run, exactly
+    (one question at a time / whole scenes per rank: every question sees the same kernels on the same operands as there)."""
+    import subprocess
+    import sys
+    from v3d import eval_scanqa as E
+    root = str(tmp_path)
+    qs = _dataset(root)
+    ckpt = TM.write_checkpoint(os.path.join(root, "llava_qwen_tiny"), TM.load())
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "video-3d-llm_amd")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(V3D_EVAL_REHEARSAL="1", PYTHONPATH=pkg + os.pathsep + env.get("PYTHONPATH", ""))
+    for name, extra in (("stride", ["--no-pipeline"]), ("scene", ["--reuse-scenes", "--no-pipeline"])):
+        assert E.main(_argv(root, ckpt, "questions.json", f"one_{name}.jsonl", *extra)) == 0
+        out = subprocess.run([sys.executable, "-m", "v3d.eval_scanqa", *_argv(root, ckpt, "questions.json", f"two_{name}.jsonl", *extra), "--n_gpu", "2"],
+                             env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert "--nproc-per-node=2" in out.stderr
+        one = [json.loads(l) for l in open(os.path.join(root, "out", f"one_{name}.jsonl"))]
+        two = [json.loads(l) for l in open(os.path.join(root, "out", f"two_{name}.jsonl"))]
+        assert [r["sample_id"] for r in two] == [q["id"] for q in qs] and two == one

@@ -12,6 +12,47 @@ def shard(items, rank, world):
     return items[rank::world]
 
 
+def launch_ranks(n, argv, script=None, module=None, json_only=False):
+    """Start N ranks of `script` (a path) or `module` (python -m) on THIS node as a child `torch.distributed.run` and wait for them - what
+    the reference's drivers do themselves with `ray.init(); eval_model.remote(questions[i::n_gpu])` (model_scanqa.py:242-247).  Called by a
+    parent that has not touched the GPU (never an exec of a process that has; `import torch` does not initialise it); rendezvous on
+    127.0.0.1 and a free port; no retry - a failed child is a failed run and its exit code is returned.  json_only: let only lines that
+    start with "{" through on stdout (the bench's one result line), everything else goes to stderr."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    target = ["-m", module] if module else [os.path.abspath(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + target + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    pkg_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # so that `-m v3d....` resolves in the ranks
+    env["PYTHONPATH"] = pkg_root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    print("%d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for ln in proc.stdout:
+        if not json_only:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        elif ln.lstrip().startswith("{"):
+            lines.append(ln.rstrip("\n"))
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    if json_only and rc == 0 and not lines:
+        print("the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 1
+    return rc
+
+
 def gather_bytes(payload: bytes, device, dst=0):
     """Every rank contributes `payload`; rank `dst` gets the list of all payloads (others get None).
     Two collectives: all_gather of 8-byte lengths, then one gather of length-padded byte tensors."""

@@ -176,30 +176,34 @@ def main(argv=None, task=None):
     ap.add_argument("--decode-group", type=int, default=16)
     ap.add_argument("--loader-workers", type=int, default=0)
     ap.add_argument("--shard", choices=("stride", "scene"), default=None)
+    ap.add_argument("--n_gpu", type=int, default=None, help="the reference's flag: started plainly with N > 1, launch N ranks of this runner")
     a = ap.parse_args(argv)
+    fixed_task = task
     task = task or a.task
-    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
-    with open(os.path.expanduser(a.question_file)) as f:
-        questions = json.load(f)[: a.test_size]
     if os.path.exists(a.answer_file):
         print(f"The {a.answer_file} already exists!!!")
         return 0
+    import sys
+    child_argv = list(sys.argv[1:] if argv is None else argv)
+    if fixed_task is not None:                       # (the per-task entry points fix the task: their ranks run this module with --task)
+        child_argv = ["--task", fixed_task] + child_argv
+    rc = E.self_launch(a.n_gpu, "v3d.eval_3d", child_argv)
+    if rc is not None:
+        return rc
+    with open(os.path.expanduser(a.question_file)) as f:
+        questions = json.load(f)[: a.test_size]
     pool = None
     if a.loader_workers >= 0 and not (task in GEN_TASKS and a.no_pipeline):
         from . import frame_io
         pool = frame_io.make_pool(a.loader_workers or E.default_workers())          # forked before this process touches the GPU
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev, gather_dev = E.rank_setup(a.n_gpu)
     from llava.video_utils import VideoProcessor
     tokenizer, model, image_processor, name = E.load_model(os.path.expanduser(a.model_path), a.overwrite_cfg)
     vp = VideoProcessor(video_folder=a.video_folder, annotation_dir=a.embodiedscan_folder, frame_sampling_strategy=a.frame_sampling_strategy,
                         metadata_dir=a.metadata_folder)
     times = []
     fn = answer_fn_for(task, model, tokenizer, image_processor, vp, name, a, pool=pool, times=times)
-    records = E.evaluate(questions, fn, rank, world, dev, shard=a.shard or ("scene" if a.reuse_scenes else "stride"))
+    records = E.evaluate(questions, fn, rank, world, gather_dev, shard=a.shard or ("scene" if a.reuse_scenes else "stride"))
     if rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(a.answer_file)), exist_ok=True)
         with open(a.answer_file, "w") as f:
@@ -210,6 +214,7 @@ def main(argv=None, task=None):
     if pool is not None:
         pool.shutdown(wait=True, cancel_futures=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     return 0

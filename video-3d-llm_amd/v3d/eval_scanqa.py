@@ -121,6 +121,37 @@ def evaluate(questions, answer_fn, rank, world, device, shard="stride"):
     return D.gather_indexed(recs, idx, device)
 
 
+def self_launch(n_gpu, module, argv):
+    """`--n_gpu N` as the reference's drivers take it (model_scanqa.py:222, 242-247: `ray.init()` and one remote worker per GPU): started
+    plainly (no RANK / WORLD_SIZE in the environment) with N > 1, this process - which has not touched the GPU - starts N ranks of `module`
+    under torch.distributed.run and returns their exit code; returns None where there is nothing to launch (N <= 1, or already a rank)."""
+    if not n_gpu or n_gpu <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return None
+    import sys
+    return D.launch_ranks(n_gpu, list(sys.argv[1:] if argv is None else argv), module=module)
+
+
+def rank_setup(n_gpu=None):
+    """(rank, world, device, gather device) of this process and its process group.  V3D_EVAL_REHEARSAL=1: every rank on cuda:0 over gloo -
+    the N > 1 path (sharding, per-rank loaders, record gather) on a one-GPU box; records gathered through host memory."""
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+    if n_gpu and n_gpu > 1 and n_gpu != world:
+        raise SystemExit(f"--n_gpu {n_gpu} but the launcher's WORLD_SIZE is {world}")
+    rehearsal = os.environ.get("V3D_EVAL_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+        os.environ["V3D_GEMM_STREAMK"] = "0"          # ranks share one card: the GEMM's split-K tail assumes one tail launch on the chip
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return rank, world, dev, (torch.device("cpu") if rehearsal else dev)
+
+
 def default_workers():
     """Loader processes per rank: the host cores this process may run on, divided among the ranks of the node, at most 16 (one
     question's 32 frames cost about half a core-second to decode; a GPU answers ten questions a second)."""
@@ -339,22 +370,22 @@ def main(argv=None):
                     help="host processes decoding frames ahead of the GPU (0: cores / ranks, at most 16; -1: none, decode on the main thread)")
     ap.add_argument("--shard", choices=("stride", "scene"), default=None,
                     help="stride: questions[rank::world] (the reference); scene: whole scenes per rank (default with --reuse-scenes)")
+    ap.add_argument("--n_gpu", type=int, default=None,
+                    help="the reference's flag (model_scanqa.py:222): started plainly with N > 1, launch N ranks of this runner on this node")
     a = ap.parse_args(argv)
-    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
-    with open(os.path.expanduser(a.question_file)) as f:
-        questions = json.load(f)[: a.test_size]
     if os.path.exists(a.answer_file):                                                         # model_scanqa.py:238-240
         print(f"The {a.answer_file} already exists!!!")
         return 0
+    rc = self_launch(a.n_gpu, "v3d.eval_scanqa", argv)
+    if rc is not None:
+        return rc
+    with open(os.path.expanduser(a.question_file)) as f:
+        questions = json.load(f)[: a.test_size]
     pool = None
     if not a.no_pipeline and a.loader_workers >= 0:
         from . import frame_io
         pool = frame_io.make_pool(a.loader_workers or default_workers())        # forked before this process touches the GPU
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev, gather_dev = rank_setup(a.n_gpu)
     from llava.video_utils import VideoProcessor
     tokenizer, model, image_processor, name = load_model(os.path.expanduser(a.model_path), a.overwrite_cfg)
     vp = VideoProcessor(video_folder=a.video_folder, annotation_dir=a.embodiedscan_folder, frame_sampling_strategy=a.frame_sampling_strategy,
@@ -362,7 +393,7 @@ def main(argv=None):
     times = []
     fn = model_answer_fn(model, tokenizer, image_processor, vp, name, a.max_frame_num, a.max_new_tokens, a.reuse_scenes, times,
                          pipeline=not a.no_pipeline, group_size=a.decode_group, workers=(0 if a.loader_workers < 0 else a.loader_workers or None), pool=pool)
-    records = evaluate(questions, fn, rank, world, dev, shard=a.shard or ("scene" if a.reuse_scenes else "stride"))
+    records = evaluate(questions, fn, rank, world, gather_dev, shard=a.shard or ("scene" if a.reuse_scenes else "stride"))
     if rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(a.answer_file)), exist_ok=True)
         with open(a.answer_file, "w") as f:
@@ -373,6 +404,7 @@ def main(argv=None):
     if pool is not None:
         pool.shutdown(wait=True, cancel_futures=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
     return 0
