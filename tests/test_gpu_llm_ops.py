@@ -586,6 +586,40 @@ def test_linear_decode_rows(ops, M, K, N):
             assert bool((err <= 2.0 ** -6 * want.abs() + 2.0 ** -6 * want.pow(2).mean().sqrt()).all())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [2, 16, 17, 32])
+@pytest.mark.parametrize("K,N", [(1152, 256), (2048, 4608), (3584, 512), (3584, 8192), (4096, 384), (1024, 128), (4224, 256), (18944, 256)])
+def test_linear_decode_rows_pipelined_forms_equal_the_r04_kernel_bitwise(ops, monkeypatch, dt, M, K, N):
+    """r04, second session: linear_decode_mfma2_kernel (persistent workgroups, activation fragments resident in registers, weight tiles
+    double-buffered in registers; 9..32 K tiles) and linear_decode_mfma_stream_kernel (any K) sum an output exactly as
+    linear_decode_mfma_kernel does - slice w of K = tiles w, w + 8, ... in ascending order, the eight slices added in order - so every bit
+    agrees.  V3D_DEC_V2 = 0: the r04 kernel; 2: the pipelined forms wherever the shape allows (grids below, at and above the chip's CU count,
+    3 and 4 tiles per wave, waves with one tile fewer than their neighbours, an odd and an even number of groups per workgroup)."""
+    g = torch.Generator().manual_seed(7 * M + K % 97)
+    x = torch.randn(M, K, generator=g).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    r = torch.randn(M, N, generator=g).to(dt).cuda()
+    cases = [dict(), dict(bias=b, epilogue=ops.DEC_BIAS), dict(res=r, epilogue=ops.DEC_RES)]
+    if N % 128 == 0:
+        cases.append(dict(epilogue=ops.DEC_SWIGLU))
+    for kw in cases:
+        n_out = N // 2 if kw.get("epilogue") == ops.DEC_SWIGLU else N
+        outs = []
+        for mode in ("0", "2"):
+            monkeypatch.setenv("V3D_DEC_V2", mode)
+            o = torch.full((M, n_out), 5.0, dtype=dt, device="cuda")
+            ops.linear_decode_rows(x, w, o, **kw)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]), (kw.get("epilogue"), M, K, N)
+    monkeypatch.setenv("V3D_DEC_V2", "2")                   # rows do not depend on their neighbours or on M (the resident fragments of absent rows are zero)
+    o_all = torch.empty((M, N), dtype=dt, device="cuda")
+    ops.linear_decode_rows(x, w, o_all)
+    o_two = torch.empty((2, N), dtype=dt, device="cuda")
+    ops.linear_decode_rows(x[M - 2:], w, o_two)
+    assert torch.equal(o_two, o_all[M - 2:])
+
+
 def test_rope_kv_append_and_argmax(ops):
     dt = torch.bfloat16
     H, KV, D = 4, 2, 128

@@ -18,8 +18,10 @@ def tm(name, N, K, epi, M, iters=40):
     for i in range(iters): f(ws[i % 4])
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    print(f"OG={os.environ.get('V3D_DEC_OG', '2')} {name:8s} M={M:2d} N={N:6d} K={K:6d} {us:8.1f} us  {N*K*2/us/1e6:6.2f} TB/s", flush=True)
+    print(f"V2={os.environ.get('V3D_DEC_V2', '1')} OG={os.environ.get('V3D_DEC_OG', '2')} {name:8s} M={M:2d} N={N:6d} K={K:6d} {us:8.1f} us  {N*K*2/us/1e6:6.2f} TB/s", flush=True)
 for M in (16, 32):
+  for v2 in os.environ.get("V3D_DEC_V2_LIST", os.environ.get("V3D_DEC_V2", "1")).split(","):
+    os.environ["V3D_DEC_V2"] = v2                           # read per call by the library
     tm("qkv", 4608, 3584, 1, M)
     tm("o_proj", 3584, 3584, 2, M)
     tm("gate_up", 37888, 3584, 3, M)

@@ -297,6 +297,288 @@ __global__ __launch_bounds__(512) void linear_decode_mfma_kernel(const T* __rest
   }
 }
 
+// ---- r04 (second session): the matrix-core decode linear as a PIPELINED stream ----------------------------------------------------
+// linear_decode_mfma_kernel above loads a wave's K tile, waits for it, parks it, multiplies, and only then asks for the next one: with
+// one workgroup per CU (139 KB of parking tiles at 32 outputs) the CU's memory queue runs empty once per tile, and gate/up at 32 rows
+// streams 4.4 TB/s where the one-row kernel reaches 6.5.  Two kernels replace it where they are faster (same arithmetic: slice w of K =
+// the tiles s = w (mod 8) summed in ascending order, the eight slices added in order 0..7, so every output bit equals the kernel above):
+//  * linear_decode_mfma2_kernel (K <= 4096): PERSISTENT workgroups walk 16-output groups; a wave's activation fragments - they depend on
+//    its K slice only, not on the group - are loaded ONCE and stay in registers (no activation traffic in the loop at all: the r04 form
+//    pulled M : 16 OG activation bytes per weight byte out of L2); its weight tiles run through two register buffers, tile j + 2 being
+//    requested as soon as tile j has been parked in LDS, across group boundaries; one barrier per group (the partial sums meet in a
+//    double-buffered LDS region); bias / residual values are requested at the start of a group so that the epilogue's wait is a counted
+//    one and never drains the weight stream.
+//  * linear_decode_mfma_stream_kernel (any K, here down_proj's 18944): one group per workgroup as before, weights AND activations of tile
+//    j + 2 requested while tile j is multiplied.
+// Buffer roles are static in both (two groups / two tiles per loop trip): hipcc's vmcnt bookkeeping merges the states of joining paths,
+// and a run-time buffer choice made every wait a full drain.
+// A tile's life: landed in registers -> parked in the wave's LDS tile (dec2_park) -> the registers are free, the tile after next is
+// requested into them AT ONCE -> fragments read back and multiplied (dec2_mult).  __builtin_amdgcn_sched_barrier pins the requests there:
+// left alone, hipcc's scheduler sank them to their first use, one tile later (load, vmcnt(0), ds_write, load, vmcnt(0), ...).
+__device__ __forceinline__ void dec2_park(const uint4 (&wr)[4], char* tl, int lr, int lc) {
+  constexpr int PITCH = 272;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(tl + (4 * j + lr) * PITCH + lc * 16) = wr[j];
+}
+template <typename T, int MB>
+__device__ __forceinline__ void dec2_mult(const char* tl, int r, int g, const uint4 (&xx)[MB][4], dec_f32x4 (&acc)[MB]) {
+  constexpr int PITCH = 272;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const uint4 a = *reinterpret_cast<const uint4*>(tl + r * PITCH + (4 * t + g) * 16);
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[b] = dec_mfma(T{}, a, xx[b][t], acc[b]);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ int dec2_row0(int grp) {                      // first weight row of 16-output group grp (SWIGLU: its gate rows)
+  const int o = 16 * grp;
+  return EPI == DEC_EPI_SWIGLU ? (o >> 6) * 128 + (o & 63) : o;
+}
+
+// NW = K tiles of THIS wave (the workgroup's waves hold NT or NT - 1: two instantiations of the loop, chosen once per wave)
+template <typename T, int EPI, int MB, int NW>
+__device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W, int64_t ldw,
+                                         const T* __restrict__ bias, const T* __restrict__ res, int64_t ldr, T* __restrict__ out,
+                                         int64_t ldo, int groups, char* smem_) {
+  constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;
+  constexpr int PITCH = 272, TILE_B = 8 * SW * 16 * PITCH, PART_F = 8 * SW * MB * 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4, lr = lane >> 4, lc = lane & 15;
+  auto tile = [&](int q) -> char* { return smem_ + (size_t)(wave * SW + q) * 16 * PITCH; };
+  auto part = [&](int pb, int w, int q, int b_) -> float* {
+    return reinterpret_cast<float*>(smem_ + TILE_B) + (size_t)pb * PART_F + (size_t)((w * SW + q) * MB + b_) * 256;
+  };
+  // resident activation fragments of this wave's K slice
+  uint4 xb[NW][MB][4];
+#pragma unroll
+  for (int u = 0; u < NW; ++u)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      const bool ok = r + 16 * b < M;
+      const T* xr = x + (int64_t)(ok ? r + 16 * b : 0) * ldx + 8 * g + 128 * (wave + 8 * u);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xb[u][b][t] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) xb[u][b][t] = *reinterpret_cast<const uint4*>(xr + 32 * t);
+      }
+    }
+  const int my_groups = (groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const T* wlane = W + (int64_t)lr * ldw + 8 * lc + 128 * wave;
+  int ig = 0, iu = 0;                                                    // issue cursor: (group of this workgroup, tile of this wave)
+  // (unconditional: past the last group the cursor re-reads the last group's tiles into a buffer nobody multiplies - a branch around
+  //  the loads would join a path WITH and a path WITHOUT them, and hipcc then waits for everything at the next use)
+  // A buffer is ONE 16-row tile (4 x 16 B per lane): with gate and up rows (SW = 2) the stream alternates gate tile / up tile, so the two
+  // buffers hold 32 registers, not 64 (beside 128 of resident activations at 32 rows the larger form spilled).
+  int iq = 0;
+  auto issue = [&](uint4 (&wr)[4]) {
+    const int igc = ig < my_groups ? ig : my_groups - 1;
+    const T* base = wlane + (int64_t)(dec2_row0<EPI>((int)blockIdx.x + igc * (int)gridDim.x) + 64 * iq) * ldw + 1024 * iu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[j] = ldg_nt(reinterpret_cast<const uint4*>(base + (int64_t)(4 * j) * ldw));
+    if (++iq == SW) { iq = 0; if (++iu == NW) { iu = 0; ++ig; } }
+  };
+  dec_f32x4 acc[SW][MB];
+#pragma unroll
+  for (int q = 0; q < SW; ++q)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[q][b] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+  // epilogue element of this thread (MB = 1: threads 0..255 only): block b, row / column of the 16 x 16 tile
+  const bool epi_on = tid < 256 * MB;
+  const int eb = tid >> 8, t8 = tid & 255, el = t8 >> 2, ei = t8 & 3;
+  const int erow = 4 * (el >> 4) + ei, em = (el & 15) + 16 * eb;
+  auto group_end = [&](int pb, int gi, float side) {
+#pragma unroll
+    for (int q = 0; q < SW; ++q)
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        *reinterpret_cast<float4*>(part(pb, wave, q, b) + lane * 4) = make_float4(acc[q][b][0], acc[q][b][1], acc[q][b][2], acc[q][b][3]);
+        acc[q][b] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    // LDS-only rendezvous: __syncthreads() is a workgroup-scope fence, i.e. s_waitcnt vmcnt(0) - it drained the weight stream every group
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (epi_on) {
+      float v[SW];
+#pragma unroll
+      for (int q = 0; q < SW; ++q) {
+        v[q] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v[q] += part(pb, w, q, eb)[t8];
+      }
+      if (em < M) {
+        const int n = 16 * ((int)blockIdx.x + gi * (int)gridDim.x) + erow;
+        if (EPI == DEC_EPI_SWIGLU) {
+          const float gt = round_to<T>(v[0]), up = round_to<T>(v[SW - 1]);
+          out[em * ldo + n] = from_f32<T>(round_to<T>(silu_f(gt)) * up);
+        } else {
+          float y = v[0];
+          if (EPI == DEC_EPI_BIAS) y += side;
+          y = round_to<T>(y);                               // the linear's own output rounding
+          if (EPI == DEC_EPI_RES) y += side;
+          out[em * ldo + n] = from_f32<T>(y);
+        }
+      }
+    }
+  };
+  auto side_load = [&](int gi) -> float {                  // requested a whole group ahead of its use; unconditional (rows beyond M read row 0)
+    const int n = 16 * ((int)blockIdx.x + gi * (int)gridDim.x) + erow;
+    if (EPI == DEC_EPI_BIAS) return to_f32(bias[n]);
+    if (EPI == DEC_EPI_RES) return to_f32(res[(int64_t)(em < M ? em : 0) * ldr + n]);
+    return 0.f;
+  };
+  uint4 wa[4], wb[4];
+  issue(wa);
+  issue(wb);
+  auto one_group = [&](int h, int gi) {                     // h = parity of the group within its pair: buffer roles and LDS half are static
+    const float side = side_load(gi);
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+#pragma unroll
+      for (int q = 0; q < SW; ++q) {
+        if ((((h * NW + u) * SW + q) & 1) == 0) {
+          dec2_park(wa, tile(q), lr, lc);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(wa);
+        } else {
+          dec2_park(wb, tile(q), lr, lc);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dec2_mult<T, MB>(tile(q), r, g, xb[u], acc[q]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    group_end(h, gi, side);
+  };
+  int gi = 0;
+  for (; gi + 1 < my_groups; gi += 2) {                     // whole pairs: no branch inside (see issue)
+    one_group(0, gi);
+    one_group(1, gi + 1);
+  }
+  if (gi < my_groups) one_group(0, gi);
+}
+
+template <typename T, int EPI, int MB, int NT>
+__global__ __launch_bounds__(512) void linear_decode_mfma2_kernel(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W,
+                                                                  int64_t ldw, const T* __restrict__ bias, const T* __restrict__ res,
+                                                                  int64_t ldr, T* __restrict__ out, int64_t ldo, int K, int groups) {
+  constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char smem_[8 * SW * 16 * 272 + 2 * 8 * SW * MB * 256 * 4];
+  const int wave = threadIdx.x >> 6;
+  const int nt_w = (K / 128 - wave + 7) / 8;               // NT or NT - 1 (host: 8 (NT - 1) < tiles <= 8 NT)
+  if (nt_w == NT) dec2_run<T, EPI, MB, NT>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_);
+  else dec2_run<T, EPI, MB, (NT > 1 ? NT - 1 : 1)>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_);
+}
+
+// any K: one 16-output group per workgroup, weights and activations of tile j + 2 in flight while tile j is multiplied
+template <typename T, int EPI, int MB>
+__global__ __launch_bounds__(512) void linear_decode_mfma_stream_kernel(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W,
+                                                                        int64_t ldw, const T* __restrict__ bias, const T* __restrict__ res,
+                                                                        int64_t ldr, T* __restrict__ out, int64_t ldo, int K) {
+  constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;
+  constexpr int PITCH = 272, TILE_B = 8 * SW * 16 * PITCH, PART_B = 8 * SW * MB * 256 * 4;
+  __shared__ __attribute__((aligned(16))) char smem_[TILE_B > PART_B ? TILE_B : PART_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4, lr = lane >> 4, lc = lane & 15;
+  auto tile = [&](int q) -> char* { return smem_ + (size_t)(wave * SW + q) * 16 * PITCH; };
+  auto part = [&](int w, int q, int b_) -> float* { return reinterpret_cast<float*>(smem_) + (size_t)((w * SW + q) * MB + b_) * 256; };
+  const int tiles = K / 128;
+  const int nt_w = tiles > wave ? (tiles - wave + 7) / 8 : 0;
+  const T* wlane = W + (int64_t)(dec2_row0<EPI>((int)blockIdx.x) + lr) * ldw + 8 * lc + 128 * wave;
+  const T* xlane[MB];
+  bool col_ok[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    col_ok[b] = r + 16 * b < M;
+    xlane[b] = x + (int64_t)(col_ok[b] ? r + 16 * b : 0) * ldx + 8 * g + 128 * wave;
+  }
+  dec_f32x4 acc[SW][MB];
+#pragma unroll
+  for (int q = 0; q < SW; ++q)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) acc[q][b] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+  // unconditional (see linear_decode_mfma2_kernel): past the end, the last tile again
+  auto issue_w = [&](uint4 (&wr)[SW][4], int u_) {
+    const int u = u_ < nt_w ? u_ : nt_w - 1;
+#pragma unroll
+    for (int q = 0; q < SW; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wr[q][j] = ldg_nt(reinterpret_cast<const uint4*>(wlane + (int64_t)(64 * q + 4 * j) * ldw + 1024 * u));
+  };
+  auto issue_x = [&](uint4 (&xr)[MB][4], int u_) {
+    const int u = u_ < nt_w ? u_ : nt_w - 1;
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xr[b][t] = *reinterpret_cast<const uint4*>(xlane[b] + 1024 * u + 32 * t);   // absent rows: row 0, zeroed at use
+  };
+  auto step = [&](uint4 (&wr)[SW][4], uint4 (&xr)[MB][4], int u_next) {   // one tile: park, re-request the weights, multiply, re-request the rows
+#pragma unroll
+    for (int q = 0; q < SW; ++q) dec2_park(wr[q], tile(q), lr, lc);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_w(wr, u_next);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      if (!col_ok[b]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xr[b][t] = make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+    for (int q = 0; q < SW; ++q) dec2_mult<T, MB>(tile(q), r, g, xr, acc[q]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_x(xr, u_next);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const bool epi_on = tid < 256 * MB;
+  const int eb = tid >> 8, t8 = tid & 255, el = t8 >> 2, ei = t8 & 3;
+  const int erow = 4 * (el >> 4) + ei, em = (el & 15) + 16 * eb;
+  const int n = 16 * (int)blockIdx.x + erow;
+  uint4 wa[SW][4], wb[SW][4], xa[MB][4], xb[MB][4];
+  issue_w(wa, 0); issue_x(xa, 0);
+  issue_w(wb, 1); issue_x(xb, 1);
+  float side = 0.f;                                         // older than every later tile request: its wait is a counted one
+  if (epi_on && em < M) {
+    if (EPI == DEC_EPI_BIAS) side = to_f32(bias[n]);
+    if (EPI == DEC_EPI_RES) side = to_f32(res[em * ldr + n]);
+  }
+  int u = 0;
+  for (; u + 1 < nt_w; u += 2) {                            // whole pairs: no branch inside
+    step(wa, xa, u + 2);
+    step(wb, xb, u + 3);
+  }
+  if (u < nt_w) step(wa, xa, u);
+  __syncthreads();                                          // the partial sums reuse the tiles' LDS
+#pragma unroll
+  for (int q = 0; q < SW; ++q)
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+      *reinterpret_cast<float4*>(part(wave, q, b) + lane * 4) = make_float4(acc[q][b][0], acc[q][b][1], acc[q][b][2], acc[q][b][3]);
+  __syncthreads();
+  if (epi_on) {
+    float v[SW];
+#pragma unroll
+    for (int q = 0; q < SW; ++q) {
+      v[q] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v[q] += part(w, q, eb)[t8];
+    }
+    if (em < M) {
+      if (EPI == DEC_EPI_SWIGLU) {
+        const float gt = round_to<T>(v[0]), up = round_to<T>(v[SW - 1]);
+        out[em * ldo + n] = from_f32<T>(round_to<T>(silu_f(gt)) * up);
+      } else {
+        float y = v[0];
+        if (EPI == DEC_EPI_BIAS) y += side;
+        y = round_to<T>(y);
+        if (EPI == DEC_EPI_RES) y += side;
+        out[em * ldo + n] = from_f32<T>(y);
+      }
+    }
+  }
+}
+
 // The same weight-streaming linear over OCP e4m3 weights (BASELINE configs[3]): W8 [N, K] bytes with one f32 scale per
 // output row (v3d_quantize_fp8_rows), activations stay 16-bit (W8A16): y[n] = sw[n] * sum_k q[n,k] x[k].  Half the
 // bytes of the 16-bit kernel per step; a 16-byte chunk is 16 weights (two x vectors).  No fused norm (callers
@@ -510,6 +792,55 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
     //   LM head  152064 x 3584: 228 -> 188 / 330 -> 260      gate/up 37888 x 3584: 56 -> 60 / 70.5 -> 62      qkv 4608 x 3584: 14.0 -> 11.4 / 20.3 -> 15.4
     //   o_proj 3584 x 3584: 9.3 -> 11.2 / 11.7 -> 14.3      down 3584 x 18944: 32.6 -> 42.1 / 45.5 -> 57.1   (112 workgroups are too few)
     // hence: 32 outputs where at least 128 workgroups remain, except in the 256..1023-workgroup range at M <= 16.  V3D_DEC_OG=1 / 3: never / always.
+    // r04, second session: the pipelined forms (linear_decode_mfma2_kernel / _stream_kernel above; bit-identical outputs).  V3D_DEC_V2 = 0: never;
+    // 1 (default): where measured faster (tools/time_decode_rows.py, profiles/r04_decode_rows.txt); 2: wherever the shape allows (tests).
+    static int cus = 0;
+    const char* v2e = getenv("V3D_DEC_V2");                 // read per call: the tests switch it inside one process
+    const int v2_env = v2e ? atoi(v2e) : 1;
+    if (cus == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (cus <= 0) cus = 256;
+    }
+    const int tiles = K / 128, groups16 = n_out / 16, nt = (tiles + 7) / 8;
+    const bool v2_shape = tiles >= 9 && tiles <= 32;                       // 2..4 K tiles per wave, none without a tile
+    const bool v2_rule = v2_env >= 2 || groups16 <= cus || groups16 >= 4 * cus;     // persistent workgroups: whole rounds or many of them
+    if (v2_env >= 1 && v2_shape && v2_rule) {
+      const int grid = groups16 < cus ? groups16 : cus;
+#define V3D_LD2_K(TT, EE, BB, NN) hipLaunchKernelGGL((linear_decode_mfma2_kernel<TT, EE, BB, NN>), dim3(grid), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                                     (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, K, groups16)
+#define V3D_LD2_N(TT, EE, BB) { if (nt == 2) V3D_LD2_K(TT, EE, BB, 2); else if (nt == 3) V3D_LD2_K(TT, EE, BB, 3); else V3D_LD2_K(TT, EE, BB, 4); }
+#define V3D_LD2_B(TT, EE) { if (M <= 16) V3D_LD2_N(TT, EE, 1) else V3D_LD2_N(TT, EE, 2) }
+#define V3D_LD2_E(TT)                                                                                 \
+  switch (epilogue) {                                                                                 \
+    case DEC_EPI_NONE: V3D_LD2_B(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LD2_B(TT, DEC_EPI_BIAS); break; \
+    case DEC_EPI_RES: V3D_LD2_B(TT, DEC_EPI_RES); break; case DEC_EPI_SWIGLU: V3D_LD2_B(TT, DEC_EPI_SWIGLU); break; \
+    default: set_error("%s: unknown epilogue %d", who, epilogue); return V3D_E_INVALID;               \
+  }
+      if (dtype == V3D_BF16) { V3D_LD2_E(bf16_t) } else { V3D_LD2_E(f16_t) }
+#undef V3D_LD2_E
+#undef V3D_LD2_B
+#undef V3D_LD2_N
+#undef V3D_LD2_K
+      return check_launch(who);
+    }
+    if (v2_env >= 2 && tiles >= 8) {     // the streaming form ties the r04 kernel on down_proj (47 vs 45.5 us at 32 rows): tests and A/B only
+                                         // (every wave needs a tile: the unconditional requests clamp to its last one)
+#define V3D_LDS_B(TT, EE) { if (M <= 16) hipLaunchKernelGGL((linear_decode_mfma_stream_kernel<TT, EE, 1>), dim3(groups16), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                                     (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, K);                            \
+                            else hipLaunchKernelGGL((linear_decode_mfma_stream_kernel<TT, EE, 2>), dim3(groups16), dim3(512), 0, st, (const TT*)x, ldx, M,     \
+                                                     (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, K); }
+#define V3D_LDS_E(TT)                                                                                 \
+  switch (epilogue) {                                                                                 \
+    case DEC_EPI_NONE: V3D_LDS_B(TT, DEC_EPI_NONE); break; case DEC_EPI_BIAS: V3D_LDS_B(TT, DEC_EPI_BIAS); break; \
+    case DEC_EPI_RES: V3D_LDS_B(TT, DEC_EPI_RES); break; case DEC_EPI_SWIGLU: V3D_LDS_B(TT, DEC_EPI_SWIGLU); break; \
+    default: set_error("%s: unknown epilogue %d", who, epilogue); return V3D_E_INVALID;               \
+  }
+      if (dtype == V3D_BF16) { V3D_LDS_E(bf16_t) } else { V3D_LDS_E(f16_t) }
+#undef V3D_LDS_E
+#undef V3D_LDS_B
+      return check_launch(who);
+    }
     static int og_env = -1;
     if (og_env < 0) { const char* e = getenv("V3D_DEC_OG"); og_env = e ? atoi(e) : 2; }
     const int wg32 = n_out / 32;
