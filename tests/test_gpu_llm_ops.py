@@ -593,8 +593,9 @@ def test_linear_decode_rows_pipelined_forms_equal_the_r04_kernel_bitwise(ops, mo
     """r04, second session: linear_decode_mfma2_kernel (persistent workgroups, activation fragments resident in registers, weight tiles
     double-buffered in registers; 9..32 K tiles) and linear_decode_mfma_stream_kernel (any K) sum an output exactly as
     linear_decode_mfma_kernel does - slice w of K = tiles w, w + 8, ... in ascending order, the eight slices added in order - so every bit
-    agrees.  V3D_DEC_V2 = 0: the r04 kernel; 2: the pipelined forms wherever the shape allows (grids below, at and above the chip's CU count,
-    3 and 4 tiles per wave, waves with one tile fewer than their neighbours, an odd and an even number of groups per workgroup)."""
+    agrees.  V3D_DEC_V2 = 0: the r04 kernel; 2: the persistent form wherever the shape allows; 3: the streaming form (grids below, at and
+    above the chip's CU count, 2..4 tiles per wave, waves with one tile fewer than their neighbours, odd and even numbers of groups per
+    workgroup).  K > 4096 without SwiGLU is the K-split form at V3D_DEC_V2 = 1 / 2 (another f32 summation order: next test)."""
     g = torch.Generator().manual_seed(7 * M + K % 97)
     x = torch.randn(M, K, generator=g).to(dt).cuda()
     w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
@@ -604,20 +605,64 @@ def test_linear_decode_rows_pipelined_forms_equal_the_r04_kernel_bitwise(ops, mo
     if N % 128 == 0:
         cases.append(dict(epilogue=ops.DEC_SWIGLU))
     for kw in cases:
-        n_out = N // 2 if kw.get("epilogue") == ops.DEC_SWIGLU else N
+        swiglu = kw.get("epilogue") == ops.DEC_SWIGLU
+        n_out = N // 2 if swiglu else N
         outs = []
-        for mode in ("0", "2"):
+        for mode in ("0", "3") + (("2",) if K <= 4096 or swiglu else ()):
             monkeypatch.setenv("V3D_DEC_V2", mode)
             o = torch.full((M, n_out), 5.0, dtype=dt, device="cuda")
             ops.linear_decode_rows(x, w, o, **kw)
             outs.append(o)
-        assert torch.equal(outs[0], outs[1]), (kw.get("epilogue"), M, K, N)
-    monkeypatch.setenv("V3D_DEC_V2", "2")                   # rows do not depend on their neighbours or on M (the resident fragments of absent rows are zero)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (kw.get("epilogue"), M, K, N)
+    monkeypatch.setenv("V3D_DEC_V2", "2")                   # rows do not depend on their neighbours or on M (absent rows' columns are never stored)
     o_all = torch.empty((M, N), dtype=dt, device="cuda")
     ops.linear_decode_rows(x, w, o_all)
     o_two = torch.empty((2, N), dtype=dt, device="cuda")
     ops.linear_decode_rows(x[M - 2:], w, o_two)
     assert torch.equal(o_two, o_all[M - 2:])
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K,N", [(4224, 256), (4736, 512), (18944, 3584), (18944, 128), (9216, 4112)])
+def test_linear_decode_rows_k_split(ops, monkeypatch, dt, K, N):
+    """K > 4096 (down_proj): K is cut into chunks whose activation fragments stay in registers; the chunks' f32 sums meet in a second
+    launch, added in ascending order.  The cut depends on K, N and the chip only: a row's bits depend neither on M nor on its neighbours
+    (2, 16, 17 and 32 rows), two launches agree bit for bit, the values meet the f64 reference as the r04 kernel does (2^-7 |ref| + 2^-8
+    rms) and stay within one 16-bit rounding (of |value| + rms) of the r04 kernel's."""
+    g = torch.Generator().manual_seed(K % 1013 + N)
+    x = torch.randn(32, K, generator=g).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    r = torch.randn(32, N, generator=g).to(dt).cuda()
+    monkeypatch.setenv("V3D_DEC_V2", "1")
+    for kw in (dict(), dict(bias=b, epilogue=ops.DEC_BIAS), dict(res=r, epilogue=ops.DEC_RES)):
+        full = torch.full((32, N), 3.0, dtype=dt, device="cuda")
+        ops.linear_decode_rows(x, w, full, **kw)
+        again = torch.full((32, N), 4.0, dtype=dt, device="cuda")
+        ops.linear_decode_rows(x, w, again, **kw)
+        assert torch.equal(full, again)
+        for lo, hi in ((30, 32), (0, 16), (3, 20), (9, 11)):
+            kw2 = dict(kw)
+            if "res" in kw2:
+                kw2["res"] = r[lo:hi]
+            sub = torch.full((hi - lo, N), 9.0, dtype=dt, device="cuda")
+            ops.linear_decode_rows(x[lo:hi], w, sub, **kw2)
+            assert torch.equal(sub, full[lo:hi]), (kw.get("epilogue"), lo, hi)
+        ref = x.double() @ w.double().t()
+        if "bias" in kw:
+            ref = ref + b.double()
+        if "res" in kw:
+            ref = ref.to(dt).double() + r.double()
+        err = (full.double() - ref).abs()
+        assert bool((err <= 2.0 ** -7 * ref.abs() + 2.0 ** -8 * ref.pow(2).mean().sqrt()).all())
+        monkeypatch.setenv("V3D_DEC_V2", "0")
+        old = torch.empty((32, N), dtype=dt, device="cuda")
+        ops.linear_decode_rows(x, w, old, **kw)
+        monkeypatch.setenv("V3D_DEC_V2", "1")
+        ulp = 2.0 ** (-7 if dt == torch.bfloat16 else -10)
+        rms = old.double().pow(2).mean().sqrt()
+        assert bool(((full.double() - old.double()).abs() <= ulp * (old.double().abs() + rms)).all())
 
 
 def test_rope_kv_append_and_argmax(ops):

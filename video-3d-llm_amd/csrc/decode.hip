@@ -8,6 +8,8 @@
 //                       epilogues: bias / residual / SwiGLU over tile-interleaved gate|up rows.
 //   v3d_rope_kv_append: rotary on the new q and k heads + copy of k,v into the cache row, one launch.
 #include "v3d_common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace v3d {
 
@@ -338,10 +340,10 @@ __device__ __forceinline__ int dec2_row0(int grp) {                      // firs
 }
 
 // NW = K tiles of THIS wave (the workgroup's waves hold NT or NT - 1: two instantiations of the loop, chosen once per wave)
-template <typename T, int EPI, int MB, int NW>
+template <typename T, int EPI, int MB, int NW, bool SPLIT>
 __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W, int64_t ldw,
                                          const T* __restrict__ bias, const T* __restrict__ res, int64_t ldr, T* __restrict__ out,
-                                         int64_t ldo, int groups, char* smem_) {
+                                         int64_t ldo, int groups, char* smem_, float* __restrict__ partial) {
   constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;
   constexpr int PITCH = 272, TILE_B = 8 * SW * 16 * PITCH, PART_F = 8 * SW * MB * 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -356,13 +358,11 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
   for (int u = 0; u < NW; ++u)
 #pragma unroll
     for (int b = 0; b < MB; ++b) {
-      const bool ok = r + 16 * b < M;
-      const T* xr = x + (int64_t)(ok ? r + 16 * b : 0) * ldx + 8 * g + 128 * (wave + 8 * u);
+      // rows beyond M read row 0: column m of the product depends on row m alone, and the columns beyond M are never stored
+      // (no branch around a load: see issue below)
+      const T* xr = x + (int64_t)(r + 16 * b < M ? r + 16 * b : 0) * ldx + 8 * g + 128 * (wave + 8 * u);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        xb[u][b][t] = make_uint4(0u, 0u, 0u, 0u);
-        if (ok) xb[u][b][t] = *reinterpret_cast<const uint4*>(xr + 32 * t);
-      }
+      for (int t = 0; t < 4; ++t) xb[u][b][t] = *reinterpret_cast<const uint4*>(xr + 32 * t);
     }
   const int my_groups = (groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const T* wlane = W + (int64_t)lr * ldw + 8 * lc + 128 * wave;
@@ -408,7 +408,9 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
       }
       if (em < M) {
         const int n = 16 * ((int)blockIdx.x + gi * (int)gridDim.x) + erow;
-        if (EPI == DEC_EPI_SWIGLU) {
+        if (SPLIT) {                                        // this K chunk's f32 sum: decode_combine_kernel adds the chunks in order
+          partial[(int64_t)em * (16 * groups) + n] = v[0];
+        } else if (EPI == DEC_EPI_SWIGLU) {
           const float gt = round_to<T>(v[0]), up = round_to<T>(v[SW - 1]);
           out[em * ldo + n] = from_f32<T>(round_to<T>(silu_f(gt)) * up);
         } else {
@@ -423,8 +425,8 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
   };
   auto side_load = [&](int gi) -> float {                  // requested a whole group ahead of its use; unconditional (rows beyond M read row 0)
     const int n = 16 * ((int)blockIdx.x + gi * (int)gridDim.x) + erow;
-    if (EPI == DEC_EPI_BIAS) return to_f32(bias[n]);
-    if (EPI == DEC_EPI_RES) return to_f32(res[(int64_t)(em < M ? em : 0) * ldr + n]);
+    if (EPI == DEC_EPI_BIAS && !SPLIT) return to_f32(bias[n]);
+    if (EPI == DEC_EPI_RES && !SPLIT) return to_f32(res[(int64_t)(em < M ? em : 0) * ldr + n]);
     return 0.f;
   };
   uint4 wa[4], wb[4];
@@ -467,8 +469,41 @@ __global__ __launch_bounds__(512) void linear_decode_mfma2_kernel(const T* __res
   __shared__ __attribute__((aligned(16))) char smem_[8 * SW * 16 * 272 + 2 * 8 * SW * MB * 256 * 4];
   const int wave = threadIdx.x >> 6;
   const int nt_w = (K / 128 - wave + 7) / 8;               // NT or NT - 1 (host: 8 (NT - 1) < tiles <= 8 NT)
-  if (nt_w == NT) dec2_run<T, EPI, MB, NT>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_);
-  else dec2_run<T, EPI, MB, (NT > 1 ? NT - 1 : 1)>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_);
+  if (nt_w == NT) dec2_run<T, EPI, MB, NT, false>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_, nullptr);
+  else dec2_run<T, EPI, MB, (NT > 1 ? NT - 1 : 1), false>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_, nullptr);
+}
+
+// K > 4096 (down_proj, K = 18944): the activation fragments of a whole row of tiles do not fit the registers, and streamed per tile they
+// are M : 16 activation bytes per weight byte out of L2 (the r04 kernel: 3.0 TB/s of weights at 32 rows).  So K is CUT into gridDim.y
+// chunks of hi or hi - 1 tiles (the first n_hi chunks hold hi): workgroup (i, c) keeps chunk c's fragments resident and walks its groups
+// exactly as above, but leaves the chunk's f32 sums in partial[c][m][n]; decode_combine_kernel adds the chunks in ascending order and
+// applies the epilogue.  The cut depends on K, N and the chip only - never on M - so a row's bits still do not depend on its group.
+template <typename T, int MB, int NT>
+__global__ __launch_bounds__(512) void linear_decode_mfma2_split_kernel(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W,
+                                                                        int64_t ldw, float* __restrict__ partial, int groups, int hi, int n_hi) {
+  __shared__ __attribute__((aligned(16))) char smem_[8 * 16 * 272 + 2 * 8 * MB * 256 * 4];
+  const int wave = threadIdx.x >> 6, c = blockIdx.y;
+  const int t0 = c < n_hi ? c * hi : n_hi * hi + (c - n_hi) * (hi - 1), ct = c < n_hi ? hi : hi - 1;
+  const int nt_w = (ct - wave + 7) / 8;                    // NT or NT - 1 (host: hi >= 9, NT = ceil(hi / 8))
+  x += 128 * t0;
+  W += 128 * t0;
+  partial += (int64_t)c * (16 * MB) * (16 * groups);
+  if (nt_w == NT) dec2_run<T, DEC_EPI_NONE, MB, NT, true>(x, ldx, M, W, ldw, nullptr, nullptr, 0, nullptr, 0, groups, smem_, partial);
+  else dec2_run<T, DEC_EPI_NONE, MB, (NT > 1 ? NT - 1 : 1), true>(x, ldx, M, W, ldw, nullptr, nullptr, 0, nullptr, 0, groups, smem_, partial);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void decode_combine_kernel(const float* __restrict__ partial, int chunks, int rows_pad, int M, int N,
+                                                             const T* __restrict__ bias, const T* __restrict__ res, int64_t ldr,
+                                                             T* __restrict__ out, int64_t ldo) {
+  const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+  if (n >= N || m >= M) return;
+  float y = 0.f;
+  for (int c = 0; c < chunks; ++c) y += partial[((int64_t)c * rows_pad + m) * N + n];
+  if (EPI == DEC_EPI_BIAS) y += to_f32(bias[n]);
+  y = round_to<T>(y);                                       // the linear's own output rounding
+  if (EPI == DEC_EPI_RES) y += to_f32(res[m * ldr + n]);
+  out[m * ldo + n] = from_f32<T>(y);
 }
 
 // any K: one 16-output group per workgroup, weights and activations of tile j + 2 in flight while tile j is multiplied
@@ -764,6 +799,23 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
 
 using namespace v3d;
 
+// f32 partial sums of the K-split decode linear: one buffer per stream (launches on one stream are ordered; two streams never share it),
+// grown when a larger product arrives (the old block is released once the stream has drained).
+static float* decode_split_workspace(hipStream_t st, size_t bytes) {
+  struct Block { void* p; size_t n; };
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, Block> blocks;
+  std::lock_guard<std::mutex> lock(mu);
+  Block& b = blocks[st];
+  if (b.n < bytes) {
+    if (b.p) { (void)hipStreamSynchronize(st); (void)hipFree(b.p); b.p = nullptr; b.n = 0; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    b.p = p; b.n = bytes;
+  }
+  return static_cast<float*>(b.p);
+}
+
 static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W, int64_t ldw,
                               const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K, int dtype,
                               int epilogue, void* stream, const char* who) {
@@ -793,7 +845,8 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
     //   o_proj 3584 x 3584: 9.3 -> 11.2 / 11.7 -> 14.3      down 3584 x 18944: 32.6 -> 42.1 / 45.5 -> 57.1   (112 workgroups are too few)
     // hence: 32 outputs where at least 128 workgroups remain, except in the 256..1023-workgroup range at M <= 16.  V3D_DEC_OG=1 / 3: never / always.
     // r04, second session: the pipelined forms (linear_decode_mfma2_kernel / _stream_kernel above; bit-identical outputs).  V3D_DEC_V2 = 0: never;
-    // 1 (default): where measured faster (tools/time_decode_rows.py, profiles/r04_decode_rows.txt); 2: wherever the shape allows (tests).
+    // 1 (default): where measured faster (tools/time_decode_rows.py, profiles/r04_decode_rows.txt); 2: wherever the shape allows (tests);
+    // 3: the streaming form wherever the shape allows (tests, A/B).
     static int cus = 0;
     const char* v2e = getenv("V3D_DEC_V2");                 // read per call: the tests switch it inside one process
     const int v2_env = v2e ? atoi(v2e) : 1;
@@ -805,7 +858,7 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
     const int tiles = K / 128, groups16 = n_out / 16, nt = (tiles + 7) / 8;
     const bool v2_shape = tiles >= 9 && tiles <= 32;                       // 2..4 K tiles per wave, none without a tile
     const bool v2_rule = v2_env >= 2 || groups16 <= cus || groups16 >= 4 * cus;     // persistent workgroups: whole rounds or many of them
-    if (v2_env >= 1 && v2_shape && v2_rule) {
+    if (v2_env >= 1 && v2_env <= 2 && v2_shape && v2_rule) {
       const int grid = groups16 < cus ? groups16 : cus;
 #define V3D_LD2_K(TT, EE, BB, NN) hipLaunchKernelGGL((linear_decode_mfma2_kernel<TT, EE, BB, NN>), dim3(grid), dim3(512), 0, st, (const TT*)x, ldx, M, \
                                                      (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, K, groups16)
@@ -823,6 +876,40 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
 #undef V3D_LD2_N
 #undef V3D_LD2_K
       return check_launch(who);
+    }
+    if (v2_env >= 1 && v2_env <= 2 && tiles > 32 && epilogue != DEC_EPI_SWIGLU) {        // K cut into chunks whose activation fragments stay in registers
+      int C = 0, hi = 0;
+      double best = 0.0;
+      for (int c = (tiles + 31) / 32; c <= 16; ++c) {                     // whole rounds of groups on as many CUs as possible
+        const int h = (tiles + c - 1) / c;
+        if (h > 32 || h < 9) continue;
+        int G = cus / c;
+        if (G < 1) break;
+        if (G > groups16) G = groups16;
+        const double eff = ((double)groups16 / G) / ((groups16 + G - 1) / G) * (double)(c * G) / cus;
+        if (eff > best + 1e-9) { best = eff; C = c; hi = h; }
+      }
+      if (C > 0) {
+        const int n_hi = tiles - C * (hi - 1), nt2 = (hi + 7) / 8, mb = M <= 16 ? 1 : 2;
+        int G = cus / C;
+        if (G > groups16) G = groups16;
+        float* ws = decode_split_workspace(st, (size_t)C * 16 * mb * n_out * sizeof(float));
+        if (!ws) { set_error("%s: no workspace for the K-split partial sums", who); return V3D_E_LAUNCH; }
+#define V3D_LDK_K(TT, BB, NN) hipLaunchKernelGGL((linear_decode_mfma2_split_kernel<TT, BB, NN>), dim3(G, C), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                                 (const TT*)W, ldw, ws, groups16, hi, n_hi)
+#define V3D_LDK_N(TT, BB) { if (nt2 == 2) V3D_LDK_K(TT, BB, 2); else if (nt2 == 3) V3D_LDK_K(TT, BB, 3); else V3D_LDK_K(TT, BB, 4); }
+#define V3D_LDK_C(TT, EE) hipLaunchKernelGGL((decode_combine_kernel<TT, EE>), dim3((n_out + 255) / 256, M), dim3(256), 0, st, ws, C, 16 * mb, M, n_out, \
+                                             (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo)
+#define V3D_LDK_T(TT) { if (mb == 1) V3D_LDK_N(TT, 1) else V3D_LDK_N(TT, 2)                                                         \
+                        if (epilogue == DEC_EPI_BIAS) V3D_LDK_C(TT, DEC_EPI_BIAS); else if (epilogue == DEC_EPI_RES) V3D_LDK_C(TT, DEC_EPI_RES); \
+                        else V3D_LDK_C(TT, DEC_EPI_NONE); }
+        if (dtype == V3D_BF16) V3D_LDK_T(bf16_t) else V3D_LDK_T(f16_t)
+#undef V3D_LDK_T
+#undef V3D_LDK_C
+#undef V3D_LDK_N
+#undef V3D_LDK_K
+        return check_launch(who);
+      }
     }
     if (v2_env >= 2 && tiles >= 8) {     // the streaming form ties the r04 kernel on down_proj (47 vs 45.5 us at 32 rows): tests and A/B only
                                          // (every wave needs a tile: the unconditional requests clamp to its last one)
