@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V3D_ABI_VERSION 6   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds; 6: sumsq, *_rows entries take 1..32 rows */
+#define V3D_ABI_VERSION 7   /* 2: *_rows decode entries, fp8 path, a7 / a3 device entries; 3: rope_kv_store, add_row, ...; 4: resize_bicubic, eos_update, embed_grad bounds; 6: sumsq, *_rows entries take 1..32 rows; 7: attention_shared_prefix */
 
 enum { V3D_F32 = 0, V3D_F16 = 1, V3D_BF16 = 2 };
 enum { V3D_U8_HWC = 16 };   /* v3d_resize_bicubic_u8 only: 8-bit interleaved output, no normalisation */
@@ -237,6 +237,17 @@ int v3d_attention(const void* q, const void* k, const void* v, void* o, int dtyp
                   int Hq, int Hkv, int D, int d_out, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                   int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk, int hso, int causal, int q_pos0,
                   float scale, void* stream);
+
+/* r04 (scene reuse): v3d_attention (causal, D = 128) for the question rows of B questions about ONE prefilled scene -
+ * the reference recomputes the scene for every question (model_scanqa.py:130-185; the shared prompt: :46-60).  Key tiles below
+ * shared_len (a multiple of 64, <= q_pos0) are read from the scene's cache k_shared / v_shared (ldk / ldv / hsk as k / v, no batch
+ * stride); keys from shared_len on from k / v + b*bsk (each question's own cache, rows at their absolute positions: rows below
+ * shared_len of those caches are never touched).  A workgroup's query slots hold the rows of all query heads of a kv head.  Every
+ * output bit equals v3d_attention's on B full copies. */
+int v3d_attention_shared_prefix(const void* q, const void* k, const void* v, const void* k_shared, const void* v_shared,
+                                int shared_len, void* o, int dtype, int B, int Sq, int Sk, int Hq, int Hkv, int64_t ldq,
+                                int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk,
+                                int hso, int q_pos0, float scale, void* stream);
 
 /* Decode step of K16 (one new query row against the K/V cache, modeling_qwen2.py:282-311 with a
  * DynamicCache): split-KV so the cache is streamed once by the whole chip.  q [Hq*128] (head stride hsq),

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/v3d.h but not exported"
         assert n in _native.SIGNATURES, f"{n} has no ctypes signature"
-    assert lib.v3d_abi_version() == 6
+    assert lib.v3d_abi_version() == 7
 
 
 def test_invalid_arguments_report_an_error():

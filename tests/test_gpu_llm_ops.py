@@ -665,6 +665,43 @@ def test_linear_decode_rows_k_split(ops, monkeypatch, dt, K, N):
         assert bool(((full.double() - old.double()).abs() <= ulp * (old.double().abs() + rms)).all())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Sq,P", [(3, 60, 6734), (2, 61, 200), (4, 1, 64), (2, 130, 130), (1, 17, 63), (5, 64, 1024), (2, 33, 6720)])
+def test_attention_shared_prefix_equals_attention_on_full_copies_bitwise(ops, dt, B, Sq, P):
+    """r04: the question rows of an answer batch (v3d_attention_shared_prefix).  Key tiles below 64 floor(P / 64) come from ONE cache, the
+    rest from each question's own cache - whose rows below that are POISONED here (NaN) to prove nobody reads them - and a workgroup's
+    query slots hold the rows of all seven query heads of a kv head.  Same tiles in the same order, the raise decided per lane: every
+    output bit equals v3d_attention over B full copies (prefix lengths on / off a tile boundary, below one tile, rows filling less and
+    more than one 128-slot tile, a single row)."""
+    Hq, Hkv, hd = 28, 4, 128
+    g = torch.Generator().manual_seed(B * 1000 + Sq + P)
+    kvw = Hkv * hd
+    Sk = P + Sq
+    cap = Sk + 7
+    scene = torch.randn(cap, 2 * kvw, generator=g).to(dt).cuda()
+    own = torch.randn(B, cap, 2 * kvw, generator=g).to(dt).cuda()
+    full = own.clone()
+    full[:, :P] = scene[:P]
+    q = (torch.randn(B * Sq, Hq * hd, generator=g) * 2).to(dt).cuda()
+    P0 = (P // 64) * 64
+    own[:, P0:P] = scene[P0:P]
+    own[:, :P0] = float("nan")
+    scale = 1.0 / math.sqrt(hd)
+    want = torch.empty(B * Sq, Hq * hd, dtype=dt, device="cuda")
+    c2 = full.view(-1, 2 * kvw)
+    ops.attention(q, c2, c2[:, kvw:], want, B, Sq, Sk, Hq, Hkv, hd, hd, q.stride(0), c2.stride(0), c2.stride(0), want.stride(0), Sq * q.stride(0),
+                  full.stride(0), Sq * want.stride(0), hd, hd, hd, True, P, scale)
+    got = torch.full((B * Sq, Hq * hd), 3.0, dtype=dt, device="cuda")
+    o2 = own.view(-1, 2 * kvw)
+    ops.attention_shared_prefix(q, o2, o2[:, kvw:], scene, scene[:, kvw:], P0, got, B, Sq, Sk, Hq, Hkv, q.stride(0), o2.stride(0), o2.stride(0),
+                                got.stride(0), Sq * q.stride(0), own.stride(0), Sq * got.stride(0), hd, hd, hd, P, scale)
+    assert not bool(torch.isnan(got.float()).any())
+    assert torch.equal(got, want)
+    with pytest.raises(Exception, match="shared_len"):
+        ops.attention_shared_prefix(q, o2, o2[:, kvw:], scene, scene[:, kvw:], P0 + 8, got, B, Sq, Sk, Hq, Hkv, q.stride(0), o2.stride(0),
+                                    o2.stride(0), got.stride(0), Sq * q.stride(0), own.stride(0), Sq * got.stride(0), hd, hd, hd, P, scale)
+
+
 def test_rope_kv_append_and_argmax(ops):
     dt = torch.bfloat16
     H, KV, D = 4, 2, 128

@@ -102,7 +102,8 @@ def test_answer_group_equals_answering_alone(dtype):
     st = eng._answer_state(len(questions))
     for gi, q in enumerate(questions):
         for layer in range(len(scene.kv)):
-            assert torch.equal(st.ctxs[gi].kv[layer][:P], scene.kv[layer][:P])
+            P0 = (P // 64) * 64      # r04: the questions' caches hold the rows of the key tile that straddles P only; the tiles below it are read from the scene's cache
+            assert torch.equal(st.ctxs[gi].kv[layer][P0:P], scene.kv[layer][P0:P])
             assert torch.equal(st.ctxs[gi].kv[layer][P: P + len(q)], alone_kv[gi][layer]), (gi, layer)
     assert eng.ctx is scene and scene.prefix_len == P
     # group independence: the same question inside other groups

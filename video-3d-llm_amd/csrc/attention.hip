@@ -86,6 +86,10 @@ struct AttnArgs {
   // (o[128], m, l) in split slot part_split0 + c of row i / q_rpg's workspace slice (part_ws_stride floats apart), head hk q_rpg + i % q_rpg
   int q_rpg, sk_total, part_split0, part_hq;
   int64_t part_ws_stride;
+  // attn_prefill_kernel<QPK> only (r04, the question rows of an answer batch over ONE copy of the scene's prefix): key tiles below
+  // sh_tiles are read from k_sh / v_sh (no batch stride: the scene's cache), the rest from k / v (each question's own cache)
+  const void* k_sh; const void* v_sh;
+  int sh_tiles;
 };
 
 #ifndef V3D_ATTN_VPF
@@ -127,7 +131,11 @@ constexpr float AT_LS_LIMIT = 255.0f;
 
 // KSV: k-steps of QK^T that can be non-zero (head dims >= d_out are zeroed in Q): SigLIP's 72-wide heads on the 96-wide tile
 // need 5 of the 6 (the sixth multiplies zeros)
-template <typename T, int D, bool CAUSAL, int KSV = D / 16, bool LSE = false>
+// QPK (r04, v3d_attention_shared_prefix: the question rows of an answer batch): the workgroup's 128 query slots are the rows of ALL the
+// query heads of one kv head (slot i = head i / Sq of the group, row i % Sq: 7 x 60 rows fill four tiles where one head per workgroup
+// filled 60 of 128 slots seven times), and key tiles below p.sh_tiles come from the scene's one cache instead of the batch entry's copy.
+// A row's arithmetic is untouched - same tiles, same order, the raise decided per lane - so its bits equal the unpacked kernel's.
+template <typename T, int D, bool CAUSAL, int KSV = D / 16, bool LSE = false, bool QPK = false>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];   // 1 KiB: fragment addresses are formed by XOR
   using M = Mfma32<T>;
@@ -158,18 +166,28 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     qt = p.n_qt - 1 - jj / p.group;
   } else {
     qt = (int)gridDim.y - 1 - (int)blockIdx.y;
-    head = blockIdx.x; b = blockIdx.z;
+    head = blockIdx.x; b = blockIdx.z;            // QPK: blockIdx.x is the kv head
   }
-  const int hk = head / p.group;
+  const int hk = QPK ? head : head / p.group;
   const int q0 = qt * AT_BQ;
 
-  const uint16_t* Q = (const uint16_t*)p.q + b * p.bsq + (int64_t)head * p.hsq;
   const uint16_t* K = (const uint16_t*)p.k + b * p.bsk + (int64_t)hk * p.hsk;
   const uint16_t* V = (const uint16_t*)p.v + b * p.bsk + (int64_t)hk * p.hsk;
+  const uint16_t* Ksh = QPK ? (const uint16_t*)p.k_sh + (int64_t)hk * p.hsk : K;
+  const uint16_t* Vsh = QPK ? (const uint16_t*)p.v_sh + (int64_t)hk * p.hsk : V;
 
   // ---- Q fragments: B operand, lane (q, h) holds c * Q[q][16ks + 8h .. +8) ----
-  const int qi = q0 + wave * 32 + ql;
-  const int qi_ld = qi < p.Sq ? qi : p.Sq - 1;
+  int qi = q0 + wave * 32 + ql;
+  int qi_ld = qi < p.Sq ? qi : p.Sq - 1;
+  if (QPK) {                                     // slot -> (head of the group, row); slots past the last row repeat it and store nothing
+    const int slots = p.group * p.Sq;
+    const int vi = qi < slots ? qi : slots - 1;
+    const int hh = vi / p.Sq;
+    head = hk * p.group + hh;
+    qi = qi < slots ? vi - hh * p.Sq : p.Sq;     // (>= Sq: "no such row")
+    qi_ld = vi - hh * p.Sq;
+  }
+  const uint16_t* Q = (const uint16_t*)p.q + b * p.bsq + (int64_t)head * p.hsq;
   Frag16 qf[KS];          // (loaded in the prologue, behind the first tiles' DMAs)
 
   // ---- tile counts ----
@@ -182,6 +200,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     n_tiles = t < n_tiles_all ? t : n_tiles_all;
     const int tw = (p.q_pos0 + q0 + wave * 32 + 31) / AT_BKV + 1;
     n_wave = tw < n_tiles ? tw : n_tiles;
+    if (QPK) {                                   // a wave's slots wrap over heads: every wave walks to the last row's tile
+      const int tq = (p.q_pos0 + p.Sq - 1) / AT_BKV + 1;
+      n_tiles = n_wave = tq < n_tiles_all ? tq : n_tiles_all;
+    }
   }
 
   // ---- KV staging by LDS-DMA: one instruction = 4 rows x 256 B; wave w stages rows [16w, 16w+16) of a tile.
@@ -202,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       glds16a((const char*)src + ((unsigned)key * ld_b + (unsigned)chunk * 16u), dst + i * 4 * AT_ROW);
     }
   };
-  auto stage_k = [&](int buf, int t) { stage(K, ldk_b, smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW, t); };
-  auto stage_v = [&](int buf, int t) { stage(V, ldv_b, smem + buf * 2 * AT_TILE + AT_TILE + (wave * 16) * AT_ROW, t); };
+  auto stage_k = [&](int buf, int t) { stage(QPK && t < p.sh_tiles ? Ksh : K, ldk_b, smem + buf * 2 * AT_TILE + (wave * 16) * AT_ROW, t); };
+  auto stage_v = [&](int buf, int t) { stage(QPK && t < p.sh_tiles ? Vsh : V, ldv_b, smem + buf * 2 * AT_TILE + AT_TILE + (wave * 16) * AT_ROW, t); };
   // r03, steady state (every row of the tile exists): the per-lane part of the four piece addresses is constant, the tile's base
   // is wave-uniform and advances on the scalar unit - no v_mad_u64 / v_min per piece in the vector issue stream (8 pieces per
   // step cost 8 x (add, min, 64-bit mad) = ~190 issue cycles of a step's ~1000).
@@ -225,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                    : : "v"(off[i]), "s"(base), "s"(lds_dst + (unsigned)(i * 4 * AT_ROW)) : "memory", "m0");
   };
-  auto stage_k_fast = [&](int buf, int t) { stage_fast(K, ldk_b, koff, lds_wave0 + buf * 2 * AT_TILE, t); };
-  auto stage_v_fast = [&](int buf, int t) { stage_fast(V, ldv_b, voff, lds_wave0 + buf * 2 * AT_TILE + AT_TILE, t); };
+  auto stage_k_fast = [&](int buf, int t) { stage_fast(QPK && t < p.sh_tiles ? Ksh : K, ldk_b, koff, lds_wave0 + buf * 2 * AT_TILE, t); };
+  auto stage_v_fast = [&](int buf, int t) { stage_fast(QPK && t < p.sh_tiles ? Vsh : V, ldv_b, voff, lds_wave0 + buf * 2 * AT_TILE + AT_TILE, t); };
 
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   // ---- per-lane LDS read addresses (buffer 0; buffer 1 and the key sub-blocks are immediate offsets) ----
@@ -249,8 +271,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = 0.f, l_run = 0.f;              // m_run in scaled log2 units; fixed by the first tile
-  const int q_pos = p.q_pos0 + qi;
-  const int wave_first_pos = p.q_pos0 + q0 + wave * 32;
+  const int q_pos = p.q_pos0 + (QPK ? qi_ld : qi);
+  const int wave_first_pos = QPK ? p.q_pos0 : p.q_pos0 + q0 + wave * 32;      // (QPK: some slot of the wave may be a head's first row)
 #ifdef V3D_ATTN_PROF
   unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -561,15 +583,23 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       *reinterpret_cast<uint2*>(so + ql * OROW + d * 2) = pk;
     }
   __syncthreads();
-  uint16_t* O = (uint16_t*)p.o + b * p.bso + (int64_t)head * p.hso;
+  uint16_t* O = (uint16_t*)p.o + b * p.bso + (int64_t)(QPK ? hk * p.group : head) * p.hso;
   constexpr int OCH = D / 8;                   // 16-byte chunks per row
 #pragma unroll
   for (int i = 0; i < (32 * OCH + 63) / 64; ++i) {
     const int idx = i * 64 + lane;
     const int row = idx / OCH, ch = idx - row * OCH;
-    const int q = q0 + wave * 32 + row;
-    if (row < 32 && q < p.Sq && ch * 8 < p.d_out)
-      *reinterpret_cast<uint4*>(O + (int64_t)q * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(so + row * OROW + ch * 16);
+    int q = q0 + wave * 32 + row;
+    int64_t off = 0;
+    bool ok = row < 32 && q < p.Sq;
+    if (QPK) {                                 // slot -> (head of the group, row)
+      ok = row < 32 && q < p.group * p.Sq;
+      const int hh = q / p.Sq;
+      q -= hh * p.Sq;
+      off = (int64_t)hh * p.hso;
+    }
+    if (ok && ch * 8 < p.d_out)
+      *reinterpret_cast<uint4*>(O + off + (int64_t)q * p.ldo + ch * 8) = *reinterpret_cast<const uint4*>(so + row * OROW + ch * 16);
   }
 }
 
@@ -2550,6 +2580,53 @@ extern "C" int v3d_attention(const void* q, const void* k, const void* v, void* 
                              float scale, void* stream) {
   return attention_entry(q, k, v, o, dtype, B, Sq, Sk, Hq, Hkv, D, d_out, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, causal, q_pos0,
                          scale, stream, nullptr);
+}
+
+// r04: the question rows of an answer batch (B questions x Sq rows at positions q_pos0 .. about ONE prefilled scene): causal attention at
+// head dim 128 as v3d_attention computes it - every output bit equal - but (1) key tiles below shared_len (a multiple of 64, <= q_pos0)
+// are read from the scene's cache k_shared / v_shared (same ldk / ldv / hsk, no batch stride) instead of each question's copy of them,
+// so the B copies need not exist, and (2) a workgroup's query slots hold the rows of all the query heads of a kv head (attn_prefill_kernel
+// <QPK>).  Keys from shared_len on come from k / v + b bsk as before (each question's own cache, rows at their absolute positions).
+extern "C" int v3d_attention_shared_prefix(const void* q, const void* k, const void* v, const void* k_shared, const void* v_shared,
+                                           int shared_len, void* o, int dtype, int B, int Sq, int Sk, int Hq, int Hkv, int64_t ldq,
+                                           int64_t ldk, int64_t ldv, int64_t ldo, int64_t bsq, int64_t bsk, int64_t bso, int hsq, int hsk,
+                                           int hso, int q_pos0, float scale, void* stream) {
+  const char* who = "v3d_attention_shared_prefix";
+  V3D_REQUIRE(q && k && v && o && k_shared && v_shared, "%s: null pointer", who);
+  V3D_REQUIRE(dtype == V3D_F16 || dtype == V3D_BF16, "%s: dtype must be f16 or bf16", who);
+  V3D_REQUIRE(B > 0 && Sq > 0 && Sk > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "%s: bad shape", who);
+  V3D_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && hsq % 8 == 0 && hsk % 8 == 0 && hso % 8 == 0 &&
+                  bsq % 8 == 0 && bsk % 8 == 0 && bso % 8 == 0, "%s: strides must be multiples of 8 elements", who);
+  V3D_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(k_shared) && aligned16(v_shared),
+              "%s: pointers must be 16-byte aligned", who);
+  V3D_REQUIRE(q_pos0 >= 0 && q_pos0 + Sq <= Sk, "%s: causal needs q_pos0 + Sq <= Sk", who);
+  V3D_REQUIRE(shared_len >= 0 && shared_len % AT_BKV == 0 && shared_len <= q_pos0, "%s: shared_len=%d must be a multiple of %d and <= q_pos0", who,
+              shared_len, AT_BKV);
+  AttnArgs p{};
+  p.q = q; p.k = k; p.v = v; p.o = o;
+  p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bsq = bsq; p.bsk = bsk; p.bso = bso;
+  p.hsq = hsq; p.hsk = hsk; p.hso = hso; p.Sq = Sq; p.Sk = Sk; p.Hq = Hq; p.group = Hq / Hkv;
+  p.d_out = 128; p.q_pos0 = q_pos0;
+  p.scale_log2 = scale * 1.44269504088896340736f;
+  p.lse = nullptr; p.xcd_p = 0;
+  p.k_sh = k_shared; p.v_sh = v_shared; p.sh_tiles = shared_len / AT_BKV;
+  p.n_qt = (p.group * Sq + AT_BQ - 1) / AT_BQ;
+  const dim3 grid(Hkv, p.n_qt, B);
+  hipStream_t st = (hipStream_t)stream;
+#define V3D_ATTN_SP(TT)                                                                                           \
+  {                                                                                                               \
+    auto kern = attn_prefill_kernel<TT, 128, true, 8, false, true>;                                               \
+    static bool done = false;                                                                                     \
+    if (!done) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS);  \
+      if (e != hipSuccess) { set_error("%s: LDS attribute: %s", who, hipGetErrorString(e)); return V3D_E_LAUNCH; } \
+      done = true;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kern, grid, dim3(256), AT_LDS, st, p);                                                     \
+  }
+  if (dtype == V3D_BF16) V3D_ATTN_SP(bf16_t) else V3D_ATTN_SP(f16_t)
+#undef V3D_ATTN_SP
+  return check_launch(who);
 }
 
 // The training forward: v3d_attention (head dim 128) that also writes the row log-sum-exp the backward recomputes the

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libv3d_hip.so")
 
 _lib = None
-ABI_VERSION = 6      # include/v3d.h V3D_ABI_VERSION
+ABI_VERSION = 7      # include/v3d.h V3D_ABI_VERSION
 
 
 class V3DError(RuntimeError):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "v3d_rope_apply": (c_i, [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "v3d_attention": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l,
                             c_l, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "v3d_attention_shared_prefix": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
+                                          c_i, c_i, c_i, c_i, c_f, c_p]),
     "v3d_attention_decode_workspace_bytes": (c_l, [c_i, c_i]),
     "v3d_attention_decode": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_i, c_i, c_i, c_f, c_p, c_l, c_p]),
     "v3d_linear_decode": (c_i, [c_p, c_p, c_f, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -479,8 +479,15 @@ class Engine:
                 cache = c3.view(-1, c3.shape[-1])
                 ops.rope_kv_store(qkv, nh, nkv, hd, self.rope, cache, positions=batch.positions, dst_rows=batch.dst_rows)
                 B, Sq = batch.B, batch.Sq
-                ops.attention(qkv, cache, cache[:, kvw:], att, B, Sq, pos0 + Sq, nh, nkv, hd, hd, qkv.stride(0), cache.stride(0),
-                              cache.stride(0), att.stride(0), Sq * qkv.stride(0), c3.stride(0), Sq * att.stride(0), hd, hd, hd, True, pos0, scale)
+                shared = getattr(batch, "shared_kv", None)
+                if shared is not None:   # answer_group: key tiles below shared_len from the scene's ONE cache (the questions' caches hold no copy)
+                    sc = shared[i]
+                    ops.attention_shared_prefix(qkv, cache, cache[:, kvw:], sc, sc[:, kvw:], batch.shared_len, att, B, Sq, pos0 + Sq, nh, nkv,
+                                                qkv.stride(0), cache.stride(0), cache.stride(0), att.stride(0), Sq * qkv.stride(0), c3.stride(0),
+                                                Sq * att.stride(0), hd, hd, hd, pos0, scale)
+                else:
+                    ops.attention(qkv, cache, cache[:, kvw:], att, B, Sq, pos0 + Sq, nh, nkv, hd, hd, qkv.stride(0), cache.stride(0),
+                                  cache.stride(0), att.stride(0), Sq * qkv.stride(0), c3.stride(0), Sq * att.stride(0), hd, hd, hd, True, pos0, scale)
                 lin(att, L, "wo", x, res=x, epilogue=ops.EPI_RES)
                 norm_lin(L["ln2"], L, "wgu", act, epilogue=ops.EPI_SWIGLU)
                 lin(act, L, "wd", x, res=x, epilogue=ops.EPI_RES)
@@ -757,8 +764,17 @@ class Engine:
         if G * Sq > l.max_pos:
             raise V3DError(f"{G} questions x {Sq} rows exceed the engine's {l.max_pos}-row workspaces")
         self._check_room(P + Sq, max_new_tokens)
+        # r04: the questions' caches no longer receive a copy of the prefix.  Their rows run over the scene's ONE cache for every key tile
+        # below P0 = 64 floor(P / 64) (v3d_attention_shared_prefix: same tiles, same order - the bits of a full copy), and the decode steps
+        # read the prefix from it as well; only the rows of the tile that straddles P are copied (at most 63).  V3D_SHARED_PREFIX=0: the
+        # r03 form, every question with its own full copy (A/B and tests).
+        share = os.environ.get("V3D_SHARED_PREFIX", "1") != "0" and scene.kv[0].stride(0) == st.kv[0].stride(1)
+        P0 = (P // 64) * 64 if share else 0
         for i in range(l.layers):
-            ops.copy_rows_bcast(scene.kv[i][:P], st.kv[i][:G])
+            if not share:
+                ops.copy_rows_bcast(scene.kv[i][:P], st.kv[i][:G])
+            elif P > P0:
+                ops.copy_rows_bcast(scene.kv[i][P0:P], st.kv[i][:G, P0:])
         ids = torch.empty((G, Sq), dtype=torch.int64)
         for g, q in enumerate(questions):
             ids[g, : lens[g]] = q.cpu()
@@ -769,6 +785,8 @@ class Engine:
         j = torch.arange(Sq)
         b.positions = (P + j).repeat(G).to(torch.int32).to(self.device)
         b.dst_rows = (torch.arange(G)[:, None] * l.max_pos + P + j[None, :]).reshape(-1).to(self.device)
+        if share:
+            b.shared_kv, b.shared_len = scene.kv, P0
         self.llm_forward(x, P, head=False, batch=b)
         last = torch.tensor([g * Sq + lens[g] - 1 for g in range(G)], dtype=torch.int64, device=self.device)
         rows = st.rows
@@ -781,9 +799,8 @@ class Engine:
         ctxs = st.ctxs[:G]
         for c, n in zip(ctxs, lens):
             c.kv_len = P + n
-        share = 0 if os.environ.get("V3D_SHARED_PREFIX", "1") == "0" else P          # (0: every question reads its own copy - A/B and tests)
-        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True, shared_prefix=share,
-                                 eos_token_id=eos_token_id)
+        toks = self.decode_group(rows, ctxs, [P + n for n in lens], max_new_tokens, logits_ready=True, shared_prefix=P if share else 0,
+                                 eos_token_id=eos_token_id, prefix_kv=scene.kv if share else None)
         self.use(scene)
         return [r.to(self.device) for r in self.trim_at_eos(toks, eos_token_id)]
 
@@ -836,10 +853,11 @@ class Engine:
         g.amax_ws = torch.empty(256 * n_scenes, dtype=torch.float32, device=self.device)
         return g
 
-    def decode_forward_rows(self, g, ctxs, positions, shared_prefix=0):
+    def decode_forward_rows(self, g, ctxs, positions, shared_prefix=0, prefix_kv=None):
         """One new token for each of the M scenes (rows of g.x, in place) at its own position: per layer 4 weight-streaming
         linears over all rows + one rotary/append and one split-KV attention launch pair covering all scenes.
-        shared_prefix > 0 (answer_group): the caches start with the same rows; the attention reads them once for all rows."""
+        shared_prefix > 0 (answer_group): the caches start with the same rows; the attention reads them once for all rows - from
+        prefix_kv[i] (the scene's own per-layer caches) when given: the rows' caches then need not hold those rows at all."""
         l = self.cfg.llm
         M = len(ctxs)
         hd, nh, nkv = self.hd, l.heads, l.kv_heads
@@ -858,7 +876,8 @@ class Engine:
             ops.rmsnorm(x, L["ln1"], l.eps, out=h)
             lin(h, L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
             ops.rope_kv_append_rows(qkv, nh, nkv, hd, self.rope, positions, [c[p] for c, p in zip(caches, positions)])
-            ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws, prefix=shared_prefix)
+            ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws, prefix=shared_prefix,
+                                      prefix_kv=(prefix_kv[i], prefix_kv[i][:, kvw:]) if prefix_kv is not None and shared_prefix else None)
             lin(att, L, "wo", x, res=x, epilogue=ops.DEC_RES)
             ops.rmsnorm(x, L["ln2"], l.eps, out=h)
             lin(h, L, "wgu", act, epilogue=ops.DEC_SWIGLU)
@@ -872,7 +891,7 @@ class Engine:
             ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
         return g.logits[:M, : l.vocab]
 
-    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False, shared_prefix=0, eos_token_id=None, lookahead=2):
+    def decode_group(self, g, ctxs, prompt_lens, max_new_tokens, logits_ready=False, shared_prefix=0, eos_token_id=None, lookahead=2, prefix_kv=None):
         """Greedy decoding of M prefilled scenes together (their prefill logits are in ctx.logits[0], or already in g.logits
         with logits_ready); returns the token ids [M, n_steps] (device), n_steps <= max_new_tokens.
         eos_token_id (int or ints): the stop test runs on the device (v3d_eos_update: a done mask per row and their count); the
@@ -910,7 +929,7 @@ class Engine:
             if step + 1 == max_new_tokens:
                 break
             ops.embed_gather(self.embed, toks[step], out=g.x[:M])
-            logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens], shared_prefix=shared_prefix)
+            logits = self.decode_forward_rows(g, ctxs, [S + step for S in prompt_lens], shared_prefix=shared_prefix, prefix_kv=prefix_kv)
         return toks[:n_steps].t()
 
     def _eos_state(self, g, eos, max_new_tokens):

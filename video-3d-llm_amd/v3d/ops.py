@@ -462,6 +462,17 @@ def attention(q, k, v, out, B, Sq, Sk, Hq, Hkv, D, d_out, ldq, ldk, ldv, ldo, bs
     return out
 
 
+def attention_shared_prefix(q, k, v, k_shared, v_shared, shared_len, out, B, Sq, Sk, Hq, Hkv, ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso,
+                            q_pos0, scale):
+    """Causal attention (D = 128) of B x Sq question rows at positions q_pos0.. : key tiles below shared_len (a multiple of 64) come from
+    the scene's cache k_shared / v_shared, the rest from each question's own cache k / v + b bsk (v3d_attention_shared_prefix; every bit
+    equals attention() on B full copies)."""
+    check(lib().v3d_attention_shared_prefix(_p(q), _p(k), _p(v), _p(k_shared), _p(v_shared), int(shared_len), _p(out), _code(q), B, Sq, Sk, Hq, Hkv,
+                                            ldq, ldk, ldv, ldo, bsq, bsk, bso, hsq, hsk, hso, q_pos0, scale, _stream()),
+          "v3d_attention_shared_prefix")
+    return out
+
+
 def attention_bshd(q, k, v, causal, scale=None, q_pos0=0, d_out=None):
     """Convenience: q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (last dim contiguous) -> [B,Sq,Hq,d_out]."""
     B, Sq, Hq, D = q.shape
@@ -540,15 +551,19 @@ def rope_kv_append_rows(qkv, n_q, n_kv, hd, table, positions, cache_rows):
           "v3d_rope_kv_append_rows")
 
 
-def attention_decode_rows(q, k_caches, v_caches, out, sk, n_heads, n_kv_heads, scale, workspace, prefix=0):
+def attention_decode_rows(q, k_caches, v_caches, out, sk, n_heads, n_kv_heads, scale, workspace, prefix=0, prefix_kv=None):
     """q / out [M, Hq*128]; k_caches / v_caches: per-scene cache views [>=Sk, ...] sharing strides; sk: lengths.
     prefix > 0: the caches all start with the same `prefix` rows (questions about one scene): those keys are read from the
-    first cache for every row, the rest from each row's own cache (bit-identical outputs, the prefix is streamed once)."""
+    first cache for every row - or from prefix_kv = (k, v) views of the scene's own cache with the same strides, when the questions'
+    caches do not hold those rows at all - the rest from each row's own cache (bit-identical outputs, the prefix is streamed once)."""
     k0 = k_caches[0]
     if prefix > 0:
         if min(sk) < prefix:
             raise V3DError("attention_decode_rows: a scene is shorter than the shared prefix")
-        check(lib().v3d_attention_decode_rows_prefix(_p(q), q.stride(0), q.shape[0], _p(k0), _p(v_caches[0]), int(prefix), _host_ptrs(k_caches),
+        kp, vp = prefix_kv if prefix_kv is not None else (k0, v_caches[0])
+        if kp.stride(0) != k0.stride(0) or vp.stride(0) != v_caches[0].stride(0):
+            raise V3DError("attention_decode_rows: the prefix cache must share the row stride of the scenes' caches")
+        check(lib().v3d_attention_decode_rows_prefix(_p(q), q.stride(0), q.shape[0], _p(kp), _p(vp), int(prefix), _host_ptrs(k_caches),
                                                      _host_ptrs(v_caches), _host_ints(sk), _p(out), out.stride(0), _code(q), n_heads, n_kv_heads,
                                                      k0.stride(0), v_caches[0].stride(0), 128, 128, 128, float(scale), _p(workspace),
                                                      workspace.numel() * workspace.element_size(), _stream()), "v3d_attention_decode_rows_prefix")
