@@ -294,6 +294,13 @@ int v3d_linear_decode(const void* x, const void* norm_weight, float eps, const v
 int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W,
                            int64_t ldw, const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N,
                            int K, int dtype, int epilogue, void* stream);
+
+/* r04: 1 when v3d_linear_decode_rows with a norm_weight and M rows takes the matrix-core form that normalises the rows itself (more than
+ * four rows, K <= 4096, 9..32 K tiles of 128, no residual epilogue; the 1 / rms of a row is formed in v3d_rmsnorm's summation order for
+ * that many rows, so the result equals v3d_rmsnorm followed by the unfused call bit for bit), else 0: such a call is then refused for
+ * M > 4 and the caller normalises with v3d_rmsnorm first.  Host-only. */
+int v3d_linear_decode_rows_fuses_norm(int M, int N, int K, int epilogue);
+
 /* The decode linear over OCP e4m3 weights (BASELINE configs[3]; W8A16): W8 [N,K] bytes (row stride ldw) with one
  * f32 scale per output row as v3d_quantize_fp8_rows writes them; y[m,n] = scale_w[n] * sum_k W8[n,k] x[m,k], then
  * the epilogue of v3d_linear_decode.  K % 16 == 0.  M = 1: VALU form; M = 2..32 with K % 256 == 0, N % 16 == 0: matrix-core

@@ -702,6 +702,41 @@ def test_attention_shared_prefix_equals_attention_on_full_copies_bitwise(ops, dt
                                     o2.stride(0), got.stride(0), Sq * q.stride(0), own.stride(0), Sq * got.stride(0), hd, hd, hd, P, scale)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [5, 16, 17, 32])
+@pytest.mark.parametrize("K,N", [(1152, 256), (2048, 4608), (3584, 512), (3584, 37888 // 4)])
+def test_linear_decode_rows_fused_norm_equals_rmsnorm_then_linear_bitwise(ops, monkeypatch, dt, M, K, N):
+    """r04: with more than four rows the persistent decode linear forms Qwen2RMSNorm of its input rows itself (1 / rms in v3d_rmsnorm's
+    summation order for that many rows, weight * round(x * r) element by element): the bits of rmsnorm() followed by the unfused call,
+    for the bias, SwiGLU and plain epilogues (QKV, gate/up, LM head).  Not offered (the engine then normalises first): up to four rows
+    (VALU form, bit-identical to the one-row kernel), K > 4096, a residual epilogue, V3D_DEC_V2=0."""
+    g = torch.Generator().manual_seed(3 * M + K)
+    x = (torch.randn(M, K, generator=g) * 3).to(dt).cuda()
+    lnw = (1 + 0.1 * torch.randn(K, generator=g)).to(dt).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).cuda()
+    b = torch.randn(N, generator=g).to(dt).cuda()
+    monkeypatch.setenv("V3D_DEC_V2", "1")
+    for kw in (dict(), dict(bias=b, epilogue=ops.DEC_BIAS), dict(epilogue=ops.DEC_SWIGLU)):
+        swiglu = kw.get("epilogue") == ops.DEC_SWIGLU
+        if swiglu and N % 128:
+            continue
+        n_out = N // 2 if swiglu else N
+        assert ops.linear_decode_rows_fuses_norm(M, N, K, kw.get("epilogue", ops.DEC_NONE))
+        h = ops.rmsnorm(x, lnw, 1e-6)
+        want = torch.empty((M, n_out), dtype=dt, device="cuda")
+        ops.linear_decode_rows(h, w, want, **kw)
+        got = torch.full((M, n_out), 2.0, dtype=dt, device="cuda")
+        ops.linear_decode_rows(x, w, got, norm_weight=lnw, eps=1e-6, **kw)
+        assert torch.equal(got, want), (kw.get("epilogue"), M, K, N)
+    assert not ops.linear_decode_rows_fuses_norm(4, N, K)
+    assert not ops.linear_decode_rows_fuses_norm(M, N, 18944)
+    assert not ops.linear_decode_rows_fuses_norm(M, N, K, ops.DEC_RES)
+    monkeypatch.setenv("V3D_DEC_V2", "0")
+    assert not ops.linear_decode_rows_fuses_norm(M, N, K)
+    with pytest.raises(Exception, match="activation rows"):
+        ops.linear_decode_rows(x, w, torch.empty((M, N), dtype=dt, device="cuda"), norm_weight=lnw, eps=1e-6)
+
+
 def test_rope_kv_append_and_argmax(ops):
     dt = torch.bfloat16
     H, KV, D = 4, 2, 128

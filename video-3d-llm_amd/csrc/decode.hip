@@ -340,10 +340,15 @@ __device__ __forceinline__ int dec2_row0(int grp) {                      // firs
 }
 
 // NW = K tiles of THIS wave (the workgroup's waves hold NT or NT - 1: two instantiations of the loop, chosen once per wave)
-template <typename T, int EPI, int MB, int NW, bool SPLIT>
+// NORM: x holds the rows BEFORE Qwen2RMSNorm; the workgroup forms every row's 1 / rms itself - in the summation order v3d_rmsnorm uses
+// for more than four rows (rmsnorm_kernel's; the host sends up to four rows elsewhere), so the bits are those of the separate launch - and
+// normalises its resident fragments in registers (weight * round(x * r), element by element as the kernels do).  One launch less per
+// norm (a dependent launch costs >= 4.5 us here; the 32-row norm 7.3), for one more pass over the rows out of L2 per workgroup.
+template <typename T, int EPI, int MB, int NW, bool SPLIT, bool NORM = false>
 __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W, int64_t ldw,
                                          const T* __restrict__ bias, const T* __restrict__ res, int64_t ldr, T* __restrict__ out,
-                                         int64_t ldo, int groups, char* smem_, float* __restrict__ partial) {
+                                         int64_t ldo, int groups, char* smem_, float* __restrict__ partial,
+                                         const T* __restrict__ norm_w = nullptr, float eps = 0.f, int cols = 0, float* nrm_lds = nullptr) {
   constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;
   constexpr int PITCH = 272, TILE_B = 8 * SW * 16 * PITCH, PART_F = 8 * SW * MB * 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -364,6 +369,43 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
 #pragma unroll
       for (int t = 0; t < 4; ++t) xb[u][b][t] = *reinterpret_cast<const uint4*>(xr + 32 * t);
     }
+  if (NORM) {
+    float* rstd = nrm_lds;                                  // [32] 1 / rms per row
+    const int nv = cols / 8;
+    {                                                       // rmsnorm_kernel (more than four rows): one wave per row, lane l sums chunks l, l + 64, ...
+      for (int row = wave; row < M; row += 8) {
+        const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)row * ldx);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = i * 64 + lane;
+          if (k < nv) {
+            const uint4 v = xr[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(v, j); ss = fmaf(f, f, ss); }
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        if (lane == 0) rstd[row] = 1.0f / sqrtf(ss / (float)cols + eps);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(norm_w + 8 * g + 128 * (wave + 8 * u) + 32 * t);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          const float rr = rstd[r + 16 * b < M ? r + 16 * b : 0];
+          float y[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(wv, j) * round_to<T>(vec_get<T>(xb[u][b][t], j) * rr);
+          xb[u][b][t] = vec_pack<T>(y);
+        }
+      }
+  }
   const int my_groups = (groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const T* wlane = W + (int64_t)lr * ldw + 8 * lc + 128 * wave;
   int ig = 0, iu = 0;                                                    // issue cursor: (group of this workgroup, tile of this wave)
@@ -461,16 +503,18 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
   if (gi < my_groups) one_group(0, gi);
 }
 
-template <typename T, int EPI, int MB, int NT>
+template <typename T, int EPI, int MB, int NT, bool NORM = false>
 __global__ __launch_bounds__(512) void linear_decode_mfma2_kernel(const T* __restrict__ x, int64_t ldx, int M, const T* __restrict__ W,
                                                                   int64_t ldw, const T* __restrict__ bias, const T* __restrict__ res,
-                                                                  int64_t ldr, T* __restrict__ out, int64_t ldo, int K, int groups) {
+                                                                  int64_t ldr, T* __restrict__ out, int64_t ldo, int K, int groups,
+                                                                  const T* __restrict__ norm_w, float eps) {
   constexpr int SW = EPI == DEC_EPI_SWIGLU ? 2 : 1;
   __shared__ __attribute__((aligned(16))) char smem_[8 * SW * 16 * 272 + 2 * 8 * SW * MB * 256 * 4];
+  __shared__ float nrm_[NORM ? 48 : 1];
   const int wave = threadIdx.x >> 6;
   const int nt_w = (K / 128 - wave + 7) / 8;               // NT or NT - 1 (host: 8 (NT - 1) < tiles <= 8 NT)
-  if (nt_w == NT) dec2_run<T, EPI, MB, NT, false>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_, nullptr);
-  else dec2_run<T, EPI, MB, (NT > 1 ? NT - 1 : 1), false>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_, nullptr);
+  if (nt_w == NT) dec2_run<T, EPI, MB, NT, false, NORM>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_, nullptr, norm_w, eps, K, nrm_);
+  else dec2_run<T, EPI, MB, (NT > 1 ? NT - 1 : 1), false, NORM>(x, ldx, M, W, ldw, bias, res, ldr, out, ldo, groups, smem_, nullptr, norm_w, eps, K, nrm_);
 }
 
 // K > 4096 (down_proj, K = 18944): the activation fragments of a whole row of tiles do not fit the registers, and streamed per tile they
@@ -816,6 +860,28 @@ static float* decode_split_workspace(hipStream_t st, size_t bytes) {
   return static_cast<float*>(b.p);
 }
 
+// Does a product with n_out outputs over K take the persistent matrix-core form (linear_decode_mfma2_kernel), and on how many workgroups?
+// V3D_DEC_V2 (read per call: the tests switch it inside one process) = 0: never; 1 (default) / 2: where the shape allows (9..32 K tiles:
+// 2..4 per wave, none without one); 3: the streaming form instead (tests, A/B).  The grid is balanced: ceil(groups / rounds) workgroups
+// with rounds = ceil(groups / CUs), so every workgroup walks the same number of groups (288 groups: 144 x 2, not 224 x 1 + 32 x 2).
+static bool dec_v2_plan(int n_out, int K, int* grid, int* v2_env_out, int* cus_out) {
+  static int cus = 0;
+  const char* v2e = getenv("V3D_DEC_V2");
+  const int v2_env = v2e ? atoi(v2e) : 1;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  if (v2_env_out) *v2_env_out = v2_env;
+  if (cus_out) *cus_out = cus;
+  const int tiles = K / 128, groups16 = n_out / 16;
+  if (K % 128 != 0 || n_out % 16 != 0 || groups16 < 1) return false;
+  const int rounds = (groups16 + cus - 1) / cus;
+  if (grid) *grid = (groups16 + rounds - 1) / rounds;
+  return v2_env >= 1 && v2_env <= 2 && tiles >= 9 && tiles <= 32;
+}
+
 static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W, int64_t ldw,
                               const void* bias, const void* res, int64_t ldr, void* out, int64_t ldo, int N, int K, int dtype,
                               int epilogue, void* stream, const char* who) {
@@ -826,7 +892,13 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
   // not grow with M and whose columns are independent - a scene's bits are the same in every group of two or more.
   // (Against the one-row form the values differ by the f32 summation order.)  Shapes the matrix-core form does not take
   // fall back to the VALU form with up to 4 rows.
-  const bool mfma_ok = !norm_weight && K % 128 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
+  // r04: with norm_weight and MORE than four rows the persistent matrix-core form normalises its resident fragments itself (where that
+  // form applies: v3d_linear_decode_rows_fuses_norm); up to four rows keep the VALU form, whose rows equal the one-row kernel's bit for bit.
+  int v2_grid = 0, v2_env = 1, cus = 256;
+  const bool mfma_shape = K % 128 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
+  const bool v2_ok = mfma_shape && dec_v2_plan(epilogue == DEC_EPI_SWIGLU ? N / 2 : N, K, &v2_grid, &v2_env, &cus);
+  const bool fused_norm = norm_weight && M > 4 && v2_ok && epilogue != DEC_EPI_RES;
+  const bool mfma_ok = mfma_shape && (!norm_weight || fused_norm);
   const bool mfma = mfma_ok && M >= 2;
   V3D_REQUIRE(M >= 1 && M <= (mfma_ok ? DEC_MAX_ROWS : 4), "%s: 1 to %d activation rows for this shape (got %d)", who, mfma_ok ? DEC_MAX_ROWS : 4, M);
   V3D_REQUIRE(N % 4 == 0 && (epilogue != DEC_EPI_SWIGLU || N % 128 == 0), "%s: N=%d not supported", who, N);
@@ -847,21 +919,13 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
     // r04, second session: the pipelined forms (linear_decode_mfma2_kernel / _stream_kernel above; bit-identical outputs).  V3D_DEC_V2 = 0: never;
     // 1 (default): where measured faster (tools/time_decode_rows.py, profiles/r04_decode_rows.txt); 2: wherever the shape allows (tests);
     // 3: the streaming form wherever the shape allows (tests, A/B).
-    static int cus = 0;
-    const char* v2e = getenv("V3D_DEC_V2");                 // read per call: the tests switch it inside one process
-    const int v2_env = v2e ? atoi(v2e) : 1;
-    if (cus == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (cus <= 0) cus = 256;
-    }
     const int tiles = K / 128, groups16 = n_out / 16, nt = (tiles + 7) / 8;
-    const bool v2_shape = tiles >= 9 && tiles <= 32;                       // 2..4 K tiles per wave, none without a tile
-    const bool v2_rule = v2_env >= 2 || groups16 <= cus || groups16 >= 4 * cus;     // persistent workgroups: whole rounds or many of them
-    if (v2_env >= 1 && v2_env <= 2 && v2_shape && v2_rule) {
-      const int grid = groups16 < cus ? groups16 : cus;
-#define V3D_LD2_K(TT, EE, BB, NN) hipLaunchKernelGGL((linear_decode_mfma2_kernel<TT, EE, BB, NN>), dim3(grid), dim3(512), 0, st, (const TT*)x, ldx, M, \
-                                                     (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, K, groups16)
+    if (v2_ok) {
+      const int grid = v2_grid;
+      const bool nrm = fused_norm;
+#define V3D_LD2_L(TT, EE, BB, NN, RR) hipLaunchKernelGGL((linear_decode_mfma2_kernel<TT, EE, BB, NN, RR>), dim3(grid), dim3(512), 0, st, (const TT*)x, ldx, M, \
+                                                     (const TT*)W, ldw, (const TT*)bias, (const TT*)res, ldr, (TT*)out, ldo, K, groups16, (const TT*)norm_weight, eps)
+#define V3D_LD2_K(TT, EE, BB, NN) do { if (nrm && EE != DEC_EPI_RES) V3D_LD2_L(TT, (EE == DEC_EPI_RES ? DEC_EPI_NONE : EE), BB, NN, true); else V3D_LD2_L(TT, EE, BB, NN, false); } while (0)
 #define V3D_LD2_N(TT, EE, BB) { if (nt == 2) V3D_LD2_K(TT, EE, BB, 2); else if (nt == 3) V3D_LD2_K(TT, EE, BB, 3); else V3D_LD2_K(TT, EE, BB, 4); }
 #define V3D_LD2_B(TT, EE) { if (M <= 16) V3D_LD2_N(TT, EE, 1) else V3D_LD2_N(TT, EE, 2) }
 #define V3D_LD2_E(TT)                                                                                 \
@@ -875,6 +939,7 @@ static int linear_decode_rows(const void* x, int64_t ldx, int M, const void* nor
 #undef V3D_LD2_B
 #undef V3D_LD2_N
 #undef V3D_LD2_K
+#undef V3D_LD2_L
       return check_launch(who);
     }
     if (v2_env >= 1 && v2_env <= 2 && tiles > 32 && epilogue != DEC_EPI_SWIGLU) {        // K cut into chunks whose activation fragments stay in registers
@@ -976,6 +1041,14 @@ extern "C" int v3d_linear_decode(const void* x, const void* norm_weight, float e
                                  const void* bias, const void* res, void* out, int N, int K, int dtype, int epilogue,
                                  void* stream) {
   return linear_decode_rows(x, 0, 1, norm_weight, eps, W, ldw, bias, res, 0, out, 0, N, K, dtype, epilogue, stream, "v3d_linear_decode");
+}
+
+extern "C" int v3d_linear_decode_rows_fuses_norm(int M, int N, int K, int epilogue) {
+  const char* off = getenv("V3D_DEC_FUSE_NORM");           // "0": callers normalise first (A/B)
+  if (off && atoi(off) == 0) return 0;
+  const bool mfma_shape = K % 128 == 0 && (epilogue == DEC_EPI_SWIGLU ? N % 128 == 0 : N % 16 == 0);
+  return (M > 4 && M <= DEC_MAX_ROWS && K <= 4096 && epilogue != DEC_EPI_RES && mfma_shape &&
+          dec_v2_plan(epilogue == DEC_EPI_SWIGLU ? N / 2 : N, K, nullptr, nullptr, nullptr)) ? 1 : 0;
 }
 
 extern "C" int v3d_linear_decode_rows(const void* x, int64_t ldx, int M, const void* norm_weight, float eps, const void* W,

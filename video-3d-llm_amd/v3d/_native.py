@@ -66,6 +66,7 @@ SIGNATURES = {
     "v3d_linear_decode": (c_i, [c_p, c_p, c_f, c_p, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "v3d_rmsnorm_quantize_fp8": (c_i, [c_p, c_l, c_p, c_f, c_l, c_i, c_i, c_p, c_l, c_p, c_p]),
     "v3d_linear_decode_fp8_rows": (c_i, [c_p, c_l, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
+    "v3d_linear_decode_rows_fuses_norm": (c_i, [c_i, c_i, c_i, c_i]),
     "v3d_linear_decode_rows": (c_i, [c_p, c_l, c_i, c_p, c_f, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
     "v3d_rope_kv_append": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     "v3d_preprocess_rgb_u8": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, ctypes.c_double, c_p, c_i, c_p]),

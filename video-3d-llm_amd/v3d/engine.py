@@ -871,23 +871,32 @@ class Engine:
         else:
             def lin(a, L, key, out, **kw):
                 return ops.linear_decode_rows(a, L[key], out, **kw)
+        # r04: with more than four rows the persistent decode linear forms the RMSNorm of its input rows itself (the bits of rmsnorm() +
+        # the unfused call: ops.linear_decode_rows_fuses_norm) - two launches fewer per layer and one before the LM head
+        def norm_lin(a, nw, w, out, **kw):
+            if not self.llm_fp8 and ops.linear_decode_rows_fuses_norm(M, w.shape[0], w.shape[1], kw.get("epilogue", ops.DEC_NONE)):
+                return ops.linear_decode_rows(a, w, out, norm_weight=nw, eps=l.eps, **kw)
+            return None
         for i, L in enumerate(self.l_layers):
             caches = [c.kv[i] for c in ctxs]
-            ops.rmsnorm(x, L["ln1"], l.eps, out=h)
-            lin(h, L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
+            if norm_lin(x, L["ln1"], L.get("wqkv"), qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS) is None:
+                ops.rmsnorm(x, L["ln1"], l.eps, out=h)
+                lin(h, L, "wqkv", qkv, bias=L["bqkv"], epilogue=ops.DEC_BIAS)
             ops.rope_kv_append_rows(qkv, nh, nkv, hd, self.rope, positions, [c[p] for c, p in zip(caches, positions)])
             ops.attention_decode_rows(qkv, caches, [c[:, kvw:] for c in caches], att, sk, nh, nkv, scale, g.ws, prefix=shared_prefix,
                                       prefix_kv=(prefix_kv[i], prefix_kv[i][:, kvw:]) if prefix_kv is not None and shared_prefix else None)
             lin(att, L, "wo", x, res=x, epilogue=ops.DEC_RES)
-            ops.rmsnorm(x, L["ln2"], l.eps, out=h)
-            lin(h, L, "wgu", act, epilogue=ops.DEC_SWIGLU)
+            if norm_lin(x, L["ln2"], L.get("wgu"), act, epilogue=ops.DEC_SWIGLU) is None:
+                ops.rmsnorm(x, L["ln2"], l.eps, out=h)
+                lin(h, L, "wgu", act, epilogue=ops.DEC_SWIGLU)
             lin(act, L, "wd", x, res=x, epilogue=ops.DEC_RES)
         for c, p in zip(ctxs, positions):
             c.kv_len = p + 1
-        ops.rmsnorm(x, self.l_norm, l.eps, out=g.last[:M])
         if self.llm_fp8:
+            ops.rmsnorm(x, self.l_norm, l.eps, out=g.last[:M])
             ops.linear_decode_fp8_rows(g.last[:M], *self.l_head8, g.logits[:M])
-        else:
+        elif norm_lin(x, self.l_norm, self.l_head, g.logits[:M]) is None:
+            ops.rmsnorm(x, self.l_norm, l.eps, out=g.last[:M])
             ops.linear_decode_rows(g.last[:M], self.l_head, g.logits[:M])
         return g.logits[:M, : l.vocab]
 

@@ -521,6 +521,12 @@ def linear_decode_rows(x, w, out, norm_weight=None, eps=1e-6, bias=None, res=Non
     return out
 
 
+def linear_decode_rows_fuses_norm(M, N, K, epilogue=DEC_NONE):
+    """True when linear_decode_rows(x [M, K], w [N, K], norm_weight=...) normalises the rows inside the matrix-core launch (bit-identical
+    to rmsnorm() + the unfused call); otherwise normalise with rmsnorm() first (v3d_linear_decode_rows_fuses_norm)."""
+    return bool(lib().v3d_linear_decode_rows_fuses_norm(int(M), int(N), int(K), int(epilogue)))
+
+
 def linear_decode_fp8_rows(x, qw, sw, out, bias=None, res=None, epilogue=DEC_NONE):
     """x [M, K] 16-bit rows against e4m3 weights qw [N, K] (uint8) with row scales sw [N] (W8A16 decode, configs[3])."""
     N, K = qw.shape
