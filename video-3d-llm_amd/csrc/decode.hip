@@ -357,6 +357,31 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
   auto part = [&](int pb, int w, int q, int b_) -> float* {
     return reinterpret_cast<float*>(smem_ + TILE_B) + (size_t)pb * PART_F + (size_t)((w * SW + q) * MB + b_) * 256;
   };
+  if (NORM) {   // the rows' 1 / rms first: wave w takes rows w, w + 8, w + 16, w + 24, all their loads in flight together (one round trip)
+    float* rstd = nrm_lds;                                  // [32]
+    const int nv = cols / 8;
+    uint4 sv[4][8];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = wave + 8 * rr;
+      const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)(row < M ? row : 0) * ldx);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int k = i * 64 + lane; sv[rr][i] = xr[k < nv ? k : 0]; }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {                        // rmsnorm_kernel's order: lane l sums chunks l, l + 64, ... , then the wave
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i * 64 + lane < nv) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(sv[rr][i], j); ss = fmaf(f, f, ss); }
+        }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+      if (lane == 0 && wave + 8 * rr < M) rstd[wave + 8 * rr] = 1.0f / sqrtf(ss / (float)cols + eps);
+    }
+  }
   // resident activation fragments of this wave's K slice
   uint4 xb[NW][MB][4];
 #pragma unroll
@@ -370,41 +395,27 @@ __device__ __forceinline__ void dec2_run(const T* __restrict__ x, int64_t ldx, i
       for (int t = 0; t < 4; ++t) xb[u][b][t] = *reinterpret_cast<const uint4*>(xr + 32 * t);
     }
   if (NORM) {
-    float* rstd = nrm_lds;                                  // [32] 1 / rms per row
-    const int nv = cols / 8;
-    {                                                       // rmsnorm_kernel (more than four rows): one wave per row, lane l sums chunks l, l + 64, ...
-      for (int row = wave; row < M; row += 8) {
-        const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)row * ldx);
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int k = i * 64 + lane;
-          if (k < nv) {
-            const uint4 v = xr[k];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = vec_get<T>(v, j); ss = fmaf(f, f, ss); }
-          }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-        if (lane == 0) rstd[row] = 1.0f / sqrtf(ss / (float)cols + eps);
-      }
-    }
-    __syncthreads();
+    float* rstd = nrm_lds;
+    uint4 wv[NW][4];                                        // the norm weights of this wave's K slice: requested before the rendezvous
 #pragma unroll
     for (int u = 0; u < NW; ++u)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint4 wv = *reinterpret_cast<const uint4*>(norm_w + 8 * g + 128 * (wave + 8 * u) + 32 * t);
+      for (int t = 0; t < 4; ++t) wv[u][t] = *reinterpret_cast<const uint4*>(norm_w + 8 * g + 128 * (wave + 8 * u) + 32 * t);
+    __syncthreads();
+    float rr[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) rr[b] = rstd[r + 16 * b < M ? r + 16 * b : 0];
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int b = 0; b < MB; ++b) {
-          const float rr = rstd[r + 16 * b < M ? r + 16 * b : 0];
           float y[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(wv, j) * round_to<T>(vec_get<T>(xb[u][b][t], j) * rr);
+          for (int j = 0; j < 8; ++j) y[j] = vec_get<T>(wv[u][t], j) * round_to<T>(vec_get<T>(xb[u][b][t], j) * rr[b]);
           xb[u][b][t] = vec_pack<T>(y);
         }
-      }
   }
   const int my_groups = (groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
   const T* wlane = W + (int64_t)lr * ldw + 8 * lc + 128 * wave;
