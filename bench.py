@@ -341,7 +341,7 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reus
                  "upload_mb_per_question": (FRAMES * (1296 * 968 * 3 + 640 * 480 * 2)) / 1e6, "dataset_write_s": t_write}
         # ---- scene reuse on the pipeline, from the same files: consecutive questions per scene
         QPS = reuse_questions_per_scene
-        n_sc = min(n_scenes, 4)
+        n_sc = min(n_scenes, 8)      # (the first scene's prefill is exposed in any run: over 8 scenes it is an eighth of the prefills, over r04's 4 a quarter)
         rq = [question(1000 + sc * QPS + j, n_words, sc, salt=3 * j + sc) for sc in range(n_sc) for j in range(QPS)]
         rstats = {}
         rfn = E.model_answer_fn(model, tok, SigLipImageProcessor(), vp, "bench", FRAMES, NEW_TOKENS, reuse_scenes=True, pipeline=True, stats=rstats,
