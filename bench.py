@@ -203,6 +203,60 @@ def measure_cached_questions(eng, ops, scene_inp, dev, n_groups, group=16, q_len
     return n_groups * group / dt_s, t_scene * 1e3
 
 
+def measure_decode_step(eng, ops, scenes, dev, steps=8):
+    """The decode step (one new token per row: four weight-streaming linears per layer + the LM head, rotary / append, split-KV attention)
+    against its HBM roofline, in the two forms the product runs: 16 rows = 16 SCENES decoding together, each over its own K/V cache (the
+    headline's decode groups), and 32 rows = 32 QUESTIONS about one scene, the prefix K/V read once for all of them (answer batches).
+    Algorithmic bytes per step = the decoder's linear weights + the LM head + the K/V rows the step attends over, each once."""
+    l = eng.cfg.llm
+    wbytes = sum(L[k].numel() * L[k].element_size() for L in eng.l_layers for k in ("wqkv", "wo", "wgu", "wd")) + eng.l_head.numel() * eng.l_head.element_size()
+    kv_row = 2 * l.kv_heads * eng.hd * 2 * l.layers                      # bytes of one position's K and V over all layers
+
+    def timed(fn):
+        fn(0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            fn(1 + i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    out = {"what": "one decode step against its HBM roofline (weights + attended K/V rows once per step; peak 8 TB/s): rows16 = 16 scenes over their own "
+                   "caches (the headline's decode groups), rows32_shared_prefix = 32 questions about one prefilled scene (answer batches)"}
+    keep = eng.ctx
+    # ---- 32 questions about the scene in eng.ctx (prefilled by measure_cached_questions): their caches hold the question rows
+    P = keep.prefix_len
+    st = eng._answer_state(32)
+    ctxs = st.ctxs[:32]
+    base = [P + TEXT_POST] * 32
+    ms = timed(lambda i: eng.decode_forward_rows(st.rows, ctxs, [b + i for b in base], shared_prefix=P, prefix_kv=keep.kv))
+    nbytes = wbytes + (P + 32 * (TEXT_POST + steps // 2)) * kv_row
+    out["rows32_shared_prefix"] = {"ms_per_step": ms, "bytes": nbytes, "achieved_TBps": nbytes / ms / 1e9, "frac_of_8TBps": nbytes / ms / 1e9 / 8.0}
+    # ---- 16 scenes, each prefilled into its own context
+    pool = [eng.new_context() for _ in range(16)]
+    grp = eng.new_group(16)
+    S = 0
+    try:
+        for i, c in enumerate(pool):
+            inp = scenes[i % len(scenes)]
+            eng.use(c)
+            feats = eng.encode_images(ops.preprocess_rgb(inp["frames"], eng.dtype))
+            ids = eng.voxel_ids(ops.unproject_sampled(inp["depth"], inp["K"], inp["P"], 384, eng.dtype).to(eng.dtype))
+            x = eng.build_inputs_embeds(inp["input_ids"], feats, ids)
+            S = x.shape[0]
+            eng.llm_forward(x, 0, last_rows=[S - 1])
+    finally:
+        eng.use(keep)
+    ms = timed(lambda i: eng.decode_forward_rows(grp, pool, [S + i] * 16))
+    nbytes = wbytes + 16 * (S + steps // 2) * kv_row
+    out["rows16"] = {"ms_per_step": ms, "bytes": nbytes, "achieved_TBps": nbytes / ms / 1e9, "frac_of_8TBps": nbytes / ms / 1e9 / 8.0}
+    del pool, grp
+    torch.cuda.empty_cache()
+    return out
+
+
 def measure_grounding(eng, ops, scenes, dev, steps):
     """BASELINE configs[2] on one GPU: the ScanRefer / Multi3DRefer forward (model_scanrefer.py:165-173): geometry, ViT, projector,
     object-proposal patch masks + masked means for 50 proposals (extract_pred_box.py:30), fusion, Qwen2 prefill, infonce head."""
@@ -629,6 +683,10 @@ def main():
                     "per question run over the cached prefix of %d rows, %d questions per batch, %d new tokens each; the one-off scene prefill "
                     "is reported beside it" % (TEXT_POST, TEXT_PRE + FRAMES * 210, AB, NEW_TOKENS),
             "value": nq, "unit": "questions/s", "scene_prefill_ms": scene_ms}
+        try:
+            extras["decode_step"] = measure_decode_step(eng, ops, scenes, dev)
+        except Exception as e:                          # an extra must never take the headline line down with it
+            extras["decode_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             extras["eval_runner"], extras["reuse_runner"] = measure_eval_runner(eng, dev, max(48, 3 * a.steps), loader_pool, n_workers)
             extras["reuse_runner"]["vs_cached_questions"] = extras["reuse_runner"]["value"] / nq
