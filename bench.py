@@ -415,6 +415,14 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reus
                          "scene already prefilled, inputs resident)" % (n_sc, QPS, at + FRAMES * 210, len(ids0) - 1 - at, NEW_TOKENS),
                  "value": len(rq) / rdt, "unit": "questions/s", "ms_per_question": rdt / len(rq) * 1e3, "questions": len(rq), "scenes": n_sc,
                  "questions_per_scene": QPS, "gpu_waited_for_loader_ms_per_scene": rstats["loader_wait_seconds"] / n_sc * 1e3}
+        # ScanQA val holds about 66 questions per scene (4675 questions, 71 scenes): the same run at 64 per scene (two answer batches of 32 per prefill)
+        rq64 = [question(5000 + sc * 64 + j, n_words, sc, salt=5 * j + sc) for sc in range(n_sc) for j in range(64)]
+        t0 = time.perf_counter()
+        rrecs = rfn(rq64)
+        torch.cuda.synchronize()
+        rdt = time.perf_counter() - t0
+        assert len(rrecs) == len(rq64)
+        reuse["at_64_questions_per_scene"] = {"value": len(rq64) / rdt, "unit": "questions/s", "questions": len(rq64), "scenes": n_sc}
         return plain, reuse
     finally:
         shutil.rmtree(root, ignore_errors=True)
