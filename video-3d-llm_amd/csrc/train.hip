@@ -243,25 +243,30 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 // A workgroup takes 32 rows (a wave per row, eight rounds); the dw contributions of its rows are summed per lane in f32 (rows in
 // order within a wave, the four waves through LDS in order) and leave as one partial row.
 constexpr int TG_MAXV = 7;
-template <typename T>
+// r04: MAXV = 16-byte vectors per lane and row the instantiation can hold (3: rows up to 1536 elements, 7: up to 3584).  The one-size kernel kept
+// 7 x 8 f32 partial sums + 2 x 7 row vectors per lane whatever the width, ran at ONE wave per SIMD (256+ registers), and a wave walks its eight
+// rows one after the other through three dependent reductions each: 178 us for 6794 x 3584 (0.8 TB/s).  Narrow rows now take the small form, and
+// both are held to two (wide) / four (narrow) waves per SIMD; a row's arithmetic and the order of the partial sums are unchanged (bit-identical).
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void rmsnorm_grad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, const T* __restrict__ dy,
                                                            int64_t ldy, const T* __restrict__ add, int64_t lda, T* __restrict__ dx, int64_t ldd,
                                                            float* __restrict__ partial, int64_t rows, int cols, float eps) {
   extern __shared__ float red[];              // [4][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = cols / 8;
-  float dwp[TG_MAXV][8];
+  float dwp[MAXV][8];
 #pragma unroll
-  for (int i = 0; i < TG_MAXV; ++i)
+  for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) dwp[i][j] = 0.f;
+#pragma unroll 1   // (unrolled, hipcc hoists every round's loads and spills: one row's registers at a time, the waves per SIMD cover the latency)
   for (int round = 0; round < TG_RPB / 4; ++round) {
     const int64_t row = (int64_t)blockIdx.x * TG_RPB + round * 4 + wave;
     if (row >= rows) break;
-    uint4 xv[TG_MAXV], gv[TG_MAXV];
+    uint4 xv[MAXV], gv[MAXV];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < TG_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv) {
         xv[i] = *reinterpret_cast<const uint4*>(x + row * ldx + k * 8);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(256) void rmsnorm_grad_kernel(const T* __restrict__
     const float r = 1.0f / sqrtf(ss / (float)cols + eps);
     float dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < TG_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv) {
         const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void rmsnorm_grad_kernel(const T* __restrict__
     }
     dot = wave_sum_f(dot) / (float)cols;
 #pragma unroll
-    for (int i = 0; i < TG_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv) {
         const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256) void rmsnorm_grad_kernel(const T* __restrict__
     }
   }
 #pragma unroll
-  for (int i = 0; i < TG_MAXV; ++i) {
+  for (int i = 0; i < MAXV; ++i) {
     const int k = i * 64 + lane;
     if (k < nv)
 #pragma unroll
@@ -574,25 +579,26 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ z, int6
 // dx = rstd (g - mean(g) - xh mean(g xh)) [+ add],  dw = sum_rows dy xh,  db = sum_rows dy.   Same shape as rmsnorm_grad_kernel:
 // 32 rows per workgroup, their dw / db contributions leave as one partial row each (partial_b follows partial_w's n_part rows).
 constexpr int LN_MAXV = 7;       // cols <= 3584 (the grounding heads' LayerNorm is as wide as the LLM)
-template <typename T>
+template <typename T, int MAXV>       // MAXV, occupancy: see rmsnorm_grad_kernel
 __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w, const T* __restrict__ dy,
                                                              int64_t ldy, const T* __restrict__ add, int64_t lda, T* __restrict__ dx, int64_t ldd,
                                                              float* __restrict__ partial_w, float* __restrict__ partial_b, int64_t rows, int cols, float eps) {
   extern __shared__ float red[];              // [2][4][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = cols / 8;
-  float dwp[LN_MAXV][8], dbp[LN_MAXV][8];
+  float dwp[MAXV][8], dbp[MAXV][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i)
+  for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dwp[i][j] = 0.f; dbp[i][j] = 0.f; }
+#pragma unroll 1   // (unrolled, hipcc hoists every round's loads and spills: one row's registers at a time, the waves per SIMD cover the latency)
   for (int round = 0; round < TG_RPB / 4; ++round) {
     const int64_t row = (int64_t)blockIdx.x * TG_RPB + round * 4 + wave;
     if (row >= rows) break;
-    uint4 xv[LN_MAXV], gv[LN_MAXV];
+    uint4 xv[MAXV], gv[MAXV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv) {
         xv[i] = *reinterpret_cast<const uint4*>(x + row * ldx + k * 8);
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict
     const float mean = wave_sum_f(sum) / (float)cols;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv)
 #pragma unroll
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict
     const float rstd = 1.0f / sqrtf(wave_sum_f(q) / (float)cols + eps);
     float sg = 0.f, sgx = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv) {
         const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict
     sg = wave_sum_f(sg) / (float)cols;
     sgx = wave_sum_f(sgx) / (float)cols;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
       const int k = i * 64 + lane;
       if (k < nv) {
         const uint4 wv = *reinterpret_cast<const uint4*>(w + k * 8);
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(256) void layernorm_grad_kernel(const T* __restrict
     }
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < MAXV; ++i) {
     const int k = i * 64 + lane;
     if (k < nv)
 #pragma unroll
@@ -927,8 +933,12 @@ extern "C" int v3d_rmsnorm_grad(const void* x, int64_t ldx, const void* weight, 
   V3D_REQUIRE(n_part < (1ll << 31), "v3d_rmsnorm_grad: too many rows");
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)4 * cols * sizeof(float);
-  V3D_DISPATCH_HALF(dtype, hipLaunchKernelGGL(rmsnorm_grad_kernel<T>, dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight,
-                                              (const T*)dy, ldy, (const T*)add, lda, (T*)dx, ldd, workspace, rows, cols, eps));
+  V3D_DISPATCH_HALF(dtype, {
+    if (cols <= 3 * 512) hipLaunchKernelGGL((rmsnorm_grad_kernel<T, 3>), dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight,
+                                            (const T*)dy, ldy, (const T*)add, lda, (T*)dx, ldd, workspace, rows, cols, eps);
+    else hipLaunchKernelGGL((rmsnorm_grad_kernel<T, TG_MAXV>), dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight,
+                            (const T*)dy, ldy, (const T*)add, lda, (T*)dx, ldd, workspace, rows, cols, eps);
+  });
   if (int e = check_launch("v3d_rmsnorm_grad")) return e;
   return colsum_final(workspace, n_part, cols, dweight, dw_dtype, st, "v3d_rmsnorm_grad");
 }
@@ -1063,12 +1073,15 @@ extern "C" int v3d_layernorm_grad(const void* x, int64_t ldx, const void* weight
   V3D_DISPATCH_HALF(dtype, {
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)layernorm_grad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * LN_MAXV * 512 * 4);
+      hipError_t e = hipFuncSetAttribute((const void*)layernorm_grad_kernel<T, LN_MAXV>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * LN_MAXV * 512 * 4);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)layernorm_grad_kernel<T, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 512 * 4);
       if (e != hipSuccess) { set_error("v3d_layernorm_grad: LDS attribute: %s", hipGetErrorString(e)); return V3D_E_LAUNCH; }
       attr_done = true;
     }
-    hipLaunchKernelGGL(layernorm_grad_kernel<T>, dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight, (const T*)dy, ldy,
-                       (const T*)add, lda, (T*)dx, ldd, pw, pb, rows, cols, eps);
+    if (cols <= 3 * 512) hipLaunchKernelGGL((layernorm_grad_kernel<T, 3>), dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight,
+                                            (const T*)dy, ldy, (const T*)add, lda, (T*)dx, ldd, pw, pb, rows, cols, eps);
+    else hipLaunchKernelGGL((layernorm_grad_kernel<T, LN_MAXV>), dim3((unsigned)n_part), dim3(256), lds, st, (const T*)x, ldx, (const T*)weight,
+                            (const T*)dy, ldy, (const T*)add, lda, (T*)dx, ldd, pw, pb, rows, cols, eps);
   });
   if (int e = check_launch("v3d_layernorm_grad")) return e;
   if (int e = colsum_final(pw, n_part, cols, dweight, dw_dtype, st, "v3d_layernorm_grad")) return e;
