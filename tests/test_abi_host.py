@@ -37,6 +37,27 @@ def test_invalid_arguments_report_an_error():
         ops.uniform_frame_indices(0, 4)
 
 
+def test_linear_decode_rows_fuses_norm_is_a_host_rule(monkeypatch):
+    """r04: which v3d_linear_decode_rows calls take a norm_weight with more than four rows (host-only query; no GPU call): more than four and
+    at most 32 rows, 9..32 K tiles of 128 (K <= 4096), outputs in 16-row groups (SwiGLU: 128-row gate|up tiles), no residual epilogue - and
+    never with V3D_DEC_V2=0 / 3 (the other kernels) or V3D_DEC_FUSE_NORM=0."""
+    monkeypatch.delenv("V3D_DEC_V2", raising=False)
+    monkeypatch.delenv("V3D_DEC_FUSE_NORM", raising=False)
+    f = ops.linear_decode_rows_fuses_norm
+    assert f(32, 4608, 3584, ops.DEC_BIAS) and f(5, 37888, 3584, ops.DEC_SWIGLU) and f(16, 152064, 3584) and f(8, 256, 1152)
+    assert not f(4, 4608, 3584) and not f(33, 4608, 3584)                      # row count
+    assert not f(32, 3584, 18944) and not f(32, 4608, 1024) and not f(32, 4608, 3592)      # K: too long, 8 tiles, not a multiple of 128
+    assert not f(32, 4600, 3584) and not f(32, 37888 + 64, 3584, ops.DEC_SWIGLU)           # N
+    assert not f(32, 3584, 3584, ops.DEC_RES)
+    for v in ("0", "3"):
+        monkeypatch.setenv("V3D_DEC_V2", v)
+        assert not f(32, 4608, 3584)
+    monkeypatch.setenv("V3D_DEC_V2", "2")
+    assert f(32, 4608, 3584)
+    monkeypatch.setenv("V3D_DEC_FUSE_NORM", "0")
+    assert not f(32, 4608, 3584)
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     with pytest.raises(_native.V3DError, match="no CPU path"):
