@@ -393,6 +393,8 @@ def measure_eval_runner(eng, dev, n_questions, pool, n_workers, n_scenes=8, reus
                  "loader_core_ms_per_question": per_q, "gpu_waited_for_loader_ms_per_question": stats["loader_wait_seconds"] / n_questions * 1e3,
                  "upload_enqueue_ms_per_question": stats["upload_enqueue_seconds"] / n_questions * 1e3,
                  "upload_mb_per_question": (FRAMES * (1296 * 968 * 3 + 640 * 480 * 2)) / 1e6, "dataset_write_s": t_write}
+        if os.environ.get("V3D_BENCH_SKIP_REUSE") == "1":      # (development: the eval_runner part alone, e.g. under a kernel trace)
+            return plain, {"skipped": True}
         # ---- scene reuse on the pipeline, from the same files: consecutive questions per scene
         QPS = reuse_questions_per_scene
         n_sc = min(n_scenes, 8)      # (the first scene's prefill is exposed in any run: over 8 scenes it is an eighth of the prefills, over r04's 4 a quarter)
